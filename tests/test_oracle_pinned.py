@@ -1,0 +1,127 @@
+"""Oracle (oracle/audiogan_oracle.py) vs vectors produced by the REFERENCE'S OWN
+definitions (oracle/pin_reference.py -> tests/golden/ref_*.npz).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import audiogan_oracle as O
+
+RTOL, ATOL = 1e-5, 1e-6  # same math on the same torch CPU kernels; only op-order differs
+
+
+def _load(golden_dir, name):
+    return dict(np.load(os.path.join(golden_dir, name)))
+
+
+def _sd(v, prefix='sd.'):
+    return {k[len(prefix):]: torch.from_numpy(a) for k, a in v.items() if k.startswith(prefix)}
+
+
+def _check_grads(module, v):
+    for k, p in module.named_parameters():
+        ref = v['grad.' + k]
+        got = p.grad.numpy() if p.grad is not None else np.zeros_like(ref)
+        np.testing.assert_allclose(got, ref, rtol=1e-4, atol=1e-5, err_msg=k)
+
+
+def test_helpers(golden_dir):
+    v = _load(golden_dir, 'ref_helpers.npz')
+    x, t = torch.from_numpy(v['x']), torch.from_numpy(v['target'])
+    lens = torch.from_numpy(v['lengths'])
+    w = O.length_mask((5, 9), lens)
+    np.testing.assert_array_equal(w.numpy(), v['mask'])
+    np.testing.assert_allclose(O.binary_cross_entropy_with_logits_per_sample(x, t).numpy(),
+                               v['bce'], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(
+        O.binary_cross_entropy_with_logits_per_sample(x, t, weight=w).numpy(), v['bce_w'],
+        rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(O.log_sigmoid(x).numpy(), v['log_sigmoid'], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(O.log_one_minus_sigmoid(x).numpy(), v['log_one_minus_sigmoid'],
+                               rtol=RTOL, atol=ATOL)
+    np.testing.assert_array_equal([O.div_roundup(a, 7) for a in range(30)], v['div_roundup'])
+    np.testing.assert_array_equal([O.roundup(a, 7) for a in range(30)], v['roundup'])
+    with pytest.raises(ValueError):
+        O.binary_cross_entropy_with_logits_per_sample(x, t[:, :3])
+
+
+def test_clip_grad(golden_dir):
+    v = _load(golden_dir, 'ref_clip_grad.npz')
+    ps = []
+    for i in range(3):
+        p = torch.nn.Parameter(torch.zeros(v['g%d' % i].shape))
+        p.grad = torch.from_numpy(v['g%d' % i]).clone()
+        ps.append(p)
+    tot = O.clip_grad(ps, 1.0)
+    np.testing.assert_allclose(float(tot), float(v['total']), rtol=1e-6)
+    for i, p in enumerate(ps):
+        np.testing.assert_allclose(p.grad.numpy(), v['c%d' % i], rtol=1e-6, atol=1e-7)
+    assert O.clip_grad(ps, 0) is None
+
+
+@pytest.mark.parametrize('tag', ['bneck_nores', 'bneck_res', 'bneck_s8'])
+def test_bottleneck(golden_dir, tag):
+    v = _load(golden_dir, 'ref_%s.npz' % tag)
+    k, s, cin, hid, cout = [int(a) for a in v['cfg']]
+    m = O.dense_res_bottleneck(k, s, cin, hid, cout)
+    m.load_state_dict(_sd(v), strict=True)
+    x = torch.from_numpy(v['x']).requires_grad_(True)
+    y = m(x)
+    np.testing.assert_allclose(y.detach().numpy(), v['y'], rtol=RTOL, atol=ATOL)
+    y.backward(torch.from_numpy(v['gy']))
+    np.testing.assert_allclose(x.grad.numpy(), v['gx'], rtol=1e-4, atol=1e-5)
+    _check_grads(m, v)
+
+
+def test_residual(golden_dir):
+    v = _load(golden_dir, 'ref_residual.npz')
+    m = O.Residual(12)
+    m.load_state_dict(_sd(v), strict=True)
+    x = torch.from_numpy(v['x']).requires_grad_(True)
+    y = m(x)
+    np.testing.assert_allclose(y.detach().numpy(), v['y'], rtol=RTOL, atol=ATOL)
+    y.backward(torch.from_numpy(v['gy']))
+    np.testing.assert_allclose(x.grad.numpy(), v['gx'], rtol=1e-4, atol=1e-5)
+    _check_grads(m, v)
+
+
+def test_generator(golden_dir):
+    v = _load(golden_dir, 'ref_generator.npz')
+    fs, es, ns, ss, nl = [int(a) for a in v['cfg']]
+    g = O.Generator(fs, es, ns, ss, nl, struct=v['cfg_struct'].tolist())
+    g.load_state_dict(_sd(v), strict=True)   # same keys as the reference, incl. '.module.'
+    z, c = torch.from_numpy(v['z']), torch.from_numpy(v['c'])
+    stop = torch.zeros(z.size(0), z.size(1), dtype=torch.long)
+    x, s, stops, length = g(z=z, c=c, stop=stop)
+    np.testing.assert_allclose(x.detach().numpy(), v['x'], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(s.detach().numpy(), v['s'], rtol=RTOL, atol=ATOL)
+    np.testing.assert_array_equal(length.numpy(), v['length'])
+    assert len(stops) == z.size(1)
+    ((x * torch.from_numpy(v['gy'])).sum() + (s * torch.from_numpy(v['gs'])).sum()).backward()
+    _check_grads(g, v)
+
+
+def test_discriminator_ragged(golden_dir):
+    v = _load(golden_dir, 'ref_discriminator.npz')
+    ss, es, nl = [int(a) for a in v['cfg']]
+    d = O.Discriminator(ss, es, nl, cnn_struct=v['cfg_struct'].tolist())
+    d.load_state_dict(_sd(v), strict=True)
+    x = torch.from_numpy(v['x']).requires_grad_(True)
+    logits, acts, act_lens, nfr = d(x, torch.from_numpy(v['length']), torch.from_numpy(v['c']))
+    np.testing.assert_allclose(logits.detach().numpy(), v['logits'], rtol=RTOL, atol=ATOL)
+    np.testing.assert_array_equal(nfr.numpy(), v['nframes'])
+    for i, (a, l) in enumerate(zip(acts, act_lens)):
+        np.testing.assert_allclose(a.detach().numpy(), v['act%d' % i], rtol=RTOL, atol=ATOL)
+        np.testing.assert_array_equal(l.numpy(), v['actlen%d' % i])
+    (logits * torch.from_numpy(v['gl'])).sum().backward()
+    np.testing.assert_allclose(x.grad.numpy(), v['gx'], rtol=1e-4, atol=1e-5)
+    _check_grads(d, v)
+
+
+def test_embedder(golden_dir):
+    v = _load(golden_dir, 'ref_embedder.npz')
+    e = O.Embedder(output_size=6, char_embed_size=4, num_chars=32)
+    e.load_state_dict(_sd(v), strict=True)
+    emb = e(torch.from_numpy(v['chars']), torch.from_numpy(v['clen']))
+    np.testing.assert_allclose(emb.detach().numpy(), v['emb'], rtol=RTOL, atol=ATOL)
