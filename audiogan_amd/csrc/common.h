@@ -1,0 +1,63 @@
+// common.h -- shared device/host helpers for libaudiogan_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/audiogan_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define AG_WAVE 64
+
+// last-error text (host side, one per process; the library is driven by one thread per GPU)
+void ag_set_error(const char* fmt, ...);
+
+#define AG_REQUIRE(cond, ...)     \
+  do {                            \
+    if (!(cond)) {                \
+      ag_set_error(__VA_ARGS__);  \
+      return AG_ERR_ARG;          \
+    }                             \
+  } while (0)
+
+#define AG_CHECK_LAUNCH(name)                                              \
+  do {                                                                     \
+    hipError_t e__ = hipGetLastError();                                    \
+    if (e__ != hipSuccess) {                                               \
+      ag_set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); \
+      return AG_ERR_LAUNCH;                                                \
+    }                                                                      \
+  } while (0)
+
+static inline int ag_cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline int64_t ag_cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline int ag_roundup(int a, int b) { return ag_cdiv(a, b) * b; }
+
+__device__ __forceinline__ float ag_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// block-wide sum for blocks of up to 1024 threads; result valid in every thread
+__device__ __forceinline__ float ag_block_sum(float v, float* sh /* >= 17 floats */) {
+  v = ag_wave_sum(v);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if (lane == 0) sh[wid] = v;
+  __syncthreads();
+  float r = 0.f;
+  for (int i = 0; i < nw; ++i) r += sh[i];
+  return r;
+}
+
+__device__ __forceinline__ float ag_apply_act(float v, int act, float slope) {
+  if (act == AG_ACT_LEAKY) return v > 0.f ? v : v * slope;
+  if (act == AG_ACT_TANH) return tanhf(v);
+  return v;
+}
+
+__device__ __forceinline__ float ag_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }

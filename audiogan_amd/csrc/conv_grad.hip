@@ -1,0 +1,242 @@
+// conv_grad.hip -- weight / bias gradients of the 1-D convolutions and the fused
+// LeakyReLU(+mask) backward.  Replaces the cuDNN backward-weight path behind
+// loss.backward() (audiogan.py:785,:903) for NN.Conv1d / NN.ConvTranspose1d.
+//
+//   dw[a, c, k] += sum_{b,t} sh[b, a, t] * lg[b, c, s*t + k - p]
+//
+// is a GEMM whose reduction axis is (b, t): MFMA row i <-> a, col j <-> flattened
+// (c,k), k-pair <-> two consecutive t.  Each workgroup owns one [rows x cols] tile of
+// dw and a strided share of the (b, time-chunk) reduction; partial tiles are combined
+// with fp32 global atomics (one 128-B row segment per half-wave, the full-rate shape).
+#include "common.h"
+
+struct WgP {
+  const float* sh;
+  const float* lg;
+  float* dw;
+  int64_t sh_bs, sh_cs, lg_bs, lg_cs;
+  int B, A, Lsh, C, Llg, K, s, p;
+  int CK;       // C*K
+  int TC;       // time chunk (even)
+  int nchunk;   // chunks per clip
+  int shp;      // LDS pitch of the sh tile (odd)
+  int lgp;      // LDS pitch of one lg channel row (odd)
+  int maxch;    // channel rows staged per tile
+};
+
+template <int TA, int TN, int WA, int WN>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgP p) {
+  static_assert(WA * WN == 4, "4 waves");
+  constexpr int AT = 32 * TA * WA, NT = 32 * TN * WN;
+  extern __shared__ float smem[];
+  float* shs = smem;                          // [AT][shp]
+  float* lgs = smem + (size_t)AT * p.shp;     // [maxch][lgp]
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int wa = wid / WN, wn = wid % WN;
+  const int a0 = blockIdx.y * AT, ck0 = blockIdx.x * NT;
+  const int c_lo = ck0 / p.K;
+  int c_hi = (ck0 + NT - 1) / p.K;
+  if (c_hi >= p.C) c_hi = p.C - 1;
+  const int nch = c_hi - c_lo + 1;
+  const int span = p.s * (p.TC - 1) + p.K;
+
+  // per-lane column constants
+  int joff[TN];
+  bool jok[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int ck = ck0 + wn * 32 * TN + 32 * j + l31;
+    jok[j] = ck < p.CK;
+    const int c = jok[j] ? ck / p.K : c_lo;
+    const int k = jok[j] ? ck - c * p.K : 0;
+    joff[j] = (c - c_lo) * p.lgp + k + p.s * h;
+  }
+
+  f32x16 acc[TA][TN];
+#pragma unroll
+  for (int i = 0; i < TA; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int total = p.B * p.nchunk;
+  for (int ch = blockIdx.z; ch < total; ch += gridDim.z) {
+    const int b = ch / p.nchunk;
+    const int t0 = (ch - b * p.nchunk) * p.TC;
+    __syncthreads();
+    // stage sh tile: rows a0..a0+AT, cols t0..t0+TC (zero outside)
+    {
+      const float* sb = p.sh + (int64_t)b * p.sh_bs;
+      for (int r = wid; r < AT; r += 4) {
+        const int a = a0 + r;
+        const bool aok = a < p.A;
+        const float* sr = sb + (int64_t)a * p.sh_cs;
+        for (int t = lane; t < p.TC; t += 64) {
+          const int tg = t0 + t;
+          shs[r * p.shp + t] = (aok && tg < p.Lsh) ? sr[tg] : 0.f;
+        }
+      }
+    }
+    // stage lg rows: channels c_lo..c_hi, positions s*t0-p .. +span
+    {
+      const float* lb = p.lg + (int64_t)b * p.lg_bs;
+      const int g0 = p.s * t0 - p.p;
+      for (int r = wid; r < nch; r += 4) {
+        const float* lr = lb + (int64_t)(c_lo + r) * p.lg_cs;
+        for (int i = lane; i < span; i += 64) {
+          const int g = g0 + i;
+          lgs[r * p.lgp + i] = (g >= 0 && g < p.Llg) ? lr[g] : 0.f;
+        }
+      }
+    }
+    __syncthreads();
+    const float* arow = shs + (wa * 32 * TA + l31) * p.shp + h;
+    for (int t = 0; t < p.TC; t += 2) {
+      float av[TA], bv[TN];
+#pragma unroll
+      for (int i = 0; i < TA; ++i) av[i] = arow[32 * i * p.shp + t];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bv[j] = jok[j] ? lgs[joff[j] + p.s * t] : 0.f;
+#pragma unroll
+      for (int i = 0; i < TA; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+    }
+  }
+
+#pragma unroll
+  for (int i = 0; i < TA; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int a = a0 + wa * 32 * TA + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
+      if (a >= p.A) continue;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int ck = ck0 + wn * 32 * TN + 32 * j + l31;
+        if (ck < p.CK) atomicAdd(p.dw + (int64_t)a * p.CK + ck, acc[i][j][e]);
+      }
+    }
+}
+
+template <int TA, int TN, int WA, int WN>
+static int launch_wgrad(WgP& p, hipStream_t st) {
+  constexpr int AT = 32 * TA * WA, NT = 32 * TN * WN;
+  p.TC = 64;
+  if (p.Lsh < 64) p.TC = ag_roundup(p.Lsh, 2);
+  p.nchunk = ag_cdiv(p.Lsh, p.TC);
+  p.shp = p.TC + 1;
+  const int span = p.s * (p.TC - 1) + p.K;
+  p.lgp = span | 1;
+  p.maxch = (NT - 1) / p.K + 2;
+  if (p.maxch > p.C) p.maxch = p.C;
+  const size_t lds = ((size_t)AT * p.shp + (size_t)p.maxch * p.lgp) * sizeof(float);
+  if (lds > 160 * 1024) {
+    ag_set_error("conv wgrad: tile needs %zu B of LDS", lds);
+    return AG_ERR_UNSUPPORTED;
+  }
+  const int gx = ag_cdiv(p.CK, NT), gy = ag_cdiv(p.A, AT);
+  const int total = p.B * p.nchunk;
+  int gz = ag_cdiv(2048, gx * gy);  // ~8 workgroups per CU over the whole grid
+  if (gz > total) gz = total;
+  if (gz < 1) gz = 1;
+  auto kern = conv_wgrad_kernel<TA, TN, WA, WN>;
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
+  hipLaunchKernelGGL(kern, dim3(gx, gy, gz), dim3(256), lds, st, p);
+  AG_CHECK_LAUNCH("ag_conv1d_wgrad");
+  return AG_OK;
+}
+
+extern "C" int ag_conv1d_wgrad(const float* sh, int64_t sh_bs, int64_t sh_cs, const float* lg,
+                               int64_t lg_bs, int64_t lg_cs, float* dw, int B, int A, int Lsh, int C,
+                               int Llg, int K, int stride, int pad, void* stream) {
+  AG_REQUIRE(sh && lg && dw, "ag_conv1d_wgrad: null tensor");
+  AG_REQUIRE(B > 0 && A > 0 && Lsh > 0 && C > 0 && Llg > 0 && K > 0 && stride > 0 && pad >= 0,
+             "ag_conv1d_wgrad: bad shape");
+  WgP p;
+  p.sh = sh; p.lg = lg; p.dw = dw;
+  p.sh_bs = sh_bs; p.sh_cs = sh_cs; p.lg_bs = lg_bs; p.lg_cs = lg_cs;
+  p.B = B; p.A = A; p.Lsh = Lsh; p.C = C; p.Llg = Llg; p.K = K; p.s = stride; p.p = pad;
+  p.CK = C * K;
+  hipStream_t st = (hipStream_t)stream;
+  if (A <= 32) return launch_wgrad<1, 1, 1, 4>(p, st);             // 32 x 128
+  if (A <= 64 || p.CK <= 64) return launch_wgrad<1, 1, 2, 2>(p, st);  // 64 x 64
+  return launch_wgrad<2, 2, 2, 2>(p, st);                           // 128 x 128
+}
+
+// ------------------------------------------------------------------------------------------
+// db[c] += sum_{b,t} dy[b,c,t]
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restrict__ dy, int64_t bs,
+                                                          int64_t cs, float* __restrict__ db, int B,
+                                                          int C, int L, int nsplit) {
+  __shared__ float red[17];
+  const int c = blockIdx.x;
+  const int64_t total = (int64_t)B * L;
+  float s = 0.f;
+  for (int64_t i = (int64_t)blockIdx.y * 256 + threadIdx.x; i < total; i += (int64_t)nsplit * 256) {
+    const int b = (int)(i / L);
+    const int t = (int)(i - (int64_t)b * L);
+    s += dy[(int64_t)b * bs + (int64_t)c * cs + t];
+  }
+  s = ag_block_sum(s, red);
+  if (threadIdx.x == 0) atomicAdd(db + c, s);
+}
+
+extern "C" int ag_channel_sum(const float* dy, int64_t bs, int64_t cs, float* db, int B, int C, int L,
+                              void* stream) {
+  AG_REQUIRE(dy && db && B > 0 && C > 0 && L > 0, "ag_channel_sum: bad args");
+  int nsplit = (int)ag_cdiv64((int64_t)B * L, 256 * 16);
+  const int cap = ag_cdiv(2048, C);
+  if (nsplit > cap) nsplit = cap;
+  if (nsplit < 1) nsplit = 1;
+  hipLaunchKernelGGL(channel_sum_kernel, dim3(C, nsplit), dim3(256), 0, (hipStream_t)stream, dy, bs,
+                     cs, db, B, C, L, nsplit);
+  AG_CHECK_LAUNCH("ag_channel_sum");
+  return AG_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// dpre = dy * leaky'(y) * mask
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void leaky_bwd_kernel(const float* __restrict__ dy, int64_t dy_bs,
+                                                        int64_t dy_cs, const float* __restrict__ y,
+                                                        int64_t y_bs, int64_t y_cs,
+                                                        float* __restrict__ dp, int64_t dp_bs,
+                                                        int64_t dp_cs, float* __restrict__ ad,
+                                                        int64_t ad_bs, int64_t ad_cs,
+                                                        const int64_t* __restrict__ lens, int C, int L,
+                                                        float slope) {
+  const int b = blockIdx.z, c = blockIdx.y;
+  const int64_t lenb = lens ? lens[b] : (int64_t)1 << 60;
+  const float* dyr = dy + (int64_t)b * dy_bs + (int64_t)c * dy_cs;
+  const float* yr = y + (int64_t)b * y_bs + (int64_t)c * y_cs;
+  float* dpr = dp + (int64_t)b * dp_bs + (int64_t)c * dp_cs;
+  float* adr = ad ? ad + (int64_t)b * ad_bs + (int64_t)c * ad_cs : nullptr;
+  for (int t = blockIdx.x * 256 + threadIdx.x; t < L; t += gridDim.x * 256) {
+    float g = dyr[t];
+    g = (yr[t] > 0.f) ? g : g * slope;
+    if (t >= lenb) g = 0.f;
+    dpr[t] = g;
+    if (adr) adr[t] += g;
+  }
+}
+
+extern "C" int ag_leaky_bwd(const float* dy, int64_t dy_bs, int64_t dy_cs, const float* y,
+                            int64_t y_bs, int64_t y_cs, float* dpre, int64_t dp_bs, int64_t dp_cs,
+                            float* add_into, int64_t ad_bs, int64_t ad_cs, const int64_t* lens_i64,
+                            int B, int C, int L, float slope, void* stream) {
+  AG_REQUIRE(dy && y && dpre && B > 0 && C > 0 && L > 0, "ag_leaky_bwd: bad args");
+  AG_REQUIRE(B <= 65535 && C <= 65535, "ag_leaky_bwd: B or C > 65535");
+  int gx = ag_cdiv(L, 256 * 4);
+  if (gx < 1) gx = 1;
+  hipLaunchKernelGGL(leaky_bwd_kernel, dim3(gx, C, B), dim3(256), 0, (hipStream_t)stream, dy, dy_bs,
+                     dy_cs, y, y_bs, y_cs, dpre, dp_bs, dp_cs, add_into, ad_bs, ad_cs, lens_i64, C, L, slope);
+  AG_CHECK_LAUNCH("ag_leaky_bwd");
+  return AG_OK;
+}

@@ -1,0 +1,215 @@
+// gemm.hip -- dense fp32 GEMM on v_mfma_f32_32x32x2_f32 with a fused epilogue.
+// Stands in for the cuBLAS calls behind NN.Linear / NN.LSTMCell / NN.LSTM gate products
+// (audiogan.py:260,380,385,409,410,498,509,511) and their backward.
+//
+//   C = act(alpha * op(A) op(B) + beta * C + bias[n] + res)
+//
+// LDS tiles are k-major (As[k][m], Bs[k][n]) so that both MFMA operands are unit-stride,
+// conflict-free ds_read_b32; the loaders transpose k-contiguous operands on the way in.
+#include "common.h"
+
+#define GBK 16
+
+struct GemmP {
+  const float* A;
+  const float* B;
+  float* C;
+  const float* bias;
+  const float* res;
+  int lda, ldb, ldc, ldres;
+  int M, N, K;
+  float alpha, beta, slope;
+  int act;
+  int vecA, vecB;  // 16-B vector loads allowed for A / B
+};
+
+// operand stored [rows][K] (k contiguous): tile -> S[k][r]
+template <int ROWS, int PITCH>
+__device__ __forceinline__ void load_kcontig(float* S, const float* __restrict__ G, int ld, int r0,
+                                             int nrows, int k0, int K, bool vec, int tid) {
+  constexpr int ITER = ROWS * (GBK / 4) / 256;
+  static_assert(ITER >= 1, "tile too small");
+#pragma unroll
+  for (int it = 0; it < ITER; ++it) {
+    const int idx = tid + it * 256;
+    const int r = idx >> 2, kq = idx & 3;
+    const int gr = r0 + r, gk = k0 + kq * 4;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (gr < nrows) {
+      const float* src = G + (int64_t)gr * ld + gk;
+      if (vec && gk + 3 < K) {
+        const f32x4 q = *reinterpret_cast<const f32x4*>(src);
+        v[0] = q[0]; v[1] = q[1]; v[2] = q[2]; v[3] = q[3];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (gk + e < K) v[e] = src[e];
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) S[(kq * 4 + e) * PITCH + r] = v[e];
+  }
+}
+
+// operand stored [K][rows] (row index contiguous): tile -> S[k][r]
+template <int ROWS, int PITCH>
+__device__ __forceinline__ void load_rcontig(float* S, const float* __restrict__ G, int ld, int r0,
+                                             int nrows, int k0, int K, bool vec, int tid) {
+  constexpr int R4 = ROWS / 4;
+  constexpr int ITER = GBK * R4 / 256;
+  static_assert(ITER >= 1, "tile too small");
+#pragma unroll
+  for (int it = 0; it < ITER; ++it) {
+    const int idx = tid + it * 256;
+    const int k = idx / R4, r = (idx % R4) * 4;
+    const int gk = k0 + k, gr = r0 + r;
+    f32x4 q = {0.f, 0.f, 0.f, 0.f};
+    if (gk < K) {
+      const float* src = G + (int64_t)gk * ld + gr;
+      if (vec && gr + 3 < nrows) {
+        q = *reinterpret_cast<const f32x4*>(src);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (gr + e < nrows) q[e] = src[e];
+      }
+    }
+    *reinterpret_cast<f32x4*>(S + k * PITCH + r) = q;
+  }
+}
+
+template <int TM, int TN, int WM, int WN, int TA, int TB>
+__global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
+  static_assert(WM * WN == 4, "4 waves");
+  constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+  constexpr int PA = BM + 4, PB = BN + 4;
+  __shared__ __attribute__((aligned(16))) float As[GBK * PA];
+  __shared__ __attribute__((aligned(16))) float Bs[GBK * PB];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int wm0 = (wid / WN) * 32 * TM, wn0 = (wid % WN) * 32 * TN;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  for (int k0 = 0; k0 < p.K; k0 += GBK) {
+    __syncthreads();
+    if (TA == 0)
+      load_kcontig<BM, PA>(As, p.A, p.lda, m0, p.M, k0, p.K, p.vecA, tid);
+    else
+      load_rcontig<BM, PA>(As, p.A, p.lda, m0, p.M, k0, p.K, p.vecA, tid);
+    if (TB == 1)
+      load_kcontig<BN, PB>(Bs, p.B, p.ldb, n0, p.N, k0, p.K, p.vecB, tid);
+    else
+      load_rcontig<BN, PB>(Bs, p.B, p.ldb, n0, p.N, k0, p.K, p.vecB, tid);
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < GBK; kk += 2) {
+      float av[TM], bv[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) av[i] = As[(kk + h) * PA + wm0 + 32 * i + l31];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bv[j] = Bs[(kk + h) * PB + wn0 + 32 * j + l31];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+    }
+  }
+
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = m0 + wm0 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
+      if (row >= p.M) continue;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int col = n0 + wn0 + 32 * j + l31;
+        if (col >= p.N) continue;
+        float v = p.alpha * acc[i][j][e];
+        float* dst = p.C + (int64_t)row * p.ldc + col;
+        if (p.beta != 0.f) v += p.beta * *dst;
+        if (p.bias) v += p.bias[col];
+        if (p.res) v += p.res[(int64_t)row * p.ldres + col];
+        *dst = ag_apply_act(v, p.act, p.slope);
+      }
+    }
+}
+
+template <int TM, int TN, int WM, int WN>
+static int launch_gemm(const GemmP& p, int ta, int tb, hipStream_t st) {
+  constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+  dim3 grid(ag_cdiv(p.N, BN), ag_cdiv(p.M, BM));
+  if (ta == 0 && tb == 0) hipLaunchKernelGGL((gemm_kernel<TM, TN, WM, WN, 0, 0>), grid, dim3(256), 0, st, p);
+  if (ta == 0 && tb == 1) hipLaunchKernelGGL((gemm_kernel<TM, TN, WM, WN, 0, 1>), grid, dim3(256), 0, st, p);
+  if (ta == 1 && tb == 0) hipLaunchKernelGGL((gemm_kernel<TM, TN, WM, WN, 1, 0>), grid, dim3(256), 0, st, p);
+  if (ta == 1 && tb == 1) hipLaunchKernelGGL((gemm_kernel<TM, TN, WM, WN, 1, 1>), grid, dim3(256), 0, st, p);
+  AG_CHECK_LAUNCH("ag_gemm");
+  return AG_OK;
+}
+
+static bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+extern "C" int ag_gemm(const float* A, int lda, int ta, const float* B, int ldb, int tb, float* C,
+                       int ldc, int M, int N, int K, float alpha, float beta, const float* bias,
+                       const float* res, int ldres, int act, float slope, void* stream) {
+  AG_REQUIRE(A && B && C, "ag_gemm: null tensor");
+  AG_REQUIRE(M > 0 && N > 0 && K > 0, "ag_gemm: bad shape %d %d %d", M, N, K);
+  AG_REQUIRE((ta == 0 || ta == 1) && (tb == 0 || tb == 1), "ag_gemm: bad transpose flag");
+  AG_REQUIRE(lda >= (ta ? M : K) && ldb >= (tb ? K : N) && ldc >= N, "ag_gemm: bad leading dim");
+  AG_REQUIRE(ag_cdiv(M, 64) <= 65535, "ag_gemm: M too large");
+  GemmP p;
+  p.A = A; p.B = B; p.C = C; p.bias = bias; p.res = res;
+  p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldres = ldres;
+  p.M = M; p.N = N; p.K = K;
+  p.alpha = alpha; p.beta = beta; p.slope = slope; p.act = act;
+  p.vecA = aligned16(A) && (lda % 4 == 0);
+  p.vecB = aligned16(B) && (ldb % 4 == 0);
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t big = (int64_t)ag_cdiv(M, 128) * ag_cdiv(N, 128);
+  if (M > 64 && N > 64 && big >= 192) return launch_gemm<2, 2, 2, 2>(p, ta, tb, st);  // 128x128
+  return launch_gemm<1, 1, 2, 2>(p, ta, tb, st);                                       // 64x64
+}
+
+// out[n] += sum_m X[m, n]
+__global__ __launch_bounds__(256) void col_sum_kernel(const float* __restrict__ X, int ldx,
+                                                      float* __restrict__ out, int M, int N,
+                                                      int rows_per) {
+  const int n = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int sub = threadIdx.x >> 6;  // 4 row-phases per block
+  const int mbeg = blockIdx.y * rows_per;
+  int mend = mbeg + rows_per;
+  if (mend > M) mend = M;
+  float s = 0.f;
+  if (n < N)
+    for (int m = mbeg + sub; m < mend; m += 4) s += X[(int64_t)m * ldx + n];
+  __shared__ float red[4][64];
+  red[sub][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (sub == 0 && n < N) {
+    s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    atomicAdd(out + n, s);
+  }
+}
+
+extern "C" int ag_col_sum(const float* X, int ldx, float* out, int M, int N, void* stream) {
+  AG_REQUIRE(X && out && M > 0 && N > 0 && ldx >= N, "ag_col_sum: bad args");
+  const int gx = ag_cdiv(N, 64);
+  int gy = ag_cdiv(1024, gx);
+  if (gy > ag_cdiv(M, 16)) gy = ag_cdiv(M, 16);
+  if (gy < 1) gy = 1;
+  const int rows_per = ag_cdiv(M, gy);
+  hipLaunchKernelGGL(col_sum_kernel, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, X, ldx, out, M,
+                     N, rows_per);
+  AG_CHECK_LAUNCH("ag_col_sum");
+  return AG_OK;
+}

@@ -1,0 +1,394 @@
+// pointwise.hip -- weight norm, LSTM cell pointwise, masked BCE, activations and the
+// fused optimiser.  Each kernel names the reference lines it replaces.
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------
+// weight norm (audiogan.py:77-80): one WAVE per row, rows reduced with wavefront shuffles;
+// a table of tensors is handled by one launch (grid.y = tensor).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void weight_norm_fwd_kernel(const ag_wn_desc* __restrict__ descs) {
+  const ag_wn_desc d = descs[blockIdx.y];
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= d.rows) return;
+  const float* v = d.v + (int64_t)r * d.cols;
+  float ss = 0.f;
+  for (int i = lane; i < d.cols; i += 64) {
+    const float x = v[i];
+    ss += x * x;
+  }
+  ss = ag_wave_sum(ss);
+  const float nrm = sqrtf(ss);
+  const float sc = d.g[r] / nrm;
+  if (lane == 0 && d.inv_norm) d.inv_norm[r] = 1.f / nrm;
+  const int d0p32 = (d.rows + 31) / 32 * 32;
+  const int s = d.stride > 0 ? d.stride : 1;
+  const int mt = (d.K + s - 1) / s;
+  const int mp = (d.d1 * s + 31) / 32 * 32;
+  for (int i = lane; i < d.cols; i += 64) {
+    const float w = v[i] * sc;
+    if (d.w) d.w[(int64_t)r * d.cols + i] = w;
+    if (d.wpa) d.wpa[(int64_t)i * d0p32 + r] = w;  // i = c*K + k
+    if (d.wpb) {
+      const int o = i / d.K, k = i - o * d.K;
+      const int m = k / s, rr = k - m * s;
+      d.wpb[((int64_t)r * mt + m) * mp + o * s + rr] = w;
+    }
+  }
+}
+
+extern "C" int ag_weight_norm_fwd(const ag_wn_desc* descs_dev, int n, int max_rows, void* stream) {
+  AG_REQUIRE(descs_dev && n > 0 && max_rows > 0, "ag_weight_norm_fwd: bad args");
+  AG_REQUIRE(n <= 65535, "ag_weight_norm_fwd: too many tensors");
+  hipLaunchKernelGGL(weight_norm_fwd_kernel, dim3(ag_cdiv(max_rows, 4), n), dim3(256), 0,
+                     (hipStream_t)stream, descs_dev);
+  AG_CHECK_LAUNCH("ag_weight_norm_fwd");
+  return AG_OK;
+}
+
+__global__ __launch_bounds__(256) void weight_norm_bwd_kernel(const ag_wn_bwd_desc* __restrict__ descs) {
+  const ag_wn_bwd_desc d = descs[blockIdx.y];
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= d.rows) return;
+  const float* v = d.v + (int64_t)r * d.cols;
+  const float* dw = d.dw + (int64_t)r * d.cols;
+  float ss = 0.f, dot = 0.f;
+  for (int i = lane; i < d.cols; i += 64) {
+    const float x = v[i];
+    ss += x * x;
+    dot += x * dw[i];
+  }
+  ss = ag_wave_sum(ss);
+  dot = ag_wave_sum(dot);
+  const float inv = 1.f / sqrtf(ss);
+  const float g = d.g[r];
+  if (lane == 0) d.dg[r] = dot * inv;
+  const float a = g * inv, bcoef = dot * inv * inv;
+  float* dv = d.dv + (int64_t)r * d.cols;
+  for (int i = lane; i < d.cols; i += 64) dv[i] = a * (dw[i] - v[i] * bcoef);
+}
+
+extern "C" int ag_weight_norm_bwd(const ag_wn_bwd_desc* descs_dev, int n, int max_rows, void* stream) {
+  AG_REQUIRE(descs_dev && n > 0 && max_rows > 0, "ag_weight_norm_bwd: bad args");
+  AG_REQUIRE(n <= 65535, "ag_weight_norm_bwd: too many tensors");
+  hipLaunchKernelGGL(weight_norm_bwd_kernel, dim3(ag_cdiv(max_rows, 4), n), dim3(256), 0,
+                     (hipStream_t)stream, descs_dev);
+  AG_CHECK_LAUNCH("ag_weight_norm_bwd");
+  return AG_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// LSTM cell pointwise (audiogan.py:380,440-442 NN.LSTMCell; :498 NN.LSTM), gate order i|f|g|o
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lstm_cell_fwd_kernel(
+    float* __restrict__ gates, int ldg, const float* __restrict__ c_prev, int ldcp,
+    float* __restrict__ h_out, int ldh, float* __restrict__ c_out, int ldc, float* __restrict__ y_out,
+    int ldy, const float* __restrict__ h_prev, int ldhp, const int64_t* __restrict__ valid, int t, int B,
+    int H) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  const int b = blockIdx.y;
+  if (j >= H) return;
+  float* gr = gates + (int64_t)b * ldg;
+  const float cp = c_prev[(int64_t)b * ldcp + j];
+  if (valid && t >= valid[b]) {
+    // padded step of a packed sequence: state is carried, output is zero
+    if (h_out) h_out[(int64_t)b * ldh + j] = h_prev ? h_prev[(int64_t)b * ldhp + j] : 0.f;
+    c_out[(int64_t)b * ldc + j] = cp;
+    if (y_out) y_out[(int64_t)b * ldy + j] = 0.f;
+    return;
+  }
+  const float ig = ag_sigmoid(gr[j]);
+  const float fg = ag_sigmoid(gr[H + j]);
+  const float gg = tanhf(gr[2 * H + j]);
+  const float og = ag_sigmoid(gr[3 * H + j]);
+  const float cn = fg * cp + ig * gg;
+  const float hn = og * tanhf(cn);
+  gr[j] = ig;
+  gr[H + j] = fg;
+  gr[2 * H + j] = gg;
+  gr[3 * H + j] = og;
+  c_out[(int64_t)b * ldc + j] = cn;
+  if (h_out) h_out[(int64_t)b * ldh + j] = hn;
+  if (y_out) y_out[(int64_t)b * ldy + j] = hn;
+}
+
+extern "C" int ag_lstm_cell_fwd(float* gates, int ldg, const float* c_prev, int ldcp, float* h_out,
+                                int ldh, float* c_out, int ldc, float* y_out, int ldy,
+                                const float* h_prev, int ldhp, const int64_t* valid_i64, int t, int B,
+                                int H, void* stream) {
+  AG_REQUIRE(gates && c_prev && c_out && (h_out || y_out), "ag_lstm_cell_fwd: null tensor");
+  AG_REQUIRE(B > 0 && H > 0 && B <= 65535 && ldg >= 4 * H, "ag_lstm_cell_fwd: bad shape");
+  hipLaunchKernelGGL(lstm_cell_fwd_kernel, dim3(ag_cdiv(H, 256), B), dim3(256), 0, (hipStream_t)stream,
+                     gates, ldg, c_prev, ldcp, h_out, ldh, c_out, ldc, y_out, ldy, h_prev, ldhp,
+                     valid_i64, t, B, H);
+  AG_CHECK_LAUNCH("ag_lstm_cell_fwd");
+  return AG_OK;
+}
+
+__global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(
+    const float* __restrict__ ga, int ldg, const float* __restrict__ c_prev, int ldcp,
+    const float* __restrict__ c_new, int ldc, const float* __restrict__ dh, int lddh,
+    const float* __restrict__ dy, int lddy, const float* __restrict__ dc_next, int lddcn,
+    float* __restrict__ dgates, int lddg,
+    float* __restrict__ dc_prev, int lddcp, float* __restrict__ dh_pass, int lddhp,
+    const int64_t* __restrict__ valid, int t, int B, int H) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  const int b = blockIdx.y;
+  if (j >= H) return;
+  float* dg = dgates + (int64_t)b * lddg;
+  const float dhf = dh ? dh[(int64_t)b * lddh + j] : 0.f;
+  const float dcn = dc_next ? dc_next[(int64_t)b * lddcn + j] : 0.f;
+  if (valid && t >= valid[b]) {
+    dg[j] = 0.f;
+    dg[H + j] = 0.f;
+    dg[2 * H + j] = 0.f;
+    dg[3 * H + j] = 0.f;
+    dc_prev[(int64_t)b * lddcp + j] = dcn;
+    if (dh_pass) dh_pass[(int64_t)b * lddhp + j] = dhf;
+    return;
+  }
+  const float dhv = dhf + (dy ? dy[(int64_t)b * lddy + j] : 0.f);
+  const float* gr = ga + (int64_t)b * ldg;
+  const float ig = gr[j], fg = gr[H + j], gg = gr[2 * H + j], og = gr[3 * H + j];
+  const float cp = c_prev[(int64_t)b * ldcp + j];
+  const float tc = tanhf(c_new[(int64_t)b * ldc + j]);
+  const float dc = dcn + dhv * og * (1.f - tc * tc);
+  dg[j] = dc * gg * ig * (1.f - ig);
+  dg[H + j] = dc * cp * fg * (1.f - fg);
+  dg[2 * H + j] = dc * ig * (1.f - gg * gg);
+  dg[3 * H + j] = dhv * tc * og * (1.f - og);
+  dc_prev[(int64_t)b * lddcp + j] = dc * fg;
+  if (dh_pass) dh_pass[(int64_t)b * lddhp + j] = 0.f;
+}
+
+extern "C" int ag_lstm_cell_bwd(const float* gates_act, int ldg, const float* c_prev, int ldcp,
+                                const float* c_new, int ldc, const float* dh, int lddh,
+                                const float* dy, int lddy, const float* dc_next, int lddcn,
+                                float* dgates, int lddg,
+                                float* dc_prev, int lddcp, float* dh_pass, int lddhp,
+                                const int64_t* valid_i64, int t, int B, int H, void* stream) {
+  AG_REQUIRE(gates_act && c_prev && c_new && (dh || dy) && dgates && dc_prev,
+             "ag_lstm_cell_bwd: null tensor");
+  AG_REQUIRE(B > 0 && H > 0 && B <= 65535, "ag_lstm_cell_bwd: bad shape");
+  hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3(ag_cdiv(H, 256), B), dim3(256), 0, (hipStream_t)stream,
+                     gates_act, ldg, c_prev, ldcp, c_new, ldc, dh, lddh, dy, lddy, dc_next, lddcn, dgates,
+                     lddg,
+                     dc_prev, lddcp, dh_pass, lddhp, valid_i64, t, B, H);
+  AG_CHECK_LAUNCH("ag_lstm_cell_bwd");
+  return AG_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// masked BCE-with-logits (audiogan.py:187-197, :204-211): one wave per sample
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bce_fwd_kernel(const float* __restrict__ x, int ldx, float target,
+                                                      const int64_t* __restrict__ nfr,
+                                                      float* __restrict__ per, float* __restrict__ loss,
+                                                      float scale, int B, int T) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  int64_t n = nfr ? nfr[b] : T;
+  const int lim = n < T ? (int)n : T;
+  float s = 0.f;
+  for (int t = lane; t < lim; t += 64) {
+    const float v = x[(int64_t)b * ldx + t];
+    const float m = fmaxf(-v, 0.f);
+    s += v - v * target + m + logf(expf(-m) + expf(-v - m));
+  }
+  s = ag_wave_sum(s);
+  if (lane == 0) {
+    if (per) per[b] = s;
+    if (loss) atomicAdd(loss, scale * s / (float)n);
+  }
+}
+
+extern "C" int ag_bce_logits_fwd(const float* x, int ldx, float target, const int64_t* nframes_i64,
+                                 float* per_sample, float* loss, float scale, int B, int T,
+                                 void* stream) {
+  AG_REQUIRE(x && (per_sample || loss) && B > 0 && T > 0 && ldx >= T, "ag_bce_logits_fwd: bad args");
+  hipLaunchKernelGGL(bce_fwd_kernel, dim3(ag_cdiv(B, 4)), dim3(256), 0, (hipStream_t)stream, x, ldx,
+                     target, nframes_i64, per_sample, loss, scale, B, T);
+  AG_CHECK_LAUNCH("ag_bce_logits_fwd");
+  return AG_OK;
+}
+
+__global__ __launch_bounds__(256) void bce_bwd_kernel(const float* __restrict__ x, int ldx, float target,
+                                                      const int64_t* __restrict__ nfr,
+                                                      const float* __restrict__ gscale, float scale,
+                                                      float* __restrict__ dx, int lddx, int B, int T) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int b = blockIdx.y;
+  if (t >= T) return;
+  const int64_t n = nfr ? nfr[b] : T;
+  float g = 0.f;
+  if (t < n) {
+    const float gs = gscale ? gscale[0] : 1.f;
+    g = gs * scale / (float)n * (ag_sigmoid(x[(int64_t)b * ldx + t]) - target);
+  }
+  dx[(int64_t)b * lddx + t] = g;
+}
+
+extern "C" int ag_bce_logits_bwd(const float* x, int ldx, float target, const int64_t* nframes_i64,
+                                 const float* gscale_dev, float scale, float* dx, int lddx, int B, int T,
+                                 void* stream) {
+  AG_REQUIRE(x && dx && B > 0 && T > 0 && B <= 65535, "ag_bce_logits_bwd: bad args");
+  hipLaunchKernelGGL(bce_bwd_kernel, dim3(ag_cdiv(T, 256), B), dim3(256), 0, (hipStream_t)stream, x, ldx,
+                     target, nframes_i64, gscale_dev, scale, dx, lddx, B, T);
+  AG_CHECK_LAUNCH("ag_bce_logits_bwd");
+  return AG_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// activations / axpby on contiguous buffers
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void act_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                      int64_t n, int act, float slope) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    y[i] = ag_apply_act(x[i], act, slope);
+}
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ dy,
+                                                      const float* __restrict__ y, float* __restrict__ dx,
+                                                      int64_t n, int act, float slope) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float o = y[i];
+    float g = dy[i];
+    if (act == AG_ACT_LEAKY) g = o > 0.f ? g : g * slope;
+    else if (act == AG_ACT_TANH) g = g * (1.f - o * o);
+    dx[i] = g;
+  }
+}
+__global__ __launch_bounds__(256) void axpby_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                    int64_t n, float a, float b) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    y[i] = a * x[i] + (b == 0.f ? 0.f : b * y[i]);
+}
+
+static unsigned ew_grid(int64_t n) {
+  int64_t g = ag_cdiv64(n, 256);
+  if (g > 4096) g = 4096;
+  if (g < 1) g = 1;
+  return (unsigned)g;
+}
+
+extern "C" int ag_act_fwd(const float* x, float* y, int64_t n, int act, float slope, void* stream) {
+  AG_REQUIRE(x && y && n > 0, "ag_act_fwd: bad args");
+  hipLaunchKernelGGL(act_fwd_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, x, y, n, act,
+                     slope);
+  AG_CHECK_LAUNCH("ag_act_fwd");
+  return AG_OK;
+}
+extern "C" int ag_act_bwd(const float* dy, const float* y, float* dx, int64_t n, int act, float slope,
+                          void* stream) {
+  AG_REQUIRE(dy && y && dx && n > 0, "ag_act_bwd: bad args");
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, dy, y, dx, n,
+                     act, slope);
+  AG_CHECK_LAUNCH("ag_act_bwd");
+  return AG_OK;
+}
+extern "C" int ag_axpby(const float* x, float* y, int64_t n, float a, float b, void* stream) {
+  AG_REQUIRE(x && y && n > 0, "ag_axpby: bad args");
+  hipLaunchKernelGGL(axpby_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, x, y, n, a, b);
+  AG_CHECK_LAUNCH("ag_axpby");
+  return AG_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// fused optimiser (audiogan.py:232-253 check_grad/clip_grad, :693-694 RMSprop;
+// computation_graph.py:58-59 Adam).  grid.y = tensor, grid.x = chunk.
+// ------------------------------------------------------------------------------------------
+#define OPT_CHUNKS 32
+
+__global__ __launch_bounds__(256) void grad_norms_kernel(const ag_opt_desc* __restrict__ descs,
+                                                         float* __restrict__ sq, int32_t* __restrict__ flags,
+                                                         float gscale) {
+  __shared__ float red[17];
+  const ag_opt_desc d = descs[blockIdx.y];
+  float s = 0.f;
+  int f = 0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < d.n; i += (int64_t)gridDim.x * 256) {
+    const float g = d.grad[i] * gscale;
+    s += g * g;
+    if (g != g) f |= AG_FLAG_NAN;
+    if (fabsf(g) > 1e5f) f |= AG_FLAG_BIG;
+  }
+  if ((int64_t)blockIdx.x * 256 >= d.n) return;  // uniform per block
+  s = ag_block_sum(s, red);
+  if (threadIdx.x == 0) atomicAdd(sq + blockIdx.y, s);
+  if (f && flags) atomicOr(flags, f);
+}
+
+__global__ void grad_norms_finish_kernel(float* __restrict__ sq_to_norm, float* __restrict__ norm_sum,
+                                         int n) {
+  // single block: norms[i] = sqrt(sq[i]); norm_sum = sum_i norms[i] (deterministic order)
+  __shared__ float red[17];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const float nr = sqrtf(sq_to_norm[i]);
+    sq_to_norm[i] = nr;
+    s += nr;
+  }
+  s = ag_block_sum(s, red);
+  if (threadIdx.x == 0 && norm_sum) norm_sum[0] = s;
+}
+
+extern "C" int ag_grad_norms(const ag_opt_desc* descs_dev, int n, float* norms, float* norm_sum,
+                             int32_t* flags, float grad_scale, void* stream) {
+  AG_REQUIRE(descs_dev && norms && n > 0 && n <= 65535, "ag_grad_norms: bad args");
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(norms, 0, sizeof(float) * n, st) != hipSuccess) {
+    ag_set_error("ag_grad_norms: memset failed");
+    return AG_ERR_LAUNCH;
+  }
+  if (flags) (void)hipMemsetAsync(flags, 0, sizeof(int32_t), st);
+  hipLaunchKernelGGL(grad_norms_kernel, dim3(OPT_CHUNKS, n), dim3(256), 0, st, descs_dev, norms, flags,
+                     grad_scale);
+  AG_CHECK_LAUNCH("ag_grad_norms");
+  hipLaunchKernelGGL(grad_norms_finish_kernel, dim3(1), dim3(256), 0, st, norms, norm_sum, n);
+  AG_CHECK_LAUNCH("ag_grad_norms(finish)");
+  return AG_OK;
+}
+
+__global__ __launch_bounds__(256) void opt_step_kernel(const ag_opt_desc* __restrict__ descs,
+                                                       const float* __restrict__ norms, int kind, float lr,
+                                                       float clip, float gscale, float a1, float b2,
+                                                       float eps, float bc1, float bc2sqrt) {
+  const ag_opt_desc d = descs[blockIdx.y];
+  const float nr = norms[blockIdx.y];
+  const bool do_clip = clip > 0.f && nr > clip;
+  const float div = do_clip ? nr / clip : 1.f;  // reference: grad /= (norm / clip), audiogan.py:252
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < d.n; i += (int64_t)gridDim.x * 256) {
+    float g = d.grad[i] * gscale;
+    if (do_clip) g = g / div;
+    if (kind == AG_OPT_RMSPROP) {
+      const float sq = a1 * d.s1[i] + (1.f - a1) * g * g;
+      d.s1[i] = sq;
+      d.p[i] = d.p[i] - lr * (g / (sqrtf(sq) + eps));
+    } else {
+      const float m = a1 * d.s1[i] + (1.f - a1) * g;
+      const float v = b2 * d.s2[i] + (1.f - b2) * g * g;
+      d.s1[i] = m;
+      d.s2[i] = v;
+      const float denom = sqrtf(v) / bc2sqrt + eps;
+      d.p[i] = d.p[i] - (lr / bc1) * (m / denom);
+    }
+  }
+}
+
+extern "C" int ag_opt_step(const ag_opt_desc* descs_dev, int n, const float* norms, int kind, float lr,
+                           float clip, float grad_scale, float alpha_or_beta1, float beta2, float eps,
+                           int step, void* stream) {
+  AG_REQUIRE(descs_dev && norms && n > 0 && n <= 65535, "ag_opt_step: bad args");
+  AG_REQUIRE(kind == AG_OPT_RMSPROP || kind == AG_OPT_ADAM, "ag_opt_step: bad optimiser kind");
+  float bc1 = 1.f, bc2s = 1.f;
+  if (kind == AG_OPT_ADAM) {
+    AG_REQUIRE(step >= 1, "ag_opt_step: Adam step must be >= 1");
+    bc1 = (float)(1.0 - pow((double)alpha_or_beta1, (double)step));
+    bc2s = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+  }
+  hipLaunchKernelGGL(opt_step_kernel, dim3(OPT_CHUNKS, n), dim3(256), 0, (hipStream_t)stream, descs_dev,
+                     norms, kind, lr, clip, grad_scale, alpha_or_beta1, beta2, eps, bc1, bc2s);
+  AG_CHECK_LAUNCH("ag_opt_step");
+  return AG_OK;
+}

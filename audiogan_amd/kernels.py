@@ -1,0 +1,337 @@
+"""Tensor-level wrappers over the C ABI (include/audiogan_hip.h).
+
+Every function takes torch CUDA fp32 tensors (views allowed where noted), checks what
+the kernels assume (device, dtype, unit stride on the last axis, shapes) and enqueues
+the kernel on torch's current HIP stream.  Nothing here computes on the host and there
+is no fallback: a non-CUDA tensor raises."""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import lib, check, ACT_NONE, ACT_LEAKY, ACT_TANH, OPT_RMSPROP, OPT_ADAM  # noqa: F401
+
+LEAKY_SLOPE = 0.01
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _chk(t, name, dtype=torch.float32):
+    if t is None:
+        return
+    if not t.is_cuda:
+        raise RuntimeError('audiogan_amd: %s must be a CUDA (HIP) tensor; there is no CPU path' % name)
+    if t.dtype != dtype:
+        raise TypeError('audiogan_amd: %s must be %s, got %s' % (name, dtype, t.dtype))
+
+
+def _bcl(t, name):
+    """(batch stride, channel stride) of a [B,C,L] view with unit time stride."""
+    _chk(t, name)
+    if t.dim() != 3 or (t.size(2) > 1 and t.stride(2) != 1):
+        raise ValueError('audiogan_amd: %s must be [B,C,L] with unit stride along L' % name)
+    return t.stride(0), t.stride(1)
+
+
+def _mat(t, name):
+    """leading dimension of a 2-D row-major view"""
+    _chk(t, name)
+    if t.dim() != 2 or (t.size(1) > 1 and t.stride(1) != 1):
+        raise ValueError('audiogan_amd: %s must be 2-D with unit stride along dim 1' % name)
+    return t.stride(0) if t.size(0) > 1 else max(t.stride(0), t.size(1))
+
+
+def wpa_numel(d0, d1, K):
+    return int(lib.ag_wpa_numel(d0, d1, K))
+
+
+def wpb_numel(d0, d1, K, stride):
+    return int(lib.ag_wpb_numel(d0, d1, K, stride))
+
+
+# ------------------------------------------------------------------------------------
+# descriptor tables (device copies of small C struct arrays), cached by content
+# ------------------------------------------------------------------------------------
+_table_cache = {}
+
+
+def _table(kind, structs, device):
+    raw = b''.join(bytes(s) for s in structs)
+    key = (kind, raw, str(device))
+    t = _table_cache.get(key)
+    if t is None:
+        if len(_table_cache) > 512:
+            _table_cache.clear()
+        t = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
+        _table_cache[key] = t
+    return t
+
+
+# ------------------------------------------------------------------------------------
+# weight norm
+# ------------------------------------------------------------------------------------
+def weight_norm_fwd(entries):
+    """entries: list of dict(v, g, w=None, wpa=None, wpb=None, stride=1).  v is the
+    parameter tensor ([d0], [d0,d1] or [d0,d1,K]); outputs are written in place."""
+    descs, max_rows = [], 1
+    for e in entries:
+        v, g = e['v'], e['g']
+        _chk(v, 'v'); _chk(g, 'g')
+        assert v.is_contiguous() and g.is_contiguous() and g.numel() == v.size(0)
+        rows = v.size(0)
+        cols = v.numel() // rows
+        if v.dim() == 3:
+            d1, K = v.size(1), v.size(2)
+        else:
+            d1, K = cols, 1
+        for k in ('w', 'wpa', 'wpb'):
+            _chk(e.get(k), k)
+        if e.get('w') is not None:
+            assert e['w'].is_contiguous() and e['w'].numel() == v.numel()
+        s = int(e.get('stride', 1))
+        if e.get('wpa') is not None:
+            assert e['wpa'].numel() == wpa_numel(rows, d1, K)
+        if e.get('wpb') is not None:
+            assert e['wpb'].numel() == wpb_numel(rows, d1, K, s)
+        descs.append(_lib.WnDesc(v.data_ptr(), g.data_ptr(), _p(e.get('w')).value or 0,
+                                 _p(e.get('wpa')).value or 0, _p(e.get('wpb')).value or 0, 0,
+                                 rows, cols, d1, K, s, 0))
+        max_rows = max(max_rows, rows)
+    tab = _table('wn', descs, entries[0]['v'].device)
+    check(lib.ag_weight_norm_fwd(_p(tab), len(descs), max_rows, _stream()), 'ag_weight_norm_fwd')
+
+
+def weight_norm_bwd(entries):
+    """entries: list of dict(v, g, dw, dv, dg); dv/dg are written."""
+    descs, max_rows = [], 1
+    for e in entries:
+        for k in ('v', 'g', 'dw', 'dv', 'dg'):
+            _chk(e[k], k)
+            assert e[k].is_contiguous()
+        rows = e['v'].size(0)
+        cols = e['v'].numel() // rows
+        assert e['dw'].numel() == e['v'].numel() == e['dv'].numel() and e['dg'].numel() == rows
+        descs.append(_lib.WnBwdDesc(e['v'].data_ptr(), e['g'].data_ptr(), e['dw'].data_ptr(),
+                                    e['dv'].data_ptr(), e['dg'].data_ptr(), rows, cols))
+        max_rows = max(max_rows, rows)
+    tab = _table('wnb', descs, entries[0]['v'].device)
+    check(lib.ag_weight_norm_bwd(_p(tab), len(descs), max_rows, _stream()), 'ag_weight_norm_bwd')
+
+
+def prep_conv_weight(w, wpa, wpb, stride):
+    _chk(w, 'w'); _chk(wpa, 'wpa'); _chk(wpb, 'wpb')
+    assert w.dim() == 3 and w.is_contiguous()
+    d0, d1, K = w.shape
+    if wpa is not None:
+        assert wpa.numel() == wpa_numel(d0, d1, K)
+    if wpb is not None:
+        assert wpb.numel() == wpb_numel(d0, d1, K, stride)
+    check(lib.ag_prep_conv_weight(_p(w), _p(wpa), _p(wpb), d0, d1, K, stride, _stream()),
+          'ag_prep_conv_weight')
+
+
+# ------------------------------------------------------------------------------------
+# conv engine
+# ------------------------------------------------------------------------------------
+def conv_engine(x, wp, y, K, stride, pad, mode, bias=None, res=None, lens=None, act=ACT_NONE,
+                slope=LEAKY_SLOPE, accumulate=False):
+    """mode 0: y[b,o,t] = sum W x[b,c,s*t+k-p]   (wp = gather layout of the weight)
+    mode 1: y[b,o,s*t+k-p] += W x[b,c,t]        (wp = scatter layout)
+    x: [B,C,Lin] view, y: [B,O,Lout] view (written in place)."""
+    x_bs, x_cs = _bcl(x, 'x')
+    y_bs, y_cs = _bcl(y, 'y')
+    _chk(wp, 'wp'); _chk(bias, 'bias'); _chk(lens, 'lens', torch.int64)
+    B, Cc, Lin = x.shape
+    B2, O, Lout = y.shape
+    assert B == B2
+    if mode == 0:
+        assert wp.numel() == wpa_numel(O, Cc, K), 'gather weight layout does not match shapes'
+    else:
+        assert wp.numel() == wpb_numel(Cc, O, K, stride), 'scatter weight layout does not match'
+    r_bs = r_cs = 0
+    if res is not None:
+        r_bs, r_cs = _bcl(res, 'res')
+        assert tuple(res.shape) == tuple(y.shape)
+    if bias is not None:
+        assert bias.numel() == O and bias.is_contiguous()
+    if lens is not None:
+        assert lens.numel() == B and lens.is_contiguous()
+    a = _lib.ConvArgs(x.data_ptr(), wp.data_ptr(), _p(bias).value or 0, _p(res).value or 0,
+                      y.data_ptr(), _p(lens).value or 0, x_bs, x_cs, y_bs, y_cs, r_bs, r_cs,
+                      B, Cc, Lin, O, Lout, K, stride, pad, mode, act, slope, 1 if accumulate else 0)
+    check(lib.ag_conv1d_engine(C.byref(a), _stream()), 'ag_conv1d_engine')
+
+
+def conv_wgrad(sh, lg, dw, K, stride, pad):
+    """dw[a,c,k] += sum_{b,t} sh[b,a,t] * lg[b,c,s*t+k-p];  dw: [A,C,K] contiguous."""
+    sh_bs, sh_cs = _bcl(sh, 'sh')
+    lg_bs, lg_cs = _bcl(lg, 'lg')
+    _chk(dw, 'dw')
+    B, A, Lsh = sh.shape
+    B2, Cc, Llg = lg.shape
+    assert B == B2 and dw.is_contiguous() and dw.numel() == A * Cc * K
+    check(lib.ag_conv1d_wgrad(_p(sh), sh_bs, sh_cs, _p(lg), lg_bs, lg_cs, _p(dw), B, A, Lsh, Cc, Llg,
+                              K, stride, pad, _stream()), 'ag_conv1d_wgrad')
+
+
+def channel_sum(dy, db):
+    """db[c] += sum_{b,t} dy[b,c,t]"""
+    bs, cs = _bcl(dy, 'dy')
+    _chk(db, 'db')
+    B, Cc, L = dy.shape
+    assert db.numel() == Cc and db.is_contiguous()
+    check(lib.ag_channel_sum(_p(dy), bs, cs, _p(db), B, Cc, L, _stream()), 'ag_channel_sum')
+
+
+def leaky_bwd(dy, y, dpre, lens=None, slope=LEAKY_SLOPE, add_into=None):
+    """dpre = dy * (y > 0 ? 1 : slope) * (t < lens[b]); all [B,C,L] views; dpre may alias dy.
+    add_into (optional [B,C,L] view, must not overlap dpre): add_into += dpre."""
+    a = _bcl(dy, 'dy'); b = _bcl(y, 'y'); c = _bcl(dpre, 'dpre')
+    d = _bcl(add_into, 'add_into') if add_into is not None else (0, 0)
+    _chk(lens, 'lens', torch.int64)
+    assert tuple(dy.shape) == tuple(y.shape) == tuple(dpre.shape)
+    assert add_into is None or tuple(add_into.shape) == tuple(dy.shape)
+    B, Cc, L = dy.shape
+    check(lib.ag_leaky_bwd(_p(dy), a[0], a[1], _p(y), b[0], b[1], _p(dpre), c[0], c[1], _p(add_into),
+                           d[0], d[1], _p(lens), B, Cc, L, slope, _stream()), 'ag_leaky_bwd')
+
+
+# ------------------------------------------------------------------------------------
+# GEMM
+# ------------------------------------------------------------------------------------
+def gemm(A, B, Cm, ta=False, tb=False, alpha=1.0, beta=0.0, bias=None, res=None, act=ACT_NONE,
+         slope=LEAKY_SLOPE):
+    """Cm[M,N] = act(alpha * op(A) @ op(B) + beta*Cm + bias + res).
+    ta: A is stored [K,M];  tb: B is stored [N,K] (a Linear weight)."""
+    lda, ldb, ldc = _mat(A, 'A'), _mat(B, 'B'), _mat(Cm, 'C')
+    M, N = Cm.shape
+    K = A.size(0) if ta else A.size(1)
+    assert (A.size(1) if ta else A.size(0)) == M, 'gemm: A shape'
+    assert (B.size(1) if tb else B.size(0)) == K and (B.size(0) if tb else B.size(1)) == N, 'gemm: B shape'
+    ldres = 0
+    if res is not None:
+        ldres = _mat(res, 'res')
+        assert tuple(res.shape) == (M, N)
+    if bias is not None:
+        _chk(bias, 'bias')
+        assert bias.numel() == N and bias.is_contiguous()
+    check(lib.ag_gemm(_p(A), lda, int(ta), _p(B), ldb, int(tb), _p(Cm), ldc, M, N, K, alpha, beta,
+                      _p(bias), _p(res), ldres, act, slope, _stream()), 'ag_gemm')
+
+
+def col_sum(X, out):
+    """out[n] += sum_m X[m,n]"""
+    ldx = _mat(X, 'X')
+    _chk(out, 'out')
+    M, N = X.shape
+    assert out.numel() == N and out.is_contiguous()
+    check(lib.ag_col_sum(_p(X), ldx, _p(out), M, N, _stream()), 'ag_col_sum')
+
+
+# ------------------------------------------------------------------------------------
+# LSTM cell pointwise
+# ------------------------------------------------------------------------------------
+def lstm_cell_fwd(gates, c_prev, c_out, h_out=None, y_out=None, h_prev=None, valid=None, t=0):
+    ldg = _mat(gates, 'gates')
+    B, H4 = gates.shape
+    H = H4 // 4
+    _chk(valid, 'valid', torch.int64)
+    ld = lambda x, n: (_mat(x, n) if x is not None else 0)  # noqa: E731
+    for x in (c_prev, c_out, h_out, y_out, h_prev):
+        assert x is None or tuple(x.shape) == (B, H)
+    check(lib.ag_lstm_cell_fwd(_p(gates), ldg, _p(c_prev), ld(c_prev, 'c_prev'), _p(h_out),
+                               ld(h_out, 'h_out'), _p(c_out), ld(c_out, 'c_out'), _p(y_out),
+                               ld(y_out, 'y_out'), _p(h_prev), ld(h_prev, 'h_prev'), _p(valid), t, B, H,
+                               _stream()), 'ag_lstm_cell_fwd')
+
+
+def lstm_cell_bwd(gates_act, c_prev, c_new, dh, dy, dc_next, dgates, dc_prev, dh_pass=None,
+                  valid=None, t=0):
+    """dh: gradient from later steps (or None), dy: gradient of this step's output (or None)"""
+    B, H4 = gates_act.shape
+    H = H4 // 4
+    _chk(valid, 'valid', torch.int64)
+    ld = lambda x, n: (_mat(x, n) if x is not None else 0)  # noqa: E731
+    for x in (c_prev, c_new, dh, dy, dc_next, dc_prev, dh_pass):
+        assert x is None or tuple(x.shape) == (B, H)
+    assert tuple(dgates.shape) == (B, H4)
+    check(lib.ag_lstm_cell_bwd(_p(gates_act), _mat(gates_act, 'gates_act'), _p(c_prev),
+                               ld(c_prev, 'c_prev'), _p(c_new), ld(c_new, 'c_new'), _p(dh), ld(dh, 'dh'),
+                               _p(dy), ld(dy, 'dy'), _p(dc_next), ld(dc_next, 'dc_next'), _p(dgates), _mat(dgates, 'dgates'),
+                               _p(dc_prev), ld(dc_prev, 'dc_prev'), _p(dh_pass), ld(dh_pass, 'dh_pass'),
+                               _p(valid), t, B, H, _stream()), 'ag_lstm_cell_bwd')
+
+
+# ------------------------------------------------------------------------------------
+# BCE / activations
+# ------------------------------------------------------------------------------------
+def bce_logits_fwd(x, target, nframes, per_sample, loss, scale):
+    """per_sample[b] = masked sum; loss[0] += scale * sum_b per_sample[b]/n[b]"""
+    ldx = _mat(x, 'x')
+    _chk(nframes, 'nframes', torch.int64); _chk(per_sample, 'per_sample'); _chk(loss, 'loss')
+    B, T = x.shape
+    check(lib.ag_bce_logits_fwd(_p(x), ldx, float(target), _p(nframes), _p(per_sample), _p(loss),
+                                float(scale), B, T, _stream()), 'ag_bce_logits_fwd')
+
+
+def bce_logits_bwd(x, target, nframes, gscale, scale, dx):
+    ldx, lddx = _mat(x, 'x'), _mat(dx, 'dx')
+    _chk(nframes, 'nframes', torch.int64); _chk(gscale, 'gscale')
+    B, T = x.shape
+    check(lib.ag_bce_logits_bwd(_p(x), ldx, float(target), _p(nframes), _p(gscale), float(scale),
+                                _p(dx), lddx, B, T, _stream()), 'ag_bce_logits_bwd')
+
+
+def act_fwd(x, y, act, slope=LEAKY_SLOPE):
+    _chk(x, 'x'); _chk(y, 'y')
+    assert x.is_contiguous() and y.is_contiguous() and x.numel() == y.numel()
+    check(lib.ag_act_fwd(_p(x), _p(y), x.numel(), act, slope, _stream()), 'ag_act_fwd')
+
+
+def act_bwd(dy, y, dx, act, slope=LEAKY_SLOPE):
+    for t_, n in ((dy, 'dy'), (y, 'y'), (dx, 'dx')):
+        _chk(t_, n)
+        assert t_.is_contiguous()
+    assert dy.numel() == y.numel() == dx.numel()
+    check(lib.ag_act_bwd(_p(dy), _p(y), _p(dx), dy.numel(), act, slope, _stream()), 'ag_act_bwd')
+
+
+def axpby(x, y, a, b):
+    """y = a*x + b*y (contiguous)"""
+    _chk(x, 'x'); _chk(y, 'y')
+    assert x.is_contiguous() and y.is_contiguous() and x.numel() == y.numel()
+    check(lib.ag_axpby(_p(x), _p(y), x.numel(), float(a), float(b), _stream()), 'ag_axpby')
+
+
+# ------------------------------------------------------------------------------------
+# optimiser
+# ------------------------------------------------------------------------------------
+def _opt_table(params, grads, s1, s2):
+    descs = []
+    for i, p in enumerate(params):
+        _chk(p, 'param'); _chk(grads[i], 'grad'); _chk(s1[i], 's1')
+        assert p.is_contiguous() and grads[i].is_contiguous() and grads[i].numel() == p.numel()
+        descs.append(_lib.OptDesc(p.data_ptr(), grads[i].data_ptr(), s1[i].data_ptr(),
+                                  s2[i].data_ptr() if s2 is not None else 0, p.numel()))
+    return _table('opt', descs, params[0].device)
+
+
+def grad_norms(params, grads, s1, s2, norms, norm_sum, flags, grad_scale=1.0):
+    """norms[i] = ||grads[i]*grad_scale||; norm_sum[0] = sum_i norms[i]; flags |= NaN/BIG bits"""
+    tab = _opt_table(params, grads, s1, s2)
+    _chk(norms, 'norms'); _chk(norm_sum, 'norm_sum'); _chk(flags, 'flags', torch.int32)
+    assert norms.numel() >= len(params)
+    check(lib.ag_grad_norms(_p(tab), len(params), _p(norms), _p(norm_sum), _p(flags), grad_scale,
+                            _stream()), 'ag_grad_norms')
+
+
+def opt_step(params, grads, s1, s2, norms, kind, lr, clip, grad_scale, a1, b2, eps, step):
+    tab = _opt_table(params, grads, s1, s2)
+    check(lib.ag_opt_step(_p(tab), len(params), _p(norms), kind, lr, clip, grad_scale, a1, b2, eps,
+                          step, _stream()), 'ag_opt_step')

@@ -1,0 +1,277 @@
+"""Drop-in ``Generator`` / ``Discriminator`` / ``Embedder`` modules.
+
+Same constructor arguments, ``forward`` signatures, return values and ``state_dict`` keys
+as the reference classes (audiogan.py:302-334, 361-468, 471-551), so a checkpoint of the
+reference's parameters loads with ``strict=True``.  What runs underneath is the fused HIP
+blocks of ``audiogan_amd.ops``; no stock torch compute op (conv, linear, LSTM) is called.
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+from .ops import ConvSpec
+
+
+def div_roundup(x, d):
+    """audiogan.py:172-173 (integer semantics of Python 2)."""
+    return (x + d - 1) // d
+
+
+def roundup(x, d):
+    """audiogan.py:174-175."""
+    return (x + d - 1) // d * d
+
+
+class Replicated(nn.Module):
+    """Holder that keeps the ``.module.`` level the reference's per-submodule
+    ``NN.DataParallel`` wrappers put into ``state_dict`` keys (audiogan.py:379-410, 492-508).
+    Data parallelism itself is process-per-GPU (audiogan_amd.ddp), not this wrapper."""
+
+    def __init__(self, module):
+        super().__init__()
+        self.module = module
+
+    def forward(self, *a, **k):
+        return self.module(*a, **k)
+
+
+def _register_wn(mod, name, w):
+    """weight_norm reparameterisation of tensor ``w`` (dim 0): g = ||w|| per row, v = w.
+    Registers ``<name>_g`` then ``<name>_v`` like torch.nn.utils.weight_norm (audiogan.py:77-80)."""
+    w = w.detach()
+    if w.dim() == 1:
+        g = w.abs()
+    else:
+        g = w.reshape(w.size(0), -1).norm(dim=1).view(w.size(0), *([1] * (w.dim() - 1)))
+    mod.register_parameter(name + '_g', nn.Parameter(g.clone()))
+    mod.register_parameter(name + '_v', nn.Parameter(w.clone()))
+
+
+class _WNModule(nn.Module):
+    """parameter container for one weight-normed layer; ``names`` in reference order"""
+
+    def __init__(self, proto, names):
+        super().__init__()
+        for n in names:
+            _register_wn(self, n, getattr(proto, n))
+
+    def wn(self, name):
+        return getattr(self, name + '_v'), getattr(self, name + '_g')
+
+
+class WNConv1d(_WNModule):
+    def __init__(self, cin, cout, k, stride, padding):
+        super().__init__(nn.Conv1d(cin, cout, k, stride=stride, padding=padding), ['weight', 'bias'])
+        self.spec = ConvSpec('conv', cin, cout, k, stride, padding)
+
+
+class WNConvTranspose1d(_WNModule):
+    def __init__(self, cin, cout, k, stride, padding):
+        super().__init__(nn.ConvTranspose1d(cin, cout, k, stride, padding=padding), ['weight', 'bias'])
+        self.spec = ConvSpec('convT', cin, cout, k, stride, padding)
+
+
+class WNLinear(_WNModule):
+    def __init__(self, fin, fout):
+        super().__init__(nn.Linear(fin, fout), ['weight', 'bias'])
+
+
+class WNLSTMCell(_WNModule):
+    def __init__(self, fin, hidden):
+        super().__init__(nn.LSTMCell(fin, hidden), ['weight_ih', 'weight_hh', 'bias_hh', 'bias_ih'])
+
+
+class Residual(nn.Module):
+    """audiogan.py:256-264 (parameters only; computed inside ops.DHeadFn)."""
+
+    def __init__(self, size):
+        super().__init__()
+        self.size = size
+        self.linear = WNLinear(size, size)
+
+
+class dense_res_bottleneck(nn.Module):
+    """audiogan.py:266-283 (parameters only; computed inside ops.GTrunkFn)."""
+
+    def __init__(self, kernel, stride, infilters, hidden_filters, outfilters):
+        super().__init__()
+        self.infilters = infilters
+        self.outfilters = outfilters
+        self.conv = WNConv1d(infilters, hidden_filters, kernel, stride, (kernel - 1) // 2)
+        self.deconv = WNConvTranspose1d(hidden_filters, outfilters, kernel - 1, stride, stride // 2)
+
+
+def _add(group, mod, name, **kw):
+    v, g = mod.wn(name)
+    group.add(v, g, **kw)
+
+
+class Generator(nn.Module):
+    """audiogan.py:361-468.  ``stop``: None -> Bernoulli stop draws like the reference
+    (:444-460); a [B,T] integer tensor -> use these draws; 'never' -> fixed-length clips
+    (no draw, no host sync; what the bench uses)."""
+
+    def __init__(self, frame_size=200, embed_size=200, noise_size=100, state_size=1024,
+                 num_layers=1,
+                 struct=((17, 8, 128, 16), (9, 4, 64, 32), (9, 4, 64, 32), (9, 4, 32, 32))):
+        super().__init__()
+        self._frame_size = frame_size
+        self._noise_size = noise_size
+        self._state_size = state_size
+        self._embed_size = embed_size
+        self._num_layers = num_layers
+        self.rnn = nn.ModuleList()
+        self.rnn.append(Replicated(WNLSTMCell(frame_size + embed_size + noise_size, state_size)))
+        for _ in range(1, num_layers):
+            self.rnn.append(Replicated(WNLSTMCell(state_size, state_size)))
+        self.dense_res_gen = nn.ModuleList()
+        cin = 1
+        for kernel, stride, hidden, cout in struct:
+            self.dense_res_gen.append(Replicated(dense_res_bottleneck(kernel, stride, cin, hidden, cout)))
+            cin += cout
+        self.dense_res_gen.append(Replicated(WNConv1d(cin, 1, 3, 1, 1)))
+        self.proj = Replicated(WNLinear(state_size, frame_size))
+        self.stopper = Replicated(WNLinear(state_size, 1))
+
+        # fused-block descriptions (share the Parameters above)
+        self._front = ops.GFront(frame_size, num_layers, state_size)
+        for cell in self.rnn:
+            for n in ('weight_ih', 'weight_hh', 'bias_ih', 'bias_hh'):
+                _add(self._front.group, cell.module, n)
+        for lin in (self.proj.module, self.stopper.module):
+            _add(self._front.group, lin, 'weight')
+            _add(self._front.group, lin, 'bias')
+        bn = [(m.module.conv.spec, m.module.deconv.spec) for m in self.dense_res_gen[:-1]]
+        self._trunk = ops.GTrunk(bn, self.dense_res_gen[-1].module.spec)
+        for m in self.dense_res_gen[:-1]:
+            for layer in (m.module.conv, m.module.deconv):
+                _add(self._trunk.group, layer, 'weight', stride=layer.spec.stride, engine=True)
+                _add(self._trunk.group, layer, 'bias')
+        fin = self.dense_res_gen[-1].module
+        _add(self._trunk.group, fin, 'weight', stride=1, engine=True)
+        _add(self._trunk.group, fin, 'bias')
+
+    def forward(self, batch_size=None, length=None, z=None, c=None, stop=None):
+        fs, ns, es = self._frame_size, self._noise_size, self._embed_size
+        dev = c.device
+        if z is None:
+            nframes = div_roundup(length, fs)
+            z = torch.randn(batch_size, nframes, ns, device=dev)
+        else:
+            batch_size, nframes, _ = z.size()
+        zc = torch.cat([z, c.unsqueeze(1).expand(batch_size, nframes, es)], 2).transpose(0, 1).contiguous()
+        x, s = ops.GFrontFn.apply(zc, self._front, *self._front.group.params())
+
+        if isinstance(stop, str):
+            assert stop == 'never'
+            t_eff = nframes
+            stops = None
+            out_len = torch.full((batch_size,), nframes * fs, dtype=torch.long, device=dev)
+        else:
+            if stop is None:
+                stops = torch.bernoulli(torch.sigmoid(s.detach())).long()
+            else:
+                stops = stop.to(dev).long()
+            # frames generated by sample b: up to and including its first stop draw (:451-458);
+            # the loop itself runs until every sample has stopped (:459-460)
+            first = torch.where(stops.bool().any(1), stops.argmax(1) + 1,
+                                torch.full_like(stops[:, 0], nframes))
+            t_eff = int(first.max())          # host sync, as the reference's generating.sum()==0
+            out_len = first * fs
+        if t_eff < nframes:
+            x, s = x[:, :t_eff * fs], s[:, :t_eff]
+        stop_list = ([stops[:, t:t + 1] for t in range(t_eff)] if stops is not None else
+                     [torch.zeros(batch_size, 1, dtype=torch.long, device=dev) for _ in range(t_eff)])
+        wave = ops.GTrunkFn.apply(x, self._trunk, *self._trunk.group.params())
+        return wave, s, stop_list, out_len
+
+
+class Discriminator(nn.Module):
+    """audiogan.py:471-551."""
+
+    def __init__(self, state_size=1024, embed_size=200, num_layers=1,
+                 cnn_struct=((7, 2, 16), (7, 2, 32), (7, 2, 64), (7, 2, 128), (7, 2, 256), (7, 2, 512))):
+        super().__init__()
+        self._state_size = state_size
+        self._embed_size = embed_size
+        self._num_layers = num_layers
+        self.cnn_struct = [list(l) for l in cnn_struct]
+        self._cnn_struct = self.cnn_struct
+        self.cnn = nn.ModuleList()
+        cin = 1
+        for kernel, stride, cout in self.cnn_struct:
+            self.cnn.append(Replicated(WNConv1d(cin, cout, kernel, stride, (kernel - 1) // 2)))
+            cin = cout
+        self.frame_size = self._frame_size = cin
+        # parameter container only (names/initialisation of NN.LSTM, :498-503); never called
+        self.rnn = nn.LSTM(cin + embed_size, state_size // 2, num_layers, bidirectional=True)
+        self.residual_net = Replicated(nn.Sequential(Residual(state_size), Residual(state_size)))
+        self.classifier = Replicated(nn.Sequential(
+            WNLinear(state_size, state_size // 2), nn.LeakyReLU(), WNLinear(state_size // 2, 1)))
+
+        self._stack = ops.DConvStack([m.module.spec for m in self.cnn])
+        for m in self.cnn:
+            _add(self._stack.group, m.module, 'weight', stride=m.module.spec.stride, engine=True)
+            _add(self._stack.group, m.module, 'bias')
+        self._head = ops.DHead(2)
+        for r in self.residual_net.module:
+            _add(self._head.group, r.linear, 'weight')
+            _add(self._head.group, r.linear, 'bias')
+        for i in (0, 2):
+            _add(self._head.group, self.classifier.module[i], 'weight')
+            _add(self._head.group, self.classifier.module[i], 'bias')
+
+    def _rnn_weights(self, layer):
+        out = []
+        for suffix in ('', '_reverse'):
+            for n in ('weight_ih', 'weight_hh', 'bias_ih', 'bias_hh'):
+                out.append(getattr(self.rnn, '%s_l%d%s' % (n, layer, suffix)))
+        return out
+
+    def forward(self, x, length, c, percent_used=0.1):
+        ss, es = self._state_size, self._embed_size
+        b = x.size(0)
+        length = length.to(x.device).long()
+        lens_list, n = [], length
+        for _, stride, _ in self.cnn_struct:
+            n = (n + stride - 1) // stride
+            lens_list.append(n.contiguous())
+        acts = ops.DConvStackFn.apply(x, self._stack, lens_list, *self._stack.group.params())
+        a = acts[-1]
+        tq = a.size(2)
+        seq = torch.cat([a.permute(2, 0, 1), c.unsqueeze(0).expand(tq, b, es)], 2)
+        for layer in range(self._num_layers):
+            seq = ops.LSTMSeqFn.apply(seq.contiguous(), n, 2, *self._rnn_weights(layer))
+        rows = seq.permute(1, 0, 2).reshape(b * tq, ss)
+        logits = ops.DHeadFn.apply(rows, self._head, *self._head.group.params()).view(b, tq)
+        return logits, list(acts), lens_list, n
+
+
+class Embedder(nn.Module):
+    """audiogan.py:302-334: char embedding -> biLSTM -> last hidden state of both directions."""
+
+    def __init__(self, output_size=100, char_embed_size=50, num_layers=1, num_chars=256):
+        super().__init__()
+        self._output_size = output_size
+        self._char_embed_size = char_embed_size
+        self._num_layers = num_layers
+        self.embed = Replicated(nn.Embedding(num_chars, char_embed_size))   # lookup = indexing
+        self.rnn = nn.LSTM(char_embed_size, output_size // 2, num_layers, bidirectional=True)
+
+    def forward(self, chars, length):
+        nl, b, o = self._num_layers, chars.size(0), self._output_size
+        dev = self.embed.module.weight.device
+        length = length.to(dev).long()
+        seq = self.embed.module.weight[chars.to(dev).long()].permute(1, 0, 2).contiguous()
+        for layer in range(nl):
+            w = []
+            for suffix in ('', '_reverse'):
+                for n in ('weight_ih', 'weight_hh', 'bias_ih', 'bias_hh'):
+                    w.append(getattr(self.rnn, '%s_l%d%s' % (n, layer, suffix)))
+            seq = ops.LSTMSeqFn.apply(seq, length, 2, *w)
+        h = o // 2
+        # last hidden state: forward direction at t = len-1, reverse direction at t = 0
+        idx = (length - 1).clamp(min=0)
+        fwd = seq[idx, torch.arange(b, device=dev), :h]
+        bwd = seq[0, :, h:]
+        return torch.cat([fwd, bwd], 1)

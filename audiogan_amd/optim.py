@@ -1,0 +1,125 @@
+"""Fused optimisers: check_grad + per-parameter clip + update in two launches per network.
+
+Replaces ``check_grad`` (audiogan.py:232-240), ``clip_grad`` (:243-253) and
+``T.optim.RMSprop(...).step()`` (:693-694, :788, :921); Adam follows the TF defaults of the
+obsolete graph (computation_graph.py:58-59), which equal torch.optim.Adam's.
+"""
+import torch
+
+from . import kernels as K
+from . import ops
+
+
+class _Fused(object):
+    kind = None
+
+    def __init__(self, params, lr):
+        self.params = [p for p in params]
+        self.lr = float(lr)
+        self.step_count = 0
+        self._state = None
+        self.last_norm_sum = None
+        self.last_flags = None
+
+    # -- state -----------------------------------------------------------------------
+    def _init_state(self):
+        dev = self.params[0].device
+        n = sum(p.numel() for p in self.params)
+        flat1 = torch.zeros(n, device=dev)
+        flat2 = torch.zeros(n, device=dev) if self.kind == K.OPT_ADAM else None
+        s1, s2, o = [], [], 0
+        for p in self.params:
+            s1.append(flat1[o:o + p.numel()])
+            if flat2 is not None:
+                s2.append(flat2[o:o + p.numel()])
+            o += p.numel()
+        self._state = dict(s1=s1, s2=s2 if flat2 is not None else None,
+                           norms=torch.zeros(len(self.params), device=dev),
+                           norm_sum=torch.zeros(1, device=dev),
+                           flags=torch.zeros(1, dtype=torch.int32, device=dev))
+
+    def zero_grad(self):
+        """keeps .grad allocated (stable pointers -> cached descriptor tables)"""
+        for p in self.params:
+            if p.grad is not None:
+                p.grad.detach_()
+                p.grad.zero_()
+
+    def state_dict(self):
+        self._ensure()
+        return dict(step=self.step_count, lr=self.lr,
+                    s1=[t.clone() for t in self._state['s1']],
+                    s2=[t.clone() for t in self._state['s2']] if self._state['s2'] else None)
+
+    def load_state_dict(self, sd):
+        self._ensure()
+        self.step_count, self.lr = sd['step'], sd['lr']
+        for a, b in zip(self._state['s1'], sd['s1']):
+            a.copy_(b)
+        if self._state['s2']:
+            for a, b in zip(self._state['s2'], sd['s2']):
+                a.copy_(b)
+
+    def _ensure(self):
+        if self._state is None or self._state['norms'].device != self.params[0].device:
+            self._init_state()
+
+    # -- step ------------------------------------------------------------------------
+    def step(self, clip_norm=0.0, grad_scale=1.0, check=False):
+        """``clip_norm``: per-PARAMETER L2 clip (0 = off) exactly as clip_grad; ``grad_scale``
+        multiplies every gradient first (1/world_size after a sum all-reduce); ``check`` reads
+        the NaN/|g|>1e5 flags back (one host sync) and asserts like check_grad."""
+        self._ensure()
+        st = self._state
+        live = [(p, p.grad, a, (st['s2'][i] if st['s2'] else None))
+                for i, (p, a) in enumerate(zip(self.params, st['s1'])) if p.grad is not None]
+        if not live:
+            return None
+        ps = [l[0].data for l in live]
+        gs = [l[1].contiguous() for l in live]
+        s1 = [l[2] for l in live]
+        s2 = [l[3] for l in live] if st['s2'] else None
+        self.step_count += 1
+        K.grad_norms(ps, gs, s1, s2, st['norms'], st['norm_sum'], st['flags'], grad_scale)
+        if check:
+            f = int(st['flags'].item())
+            assert not (f & 1), 'NaN in gradients (check_grad)'
+            assert not (f & 2), '|grad| > 1e5 (check_grad)'
+        self._launch(ps, gs, s1, s2, st['norms'], clip_norm, grad_scale)
+        ops.PARAM_EPOCH[0] += 1
+        self.last_norm_sum, self.last_flags = st['norm_sum'], st['flags']
+        return st['norm_sum']
+
+
+class RMSprop(_Fused):
+    """torch.optim.RMSprop defaults: alpha 0.99, eps 1e-8, no momentum (audiogan.py:693-694)."""
+    kind = K.OPT_RMSPROP
+
+    def __init__(self, params, lr=1e-2, alpha=0.99, eps=1e-8):
+        super().__init__(params, lr)
+        self.alpha, self.eps = alpha, eps
+
+    def _launch(self, ps, gs, s1, s2, norms, clip, gscale):
+        K.opt_step(ps, gs, s1, None, norms, K.OPT_RMSPROP, self.lr, float(clip), float(gscale),
+                   self.alpha, 0.0, self.eps, self.step_count)
+
+
+class Adam(_Fused):
+    """lr 1e-3, betas (0.9, 0.999), eps 1e-8 (computation_graph.py:58-59)."""
+    kind = K.OPT_ADAM
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        super().__init__(params, lr)
+        self.betas, self.eps = betas, eps
+
+    def _launch(self, ps, gs, s1, s2, norms, clip, gscale):
+        K.opt_step(ps, gs, s1, s2, norms, K.OPT_ADAM, self.lr, float(clip), float(gscale),
+                   self.betas[0], self.betas[1], self.eps, self.step_count)
+
+
+def make_optimizer(params, kind, lr):
+    if kind == 'rmsprop':
+        return RMSprop(params, lr=lr)
+    if kind == 'adam':
+        return Adam(params, lr=lr)
+    raise ValueError(kind)

@@ -1,0 +1,47 @@
+"""The canonical G+D step: audiogan.py:706-788 (critic) and :816-921
+(generator) minus the out-of-scope extras.  All stochastic inputs are arguments so the same
+numbers can be fed to the CPU oracle."""
+import torch
+
+from .losses import masked_bce_mean
+
+
+def d_step(g, d, opt_d, real, real_len, c, z, noise_real, noise_fake, dgradclip=1.0, stop='never',
+           grad_hook=None, check=False):
+    """One critic iteration: G forward without grad, D(real) vs 0.9, D(fake) vs 0
+    (audiogan.py:723-728, 739-740, 748-751, 761-766, 780-788)."""
+    with torch.no_grad():
+        fake, _, _, fake_len = g(z=z, c=c, stop=stop)
+        fake = fake + noise_fake
+    cls_d, _, _, nf_d = d(real + noise_real, real_len, c)
+    loss_d, _ = masked_bce_mean(cls_d, 0.9, nf_d)
+    cls_g, _, _, nf_g = d(fake, fake_len, c)
+    loss_g, _ = masked_bce_mean(cls_g, 0.0, nf_g)
+    loss = loss_d + loss_g
+    opt_d.zero_grad()
+    loss.backward()
+    scale = grad_hook() if grad_hook is not None else 1.0
+    opt_d.step(clip_norm=dgradclip, grad_scale=scale, check=check)
+    return loss.detach(), cls_d.detach(), cls_g.detach()
+
+
+def g_step(g, d, opt_g, c, z, noise_fake, ggradclip=0.1, g_optim='boundary_seeking', stop='never',
+           grad_hook=None, check=False):
+    """One generator iteration: loss through D into G (audiogan.py:841-845, 857-864, 897,
+    902-903, 909-921)."""
+    flags = [p.requires_grad for p in d.parameters()]
+    for p in d.parameters():
+        p.requires_grad_(False)
+    try:
+        fake, _, _, fake_len = g(z=z, c=c, stop=stop)
+        cls_g, _, _, nf_g = d(fake + noise_fake, fake_len, c)
+        tgt = 0.5 if g_optim == 'boundary_seeking' else 0.0
+        loss, _ = masked_bce_mean(cls_g, tgt, nf_g)
+        opt_g.zero_grad()
+        loss.backward()
+    finally:
+        for p, r in zip(d.parameters(), flags):
+            p.requires_grad_(r)
+    scale = grad_hook() if grad_hook is not None else 1.0
+    opt_g.step(clip_norm=ggradclip, grad_scale=scale, check=check)
+    return loss.detach(), fake.detach(), cls_g.detach()

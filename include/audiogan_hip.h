@@ -1,0 +1,233 @@
+/* audiogan_hip.h  --  C ABI of libaudiogan_hip.so (gfx950 / MI355X only).
+ *
+ * The reference (BarclayII/audiogan) has no FFI layer: its hot path bottoms out in
+ * third-party PyTorch ops called from audiogan.py.  Each entry point below replaces
+ * one of those implicit device ops; the comment on each names the reference call
+ * site(s) it stands in for (paths relative to /root/reference).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to fp32 data unless its name ends in _i64
+ *     (int64) or says otherwise; the library borrows them for the call and owns
+ *     nothing except the descriptor tables it is handed.
+ *   - tensors are dense along their last (time / feature) axis; batch and channel
+ *     strides are passed explicitly (in elements) so a layer can read from / write
+ *     into a slice of a pre-allocated channel slab (this is what removes the
+ *     T.cat at audiogan.py:467).
+ *   - `stream` is a hipStream_t passed as void*; kernels are enqueued, never
+ *     synchronised.  No allocation, no host sync inside any call (graph-capturable).
+ *   - return value: AG_OK (0) or a negative AG_ERR_* code; never aborts.
+ */
+#ifndef AUDIOGAN_HIP_H
+#define AUDIOGAN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AG_OK 0
+#define AG_ERR_ARG (-1)         /* bad shape / null pointer / unsupported size     */
+#define AG_ERR_LAUNCH (-2)      /* hipGetLastError() != hipSuccess after a launch  */
+#define AG_ERR_UNSUPPORTED (-3) /* valid request this build has no kernel for      */
+
+#define AG_ACT_NONE 0
+#define AG_ACT_LEAKY 1 /* LeakyReLU(slope): audiogan.py:261,277,532 (slope 0.01) */
+#define AG_ACT_TANH 2  /* audiogan.py:443 */
+
+/* library / build identification (ABI version, gfx arch string) */
+int ag_abi_version(void);
+const char* ag_arch(void);
+const char* ag_last_error(void);
+
+/* ---------------------------------------------------------------------------
+ * Weight norm  (audiogan.py:77-80; torch.nn.utils.weight_norm, dim 0)
+ *   w[r, :] = g[r] * v[r, :] / ||v[r, :]||_2      rows = size of dim 0, cols = rest
+ * A table of `n` descriptors (device memory, see ag_wn_desc) is processed by ONE
+ * launch.  For 3-D conv weights the kernel can also emit the two MFMA-friendly
+ * layouts the conv engine consumes (see ag_conv1d_engine).
+ * ------------------------------------------------------------------------- */
+typedef struct ag_wn_desc {
+  const float* v;  /* [rows, cols]                                      */
+  const float* g;  /* [rows]                                            */
+  float* w;        /* [rows, cols] standard layout (may be NULL)        */
+  float* wpa;      /* gather layout  [pad2(d1)][K][pad32(d0)]  or NULL  */
+  float* wpb;      /* scatter layout [d0][ceil(K/s)][pad32(d1*s)] or NULL */
+  float* inv_norm; /* [rows] 1/||v||, saved for backward (may be NULL)  */
+  int32_t rows;    /* d0                                                */
+  int32_t cols;    /* d1*K                                              */
+  int32_t d1;      /* second dim (1 for 2-D / 1-D tensors)              */
+  int32_t K;       /* taps (1 for 2-D / 1-D tensors)                    */
+  int32_t stride;  /* conv stride used for the wpb layout               */
+  int32_t pad_;
+} ag_wn_desc;
+
+int ag_weight_norm_fwd(const ag_wn_desc* descs_dev, int n, int max_rows, void* stream);
+
+typedef struct ag_wn_bwd_desc {
+  const float* v;
+  const float* g;
+  const float* dw; /* [rows, cols] gradient wrt w (standard layout) */
+  float* dv;       /* [rows, cols] */
+  float* dg;       /* [rows] */
+  int32_t rows;
+  int32_t cols;
+} ag_wn_bwd_desc;
+
+int ag_weight_norm_bwd(const ag_wn_bwd_desc* descs_dev, int n, int max_rows, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * 1-D convolution engine (fp32 MFMA implicit GEMM).  One kernel family covers
+ *   mode 0 "gather":  y[b,o,t]      = sum_{c,k} W[o,c,k] x[b,c, s*t+k-p]
+ *        = NN.Conv1d forward            (audiogan.py:272,406,490)
+ *        = NN.ConvTranspose1d backward-data
+ *   mode 1 "scatter": y[b,o,s*t+k-p] += sum_c W[c,o,k] x[b,c,t]
+ *        = NN.ConvTranspose1d forward   (audiogan.py:275)
+ *        = NN.Conv1d backward-data      (loss.backward(), audiogan.py:785,903)
+ * followed by the fused epilogue
+ *   v = acc + bias[o] + res[b,o,t];  v = act(v);  v *= (t < lens_i64[b]);
+ *   y = accumulate ? y + v : v
+ * (bias/res/lens optional).  `wp` is the prepared weight layout written by
+ * ag_weight_norm_fwd (wpa for mode 0, wpb for mode 1) or by ag_prep_conv_weight.
+ * ------------------------------------------------------------------------- */
+typedef struct ag_conv_args {
+  const float* x;
+  const float* wp;
+  const float* bias;
+  const float* res;
+  float* y;
+  const int64_t* lens_i64;
+  int64_t x_bs, x_cs;     /* input batch / channel stride (elements)  */
+  int64_t y_bs, y_cs;     /* output strides                            */
+  int64_t res_bs, res_cs; /* residual strides                          */
+  int32_t B, C, Lin, O, Lout;
+  int32_t K, stride, pad; /* parameters of the underlying conv         */
+  int32_t mode;           /* 0 gather, 1 scatter                       */
+  int32_t act;            /* AG_ACT_*                                  */
+  float slope;
+  int32_t accumulate;
+} ag_conv_args;
+
+int ag_conv1d_engine(const ag_conv_args* args, void* stream);
+
+/* plain (non weight-normed) weights -> engine layouts; w is [d0][d1][K] */
+int ag_prep_conv_weight(const float* w, float* wpa, float* wpb, int d0, int d1, int K, int stride,
+                        void* stream);
+/* sizes (in floats) of the two layouts, so the host can allocate them */
+int64_t ag_wpa_numel(int d0, int d1, int K);
+int64_t ag_wpb_numel(int d0, int d1, int K, int stride);
+
+/* Weight gradient of a strided conv (conv backward-weight, convT backward-weight):
+ *   dw[a,c,k] (+)= sum_{b,t} sh[b,a,t] * lg[b,c, s*t+k-p]
+ * Conv1d:          sh = dY (a = out ch),  lg = x  (c = in ch)   -> dw[O][C][K]
+ * ConvTranspose1d: sh = x  (a = in ch),   lg = dY (c = out ch)  -> dw[Ci][Co][K]
+ * dw must be zero-filled (or hold a value to accumulate into); fp32 atomics. */
+int ag_conv1d_wgrad(const float* sh, int64_t sh_bs, int64_t sh_cs, const float* lg, int64_t lg_bs,
+                    int64_t lg_cs, float* dw, int B, int A, int Lsh, int C, int Llg, int K,
+                    int stride, int pad, void* stream);
+
+/* db[c] (+)= sum_{b,t} dy[b,c,t]   (bias gradient; atomics, db pre-zeroed) */
+int ag_channel_sum(const float* dy, int64_t bs, int64_t cs, float* db, int B, int C, int L,
+                   void* stream);
+
+/* dpre = dy * (y > 0 ? 1 : slope) * (t < lens[b])   elementwise on [B,C,L] views.
+ * LeakyReLU keeps the sign, so the saved OUTPUT y is enough (no pre-activation).
+ * add_into (optional, same shape): add_into += dpre  -- the gradient of the
+ * "act += x[:, -out:, :]" skip connection of dense_res_bottleneck (audiogan.py:281-282). */
+int ag_leaky_bwd(const float* dy, int64_t dy_bs, int64_t dy_cs, const float* y, int64_t y_bs,
+                 int64_t y_cs, float* dpre, int64_t dp_bs, int64_t dp_cs, float* add_into,
+                 int64_t ad_bs, int64_t ad_cs, const int64_t* lens_i64, int B, int C, int L,
+                 float slope, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Dense fp32 GEMM on MFMA (NN.Linear / LSTM gate products: audiogan.py:260,380,
+ * 385,409,410,498,509,511 and their backward):
+ *   C[M,N] = act( alpha * op(A)[M,K] * op(B)[K,N] + beta * C + bias[N] + res[M,N] )
+ * ta: 0 -> A is [M,K] row-major (lda), 1 -> A is stored [K,M]
+ * tb: 0 -> B is [K,N] row-major (ldb), 1 -> B is stored [N,K]   (Linear weight)
+ * ------------------------------------------------------------------------- */
+int ag_gemm(const float* A, int lda, int ta, const float* B, int ldb, int tb, float* C, int ldc,
+            int M, int N, int K, float alpha, float beta, const float* bias, const float* res,
+            int ldres, int act, float slope, void* stream);
+
+/* column sums: out[n] (+)= sum_m X[m, n]   (Linear bias gradient) */
+int ag_col_sum(const float* X, int ldx, float* out, int M, int N, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * LSTM cell pointwise step (NN.LSTMCell / NN.LSTM, audiogan.py:380,440-442,498):
+ * gates[B,4H] hold i|f|g|o pre-activations (PyTorch order) INCLUDING biases.
+ *   i,f,o = sigmoid, g = tanh;  c' = f*c + i*g;  h' = o*tanh(c')
+ * fwd overwrites gates with the ACTIVATED values (saved for backward).
+ * `valid_i64`/`t`: rows with t >= valid[b] keep (h,c) unchanged and output 0
+ * (packed-sequence semantics of dynamic_rnn, audiogan.py:214-229); NULL = all valid.
+ * ------------------------------------------------------------------------- */
+int ag_lstm_cell_fwd(float* gates, int ldg, const float* c_prev, int ldcp, float* h_out, int ldh,
+                     float* c_out, int ldc, float* y_out, int ldy, const float* h_prev, int ldhp,
+                     const int64_t* valid_i64, int t, int B, int H, void* stream);
+/* backward: dh = gradient reaching the state h' from later steps (NULL = 0), dy = gradient
+ * of the step's output (NULL = 0), dc_next (NULL = 0) -> dgates (pre-activation), dc_prev.
+ * Valid rows use dh + dy and write dh_pass = 0; padded rows write dgates = 0,
+ * dc_prev = dc_next and pass dh through (dh_pass = dh; their output was the constant 0). */
+int ag_lstm_cell_bwd(const float* gates_act, int ldg, const float* c_prev, int ldcp,
+                     const float* c_new, int ldc, const float* dh, int lddh, const float* dy,
+                     int lddy, const float* dc_next, int lddcn, float* dgates, int lddg,
+                     float* dc_prev, int lddcp, float* dh_pass, int lddhp, const int64_t* valid_i64,
+                     int t, int B, int H, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Masked BCE-with-logits per sample (audiogan.py:187-197 + :204-211 + the
+ * "/ nframes ... .mean()" at :739-740,766,780,864,897), fused:
+ *   l[b,t]  = x - x*target + m + log(exp(-m) + exp(-x-m)),  m = max(-x, 0)
+ *   per[b]  = sum_{t < n[b]} l[b,t]               n = nframes_i64 (NULL: all T)
+ *   loss   += scale * sum_b per[b] / n[b]         (scale = 1/B gives the mean)
+ * bwd: dx[b,t] = gscale * scale / n[b] * (sigmoid(x) - target) * (t < n[b])
+ * ------------------------------------------------------------------------- */
+int ag_bce_logits_fwd(const float* x, int ldx, float target, const int64_t* nframes_i64,
+                      float* per_sample, float* loss, float scale, int B, int T, void* stream);
+int ag_bce_logits_bwd(const float* x, int ldx, float target, const int64_t* nframes_i64,
+                      const float* gscale_dev, float scale, float* dx, int lddx, int B, int T,
+                      void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Elementwise helpers
+ * ------------------------------------------------------------------------- */
+/* y = act(x) on n contiguous floats (in place allowed) */
+int ag_act_fwd(const float* x, float* y, int64_t n, int act, float slope, void* stream);
+/* dx = dy * act'(.) using the saved OUTPUT y */
+int ag_act_bwd(const float* dy, const float* y, float* dx, int64_t n, int act, float slope,
+               void* stream);
+/* y = a*x + b*y  on n contiguous floats */
+int ag_axpby(const float* x, float* y, int64_t n, float a, float b, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Fused optimiser: check_grad + per-PARAMETER clip + update for a whole network
+ * in two launches (audiogan.py:232-253, 693-694, 786-788, 909-921).
+ *   pass 1: norm[i] = ||grad_i||_2 ; flags |= NaN / |g|>1e5
+ *   pass 2: g = grad * min(1, clip/norm[i]) (clip == 0: no clip), then
+ *     RMSprop (torch defaults): sq = a*sq + (1-a) g^2 ; p -= lr * g / (sqrt(sq)+eps)
+ *     Adam (TF/torch defaults): m,v moments with bias correction from `step`
+ * `norm_sum` receives sum_i norm[i] (the value clip_grad returns, :253).
+ * ------------------------------------------------------------------------- */
+typedef struct ag_opt_desc {
+  float* p;
+  const float* grad;
+  float* s1; /* RMSprop: square_avg ; Adam: exp_avg    */
+  float* s2; /* Adam: exp_avg_sq (unused for RMSprop)  */
+  int64_t n;
+} ag_opt_desc;
+
+#define AG_OPT_RMSPROP 0
+#define AG_OPT_ADAM 1
+#define AG_FLAG_NAN 1
+#define AG_FLAG_BIG 2
+
+int ag_grad_norms(const ag_opt_desc* descs_dev, int n, float* norms, float* norm_sum,
+                  int32_t* flags, float grad_scale, void* stream);
+int ag_opt_step(const ag_opt_desc* descs_dev, int n, const float* norms, int kind, float lr,
+                float clip, float grad_scale, float alpha_or_beta1, float beta2, float eps, int step,
+                void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AUDIOGAN_HIP_H */

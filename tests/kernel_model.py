@@ -1,0 +1,282 @@
+"""Torch-CPU model of every entry point of ``audiogan_amd.kernels``  --  TEST INFRASTRUCTURE.
+
+Written from the contracts in include/audiogan_hip.h.  The CPU test-suite monkeypatches
+``audiogan_amd.kernels`` with these functions so that the HOST logic of the package
+(autograd blocks, slab bookkeeping, weight layouts, module API, DDP, optimiser wiring) can be
+checked against the oracle without a GPU.  The product never imports this file; on the GPU
+box the real HIP kernels run and are themselves compared with the oracle (tests -m gpu).
+"""
+import torch
+import torch.nn.functional as F
+
+ACT_NONE, ACT_LEAKY, ACT_TANH = 0, 1, 2
+OPT_RMSPROP, OPT_ADAM = 0, 1
+LEAKY_SLOPE = 0.01
+
+
+def _r(a, b):
+    return (a + b - 1) // b * b
+
+
+def wpa_numel(d0, d1, K):
+    return _r(d1, 2) * K * _r(d0, 32)
+
+
+def wpb_numel(d0, d1, K, stride):
+    return _r(d0, 2) * ((K + stride - 1) // stride) * _r(d1 * stride, 32)
+
+
+def _fill_layouts(w, wpa, wpb, stride):
+    d0, d1, K = w.shape
+    if wpa is not None:
+        wpa.view(_r(d1, 2), K, _r(d0, 32))[:d1, :, :d0] = w.permute(1, 2, 0)
+    if wpb is not None:
+        mt, mp = (K + stride - 1) // stride, _r(d1 * stride, 32)
+        v = wpb.view(_r(d0, 2), mt, mp)
+        for k in range(K):
+            v[:d0, k // stride, torch.arange(d1) * stride + k % stride] = w[:, :, k]
+
+
+def weight_norm_fwd(entries):
+    for e in entries:
+        v, g = e['v'], e['g']
+        rows = v.size(0)
+        v2 = v.reshape(rows, -1)
+        w = (v2 * (g.view(rows, 1) / v2.norm(dim=1, keepdim=True))).view(v.shape)
+        if e.get('w') is not None:
+            e['w'].copy_(w)
+        if v.dim() == 3:
+            _fill_layouts(w, e.get('wpa'), e.get('wpb'), int(e.get('stride', 1)))
+
+
+def weight_norm_bwd(entries):
+    for e in entries:
+        v, g, dw = e['v'], e['g'], e['dw']
+        rows = v.size(0)
+        v2, dw2 = v.reshape(rows, -1), dw.reshape(rows, -1)
+        inv = 1.0 / v2.norm(dim=1, keepdim=True)
+        dot = (v2 * dw2).sum(1, keepdim=True)
+        e['dg'].copy_((dot * inv).view(-1))
+        e['dv'].copy_((g.view(rows, 1) * inv * (dw2 - v2 * dot * inv * inv)).view(v.shape))
+
+
+def prep_conv_weight(w, wpa, wpb, stride):
+    _fill_layouts(w, wpa, wpb, stride)
+
+
+def _act(v, act, slope):
+    if act == ACT_LEAKY:
+        return torch.where(v > 0, v, v * slope)
+    if act == ACT_TANH:
+        return torch.tanh(v)
+    return v
+
+
+def _fit(t, n):
+    if t.size(2) >= n:
+        return t[:, :, :n]
+    return F.pad(t, (0, n - t.size(2)))
+
+
+def conv_engine(x, wp, y, K, stride, pad, mode, bias=None, res=None, lens=None, act=ACT_NONE,
+                slope=LEAKY_SLOPE, accumulate=False):
+    B, C, Lin = x.shape
+    _, O, Lout = y.shape
+    if mode == 0:
+        assert wp.numel() == wpa_numel(O, C, K)
+        w = wp.view(_r(C, 2), K, _r(O, 32))[:C, :, :O].permute(2, 0, 1)          # [O,C,K]
+        out = _fit(F.conv1d(x, w, None, stride, pad), Lout)
+    else:
+        assert wp.numel() == wpb_numel(C, O, K, stride)
+        mt, mp = (K + stride - 1) // stride, _r(O * stride, 32)
+        v = wp.view(_r(C, 2), mt, mp)
+        w = torch.stack([v[:C, k // stride, torch.arange(O) * stride + k % stride] for k in range(K)], 2)
+        full = F.conv_transpose1d(x, w, None, stride, 0)                    # w: [C,O,K]; u + pad
+        out = _fit(full[:, :, pad:], Lout)
+    if bias is not None:
+        out = out + bias.view(1, O, 1)
+    if res is not None:
+        out = out + res
+    out = _act(out, act, slope)
+    if lens is not None:
+        out = out * (torch.arange(Lout).view(1, 1, Lout) < lens.view(B, 1, 1)).float()
+    if accumulate:
+        out = out + y
+    y.copy_(out)
+
+
+def conv_wgrad(sh, lg, dw, K, stride, pad):
+    B, A, Lsh = sh.shape
+    _, C, Llg = lg.shape
+    need = stride * (Lsh - 1) + K
+    lp = F.pad(lg, (pad, max(0, need - pad - Llg)))
+    acc = torch.zeros(A, C, K)
+    for k in range(K):
+        acc[:, :, k] = torch.einsum('bat,bct->ac', sh, lp[:, :, k:k + stride * (Lsh - 1) + 1:stride])
+    dw.add_(acc.view(dw.shape))
+
+
+def channel_sum(dy, db):
+    db.add_(dy.sum((0, 2)))
+
+
+def leaky_bwd(dy, y, dpre, lens=None, slope=LEAKY_SLOPE, add_into=None):
+    B, C, L = dy.shape
+    g = torch.where(y > 0, dy, dy * slope)
+    if lens is not None:
+        g = g * (torch.arange(L).view(1, 1, L) < lens.view(B, 1, 1)).float()
+    dpre.copy_(g)
+    if add_into is not None:
+        add_into.add_(g)
+
+
+def gemm(A, B, Cm, ta=False, tb=False, alpha=1.0, beta=0.0, bias=None, res=None, act=ACT_NONE,
+         slope=LEAKY_SLOPE):
+    a = A.t() if ta else A
+    b = B.t() if tb else B
+    out = alpha * (a @ b)
+    if beta != 0.0:
+        out = out + beta * Cm
+    if bias is not None:
+        out = out + bias.view(1, -1)
+    if res is not None:
+        out = out + res
+    Cm.copy_(_act(out, act, slope))
+
+
+def col_sum(X, out):
+    out.add_(X.sum(0))
+
+
+def lstm_cell_fwd(gates, c_prev, c_out, h_out=None, y_out=None, h_prev=None, valid=None, t=0):
+    B, H4 = gates.shape
+    H = H4 // 4
+    i, f, g, o = [gates[:, k * H:(k + 1) * H] for k in range(4)]
+    ia, fa, ga, oa = torch.sigmoid(i), torch.sigmoid(f), torch.tanh(g), torch.sigmoid(o)
+    cn = fa * c_prev + ia * ga
+    hn = oa * torch.tanh(cn)
+    if valid is not None:
+        ok = (t < valid).view(B, 1)
+    else:
+        ok = torch.ones(B, 1, dtype=torch.bool)
+    hp = h_prev if h_prev is not None else torch.zeros(B, H)
+    new_gates = torch.where(ok, torch.cat([ia, fa, ga, oa], 1), gates)
+    cn2, hn2, yn = torch.where(ok, cn, c_prev), torch.where(ok, hn, hp), torch.where(ok, hn, torch.zeros(B, H))
+    gates.copy_(new_gates)
+    c_out.copy_(cn2)
+    if h_out is not None:
+        h_out.copy_(hn2)
+    if y_out is not None:
+        y_out.copy_(yn)
+
+
+def lstm_cell_bwd(gates_act, c_prev, c_new, dh, dy, dc_next, dgates, dc_prev, dh_pass=None,
+                  valid=None, t=0):
+    B, H4 = gates_act.shape
+    H = H4 // 4
+    ig, fg, gg, og = [gates_act[:, k * H:(k + 1) * H] for k in range(4)]
+    z = torch.zeros(B, H)
+    dhf = dh if dh is not None else z
+    dcn = dc_next if dc_next is not None else z
+    dhv = dhf + (dy if dy is not None else z)
+    tc = torch.tanh(c_new)
+    dc = dcn + dhv * og * (1 - tc * tc)
+    dg = torch.cat([dc * gg * ig * (1 - ig), dc * c_prev * fg * (1 - fg), dc * ig * (1 - gg * gg),
+                    dhv * tc * og * (1 - og)], 1)
+    ok = (t < valid).view(B, 1) if valid is not None else torch.ones(B, 1, dtype=torch.bool)
+    dgates.copy_(torch.where(ok, dg, torch.zeros_like(dg)))
+    dc_prev.copy_(torch.where(ok, dc * fg, dcn))
+    if dh_pass is not None:
+        dh_pass.copy_(torch.where(ok, z, dhf))
+
+
+def _bce_elem(x, target):
+    m = (-x).clamp(min=0)
+    return x - x * target + m + ((-m).exp() + (-x - m).exp()).log()
+
+
+def bce_logits_fwd(x, target, nframes, per_sample, loss, scale):
+    B, T = x.shape
+    n = nframes if nframes is not None else torch.full((B,), T, dtype=torch.long)
+    mask = (torch.arange(T).view(1, T) < n.view(B, 1)).float()
+    per = (_bce_elem(x, target) * mask).sum(1)
+    if per_sample is not None:
+        per_sample.copy_(per)
+    if loss is not None:
+        loss.add_(scale * (per / n.float()).sum())
+
+
+def bce_logits_bwd(x, target, nframes, gscale, scale, dx):
+    B, T = x.shape
+    n = nframes if nframes is not None else torch.full((B,), T, dtype=torch.long)
+    mask = (torch.arange(T).view(1, T) < n.view(B, 1)).float()
+    gs = gscale.view(()) if gscale is not None else 1.0
+    dx.copy_(gs * scale / n.float().view(B, 1) * (torch.sigmoid(x) - target) * mask)
+
+
+def act_fwd(x, y, act, slope=LEAKY_SLOPE):
+    y.copy_(_act(x, act, slope))
+
+
+def act_bwd(dy, y, dx, act, slope=LEAKY_SLOPE):
+    if act == ACT_LEAKY:
+        g = torch.where(y > 0, dy, dy * slope)
+    elif act == ACT_TANH:
+        g = dy * (1 - y * y)
+    else:
+        g = dy
+    dx.copy_(g)
+
+
+def axpby(x, y, a, b):
+    y.copy_(a * x + (b * y if b != 0.0 else 0.0))
+
+
+def grad_norms(params, grads, s1, s2, norms, norm_sum, flags, grad_scale=1.0):
+    f = 0
+    tot = 0.0
+    for i, g in enumerate(grads):
+        gs = g * grad_scale
+        n = gs.norm()
+        norms[i] = n
+        tot = tot + n
+        if bool((gs != gs).any()):
+            f |= 1
+        if bool((gs.abs() > 1e5).any()):
+            f |= 2
+    if norm_sum is not None:
+        norm_sum.fill_(float(tot))
+    if flags is not None:
+        flags.fill_(f)
+
+
+def opt_step(params, grads, s1, s2, norms, kind, lr, clip, grad_scale, a1, b2, eps, step):
+    for i, p in enumerate(params):
+        g = grads[i].reshape(-1) * grad_scale
+        n = norms[i]
+        pf = p.data.view(-1)
+        if clip > 0 and float(n) > clip:
+            g = g / (n / clip)
+        if kind == OPT_RMSPROP:
+            s1[i].view(-1).mul_(a1).add_((1 - a1) * g * g)
+            pf.sub_(lr * g / (s1[i].view(-1).sqrt() + eps))
+        else:
+            s1[i].view(-1).mul_(a1).add_((1 - a1) * g)
+            s2[i].view(-1).mul_(b2).add_((1 - b2) * g * g)
+            bc1 = 1 - a1 ** step
+            bc2s = (1 - b2 ** step) ** 0.5
+            pf.sub_((lr / bc1) * s1[i].view(-1) / (s2[i].view(-1).sqrt() / bc2s + eps))
+
+
+ALL = [n for n, v in list(globals().items()) if callable(v) and not n.startswith('_')
+       and n not in ('F',)]
+
+
+def install(monkeypatch):
+    """Replace every function of audiogan_amd.kernels by its CPU model (pytest monkeypatch)."""
+    import audiogan_amd.kernels as K
+    for n in ALL:
+        if n == 'install':
+            continue
+        assert hasattr(K, n), 'kernel model has %s but audiogan_amd.kernels does not' % n
+        monkeypatch.setattr(K, n, globals()[n])

@@ -1,0 +1,300 @@
+"""-m gpu: every HIP kernel called through the C ABI (audiogan_amd.kernels -> ctypes ->
+libaudiogan_hip.so) and compared with torch-CPU fp32 on the same seeded inputs.
+Tolerance: 1e-3 relative (north_star), written per test; most kernels are far tighter because
+v_mfma_f32_32x32x2_f32 is an exact fp32 fma chain."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests import kernel_model as KM
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def K():
+    assert torch.cuda.is_available(), 'gpu tests need a GPU'
+    import audiogan_amd.kernels as K_
+    assert K_.conv_engine.__module__ == 'audiogan_amd.kernels', 'real kernels must be in place'
+    return K_
+
+
+def dev(t):
+    return t.cuda() if t is not None else None
+
+
+def close(got, ref, rtol=1e-3, atol=None, msg=''):
+    ref = ref.detach().cpu().float().numpy() if torch.is_tensor(ref) else np.asarray(ref)
+    got = got.detach().cpu().float().numpy() if torch.is_tensor(got) else np.asarray(got)
+    if atol is None:
+        atol = 1e-5 * max(1.0, float(np.abs(ref).max()))
+    np.testing.assert_allclose(got, ref, rtol=rtol, atol=atol, err_msg=msg)
+
+
+# C2 layer table: kind, cin, cout, K, stride, pad, Lin
+G_LAYERS = [('conv', 1, 128, 17, 8, 8, 8192), ('convT', 128, 16, 16, 8, 4, 1024),
+            ('conv', 17, 64, 9, 4, 4, 8192), ('convT', 64, 32, 8, 4, 2, 2048),
+            ('conv', 49, 64, 9, 4, 4, 8192), ('conv', 81, 32, 9, 4, 4, 8192),
+            ('convT', 32, 32, 8, 4, 2, 2048), ('conv', 113, 1, 3, 1, 1, 8192)]
+D_LAYERS = [('conv', 1, 16, 7, 2, 3, 8192), ('conv', 16, 32, 7, 2, 3, 4096), ('conv', 32, 64, 7, 2, 3, 2048),
+            ('conv', 64, 128, 7, 2, 3, 1024), ('conv', 128, 256, 7, 2, 3, 512), ('conv', 256, 512, 7, 2, 3, 256)]
+EDGE_LAYERS = [('conv', 3, 5, 5, 2, 2, 16), ('convT', 5, 3, 4, 2, 1, 8), ('conv', 2, 3, 1, 1, 0, 7),
+               ('conv', 7, 33, 5, 5, 2, 333), ('convT', 6, 7, 5, 5, 0, 41), ('conv', 5, 70, 3, 3, 1, 100),
+               ('convT', 3, 20, 5, 2, 2, 129), ('conv', 1, 1, 3, 1, 1, 1), ('conv', 130, 140, 3, 1, 1, 70)]
+
+
+def _out_len(kind, lin, k, s, p):
+    return (lin + 2 * p - k) // s + 1 if kind == 'conv' else (lin - 1) * s - 2 * p + k
+
+
+def _mk(kind, cin, cout, k, s, p, lin, B, seed):
+    gen = torch.Generator().manual_seed(seed)
+    w = torch.randn((cout, cin, k) if kind == 'conv' else (cin, cout, k), generator=gen) / (cin * k) ** 0.5
+    x = torch.randn(B, cin, lin, generator=gen)
+    return w, x
+
+
+@pytest.mark.parametrize('layer', G_LAYERS + D_LAYERS + EDGE_LAYERS)
+def test_conv_forward_backward_data(K, layer):
+    kind, cin, cout, k, s, p, lin = layer
+    B = 2
+    w, x = _mk(kind, cin, cout, k, s, p, lin, B, 1)
+    lout = _out_len(kind, lin, k, s, p)
+    gen = torch.Generator().manual_seed(2)
+    bias = torch.randn(cout, generator=gen)
+    res = torch.randn(B, cout, lout, generator=gen)
+    lens = torch.tensor([lout, max(1, lout // 3)])
+    d0, d1, _ = w.shape
+    wpa, wpb = torch.zeros(K.wpa_numel(d0, d1, k)).cuda(), torch.zeros(K.wpb_numel(d0, d1, k, s)).cuda()
+    K.prep_conv_weight(dev(w), wpa, wpb, s)
+    ra, rb = torch.zeros(wpa.numel()), torch.zeros(wpb.numel())
+    KM.prep_conv_weight(w, ra, rb, s)
+    close(wpa, ra, rtol=0, atol=0)
+    close(wpb, rb, rtol=0, atol=0)
+    fwd_mode = 0 if kind == 'conv' else 1
+    fwd_wp, bwd_wp = (wpa, wpb) if kind == 'conv' else (wpb, wpa)
+    # forward, full epilogue
+    xr = x.clone().requires_grad_(True)
+    lin_out = F.conv1d(xr, w, bias, s, p) if kind == 'conv' else F.conv_transpose1d(xr, w, bias, s, p)
+    ref = F.leaky_relu(lin_out + res) * (torch.arange(lout).view(1, 1, -1) < lens.view(B, 1, 1)).float()
+    y = torch.full((B, cout, lout), float('nan')).cuda()
+    K.conv_engine(dev(x), fwd_wp, y, k, s, p, fwd_mode, bias=dev(bias), res=dev(res), lens=dev(lens),
+                  act=K.ACT_LEAKY)
+    close(y, ref, msg='forward')
+    # plain forward + accumulate
+    y2 = dev(res.clone())
+    K.conv_engine(dev(x), fwd_wp, y2, k, s, p, fwd_mode, accumulate=True)
+    plain = F.conv1d(x, w, None, s, p) if kind == 'conv' else F.conv_transpose1d(x, w, None, s, p)
+    close(y2, plain + res, msg='accumulate')
+    # backward-data (adjoint)
+    gy = torch.randn(B, cout, lout, generator=gen)
+    lin_out.backward(gy)
+    dx = torch.full((B, cin, lin), float('nan')).cuda()
+    K.conv_engine(dev(gy), bwd_wp, dx, k, s, p, 1 - fwd_mode)
+    close(dx, xr.grad, msg='backward-data')
+
+
+@pytest.mark.parametrize('layer', G_LAYERS + D_LAYERS + EDGE_LAYERS)
+def test_conv_weight_bias_grad(K, layer):
+    kind, cin, cout, k, s, p, lin = layer
+    B = 3
+    w, x = _mk(kind, cin, cout, k, s, p, lin, B, 3)
+    wr, xr = w.clone().requires_grad_(True), x
+    b = torch.zeros(cout, requires_grad=True)
+    y = F.conv1d(xr, wr, b, s, p) if kind == 'conv' else F.conv_transpose1d(xr, wr, b, s, p)
+    gy = torch.randn(y.shape, generator=torch.Generator().manual_seed(4))
+    y.backward(gy)
+    dw = torch.zeros_like(w).cuda()
+    db = torch.zeros(cout).cuda()
+    if kind == 'conv':
+        K.conv_wgrad(dev(gy), dev(x), dw, k, s, p)
+    else:
+        K.conv_wgrad(dev(x), dev(gy), dw, k, s, p)
+    K.channel_sum(dev(gy), db)
+    close(dw, wr.grad, msg='dw')
+    close(db, b.grad, msg='db')
+
+
+def test_conv_slab_views_and_residual_grad(K):
+    """strided views into a channel slab (what removes the T.cat) + leaky_bwd add_into"""
+    B, L = 2, 256
+    gen = torch.Generator().manual_seed(5)
+    slab = torch.randn(B, 12, L, generator=gen)
+    w = torch.randn(4, 8, 8, generator=gen) * 0.2          # convT 8 -> 4, k8 s4 p2 on hidden
+    hid = torch.randn(B, 8, L // 4, generator=gen)
+    wpb = torch.zeros(K.wpb_numel(8, 4, 8, 4)).cuda()
+    K.prep_conv_weight(dev(w.permute(1, 0, 2).contiguous()), None, wpb, 4)
+    wt = w.permute(1, 0, 2).contiguous()                   # [Cin=8, Cout=4, K]
+    ref = F.leaky_relu(F.conv_transpose1d(hid, wt, None, 4, 2) + slab[:, 4:8])
+    s_d = dev(slab.clone())
+    K.conv_engine(dev(hid), wpb, s_d[:, 8:12], 8, 4, 2, 1, res=s_d[:, 4:8], act=K.ACT_LEAKY)
+    close(s_d[:, 8:12], ref)
+    close(s_d[:, :8], slab[:, :8], rtol=0, atol=0)         # neighbours untouched
+    dsl = torch.randn(B, 12, L, generator=gen)
+    d_d = dev(dsl.clone())
+    K.leaky_bwd(d_d[:, 8:12], s_d[:, 8:12], d_d[:, 8:12], add_into=d_d[:, 4:8])
+    g = torch.where(ref > 0, dsl[:, 8:12], dsl[:, 8:12] * 0.01)
+    close(d_d[:, 8:12], g)
+    close(d_d[:, 4:8], dsl[:, 4:8] + g)
+    close(d_d[:, :4], dsl[:, :4], rtol=0, atol=0)
+
+
+@pytest.mark.parametrize('shape', [(64, 4096, 1480), (8192, 1024, 1024), (8192, 1, 512), (37, 53, 29),
+                                   (64, 256, 1024), (130, 70, 5), (1, 1, 1), (2048, 4096, 200)])
+@pytest.mark.parametrize('ta,tb', [(False, True), (False, False), (True, False), (True, True)])
+def test_gemm(K, shape, ta, tb):
+    M, N, Kd = shape
+    if M * N * Kd > 3e9 and (ta or not tb):
+        pytest.skip('largest shape only in the Linear orientation')
+    gen = torch.Generator().manual_seed(6)
+    A = torch.randn((Kd, M) if ta else (M, Kd), generator=gen) / Kd ** 0.5
+    Bm = torch.randn((N, Kd) if tb else (Kd, N), generator=gen)
+    C0 = torch.randn(M, N, generator=gen)
+    bias, res = torch.randn(N, generator=gen), torch.randn(M, N, generator=gen)
+    ref = F.leaky_relu(0.5 * ((A.t() if ta else A) @ (Bm.t() if tb else Bm)) + 2.0 * C0 + bias + res)
+    Cd = dev(C0.clone())
+    K.gemm(dev(A), dev(Bm), Cd, ta=ta, tb=tb, alpha=0.5, beta=2.0, bias=dev(bias), res=dev(res),
+           act=K.ACT_LEAKY)
+    close(Cd, ref)
+
+
+def test_gemm_strided_views(K):
+    gen = torch.Generator().manual_seed(7)
+    big = torch.randn(64, 456, generator=gen)
+    w = torch.randn(128, 456, generator=gen)
+    out = torch.zeros(10, 64, 128)
+    o_d = dev(out)
+    K.gemm(dev(big)[:, 256:], dev(w)[:, 256:], o_d[3], tb=True)
+    close(o_d[3], big[:, 256:] @ w[:, 256:].t())
+    x = torch.randn(64, 8 * 32, generator=gen)
+    x_d = dev(x.clone())
+    h = torch.randn(64, 100, generator=gen)
+    pw = torch.randn(32, 100, generator=gen)
+    K.gemm(dev(h), dev(pw), x_d[:, 64:96], tb=True, act=K.ACT_TANH)
+    ref = x.clone()
+    ref[:, 64:96] = torch.tanh(h @ pw.t())
+    close(x_d, ref)
+    cs = torch.zeros(128).cuda()
+    K.col_sum(dev(w)[:, 200:328], cs)
+    close(cs, w[:, 200:328].sum(0))
+
+
+def test_lstm_cell(K):
+    B, H = 5, 70
+    gen = torch.Generator().manual_seed(8)
+    gates, cp, hp = torch.randn(B, 4 * H, generator=gen), torch.randn(B, H, generator=gen), torch.randn(B, H, generator=gen)
+    valid = torch.tensor([3, 1, 0, 7, 2])
+    for v, t in ((None, 0), (valid, 2)):
+        rg, rc, rh, ry = gates.clone(), torch.empty(B, H), torch.empty(B, H), torch.empty(B, H)
+        KM.lstm_cell_fwd(rg, cp, rc, rh, ry, hp, v, t)
+        g_d, c_d, h_d, y_d = dev(gates.clone()), torch.empty(B, H).cuda(), torch.empty(B, H).cuda(), torch.empty(B, H).cuda()
+        K.lstm_cell_fwd(g_d, dev(cp), c_d, h_d, y_d, dev(hp), dev(v), t)
+        ok = torch.ones(B, dtype=torch.bool) if v is None else (t < v)
+        close(g_d[ok], rg[ok]); close(c_d, rc); close(h_d, rh); close(y_d, ry)
+        dh, dy, dcn = torch.randn(B, H, generator=gen), torch.randn(B, H, generator=gen), torch.randn(B, H, generator=gen)
+        rdg, rdc, rdp = torch.empty(B, 4 * H), torch.empty(B, H), torch.empty(B, H)
+        KM.lstm_cell_bwd(rg, cp, rc, dh, dy, dcn, rdg, rdc, rdp, v, t)
+        dg_d, dc_d, dp_d = torch.empty(B, 4 * H).cuda(), torch.empty(B, H).cuda(), torch.empty(B, H).cuda()
+        K.lstm_cell_bwd(dev(rg), dev(cp), dev(rc), dev(dh), dev(dy), dev(dcn), dg_d, dc_d, dp_d, dev(v), t)
+        close(dg_d, rdg); close(dc_d, rdc); close(dp_d, rdp)
+
+
+def test_weight_norm(K):
+    gen = torch.Generator().manual_seed(9)
+    shapes = [(128, 1, 17), (128, 16, 16), (64, 49, 9), (4096, 456), (4096,), (1, 113, 3), (512, 256, 7), (3,)]
+    strides = [8, 8, 4, 1, 1, 1, 2, 1]
+    ents_d, ents_c = [], []
+    for sh, s in zip(shapes, strides):
+        v = torch.randn(sh, generator=gen)
+        g = torch.rand(sh[0], generator=gen) + 0.5
+        e = dict(v=v, g=g, w=torch.empty(sh), stride=s)
+        if len(sh) == 3:
+            e['wpa'] = torch.zeros(K.wpa_numel(sh[0], sh[1], sh[2]))
+            e['wpb'] = torch.zeros(K.wpb_numel(sh[0], sh[1], sh[2], s))
+        ents_c.append(e)
+        ents_d.append({k: (dev(t) if torch.is_tensor(t) else t) for k, t in e.items()})
+    KM.weight_norm_fwd(ents_c)
+    K.weight_norm_fwd(ents_d)
+    for a, b in zip(ents_d, ents_c):
+        for k in ('w', 'wpa', 'wpb'):
+            if k in b:
+                close(a[k], b[k], rtol=1e-5, msg=k)
+    bd, bc = [], []
+    for e in ents_c:
+        dw = torch.randn(e['v'].shape, generator=gen)
+        c = dict(v=e['v'], g=e['g'], dw=dw, dv=torch.empty_like(dw), dg=torch.empty_like(e['g']))
+        bc.append(c)
+        bd.append({k: dev(t) for k, t in c.items()})
+    KM.weight_norm_bwd(bc)
+    K.weight_norm_bwd(bd)
+    for a, b in zip(bd, bc):
+        close(a['dg'], b['dg'], rtol=1e-4)
+        close(a['dv'], b['dv'], rtol=1e-4, atol=1e-6)
+
+
+def test_bce(K):
+    gen = torch.Generator().manual_seed(10)
+    x = torch.randn(64, 128, generator=gen) * 5
+    x[0, 0], x[0, 1] = 80.0, -80.0
+    n = torch.randint(1, 129, (64,), generator=gen)
+    for tgt in (0.9, 0.0, 0.5):
+        for nn_ in (n, None):
+            per_r, loss_r = torch.empty(64), torch.zeros(1)
+            KM.bce_logits_fwd(x, tgt, nn_, per_r, loss_r, 1 / 64)
+            per, loss = torch.empty(64).cuda(), torch.zeros(1).cuda()
+            K.bce_logits_fwd(dev(x), tgt, dev(nn_), per, loss, 1 / 64)
+            close(per, per_r, rtol=1e-5); close(loss, loss_r, rtol=1e-5)
+            dx_r, dx = torch.empty_like(x), torch.empty_like(x).cuda()
+            gs = torch.tensor([0.7])
+            KM.bce_logits_bwd(x, tgt, nn_, gs, 1 / 64, dx_r)
+            K.bce_logits_bwd(dev(x), tgt, dev(nn_), dev(gs), 1 / 64, dx)
+            close(dx, dx_r, rtol=1e-5, atol=1e-9)
+
+
+def test_elementwise(K):
+    gen = torch.Generator().manual_seed(11)
+    x, dy = torch.randn(100003, generator=gen), torch.randn(100003, generator=gen)
+    for act in (K.ACT_LEAKY, K.ACT_TANH, K.ACT_NONE):
+        y, yr = torch.empty_like(x).cuda(), torch.empty_like(x)
+        K.act_fwd(dev(x), y, act); KM.act_fwd(x, yr, act); close(y, yr, rtol=1e-6)
+        dx, dxr = torch.empty_like(x).cuda(), torch.empty_like(x)
+        K.act_bwd(dev(dy), y, dx, act); KM.act_bwd(dy, yr, dxr, act); close(dx, dxr, rtol=1e-5)
+    y = dev(dy.clone())
+    K.axpby(dev(x), y, 2.0, -0.5)
+    close(y, 2.0 * x - 0.5 * dy, rtol=1e-6)
+
+
+@pytest.mark.parametrize('kind', ['rmsprop', 'adam'])
+def test_fused_optimizer_vs_torch(K, kind):
+    from audiogan_amd import optim
+    gen = torch.Generator().manual_seed(12)
+    shapes = [(512, 256, 7), (4096, 1024), (4096,), (1,), (33, 5)]
+    ps_ref = [torch.nn.Parameter(torch.randn(s, generator=gen)) for s in shapes]
+    ps = [torch.nn.Parameter(p.detach().clone().cuda()) for p in ps_ref]
+    oref = (torch.optim.RMSprop(ps_ref, lr=1e-3) if kind == 'rmsprop' else torch.optim.Adam(ps_ref, lr=1e-3))
+    o = optim.make_optimizer(ps, kind, 1e-3)
+    from oracle import audiogan_oracle as O
+    for it in range(3):
+        scales = [30.0, 1e-3, 1.0, 5.0, 0.1]
+        for p, q, sc in zip(ps_ref, ps, scales):
+            g = torch.randn(p.shape, generator=gen) * sc
+            p.grad, q.grad = g.clone(), g.clone().cuda()
+        tot = O.clip_grad(ps_ref, 1.0)
+        oref.step()
+        ns = o.step(clip_norm=1.0, check=True)
+        close(ns, float(tot), rtol=1e-5)
+        for p, q in zip(ps_ref, ps):
+            close(q, p, rtol=1e-5, atol=1e-7)
+    ps[0].grad[0, 0, 0] = float('nan')
+    with pytest.raises(AssertionError):
+        o.step(clip_norm=1.0, check=True)
+
+
+def test_error_convention(K):
+    """C status codes surface as Python exceptions; nothing aborts"""
+    x = torch.zeros(2, 3, 8).cuda()
+    with pytest.raises(ValueError):
+        K.conv_engine(x, torch.zeros(K.wpa_numel(4, 3, 3)).cuda(), torch.zeros(2, 4, 9999).cuda(), 3, 1, 1, 0)
+    with pytest.raises(RuntimeError):
+        K.act_fwd(torch.zeros(4), torch.zeros(4), K.ACT_LEAKY)   # CPU tensor: no fallback
