@@ -1,0 +1,63 @@
+"""Process-per-GPU data parallelism for the G+D step: gradients of each network live in ONE
+flat fp32 buffer (parameters' ``.grad`` are views into it) and are summed across ranks with a
+single RCCL all-reduce per network per step over xGMI; the 1/world_size factor is folded into
+the fused optimiser kernel (``grad_scale``).  New in this build: the reference has no
+distributed path, only per-submodule ``NN.DataParallel``."""
+import torch
+import torch.distributed as dist
+
+
+class GradBucket(object):
+    """Owns the flat gradient buffer of one network."""
+
+    def __init__(self, params, group=None):
+        self.params = [p for p in params]
+        self.group = group
+        n = sum(p.numel() for p in self.params)
+        dev = self.params[0].device
+        self.flat = torch.zeros(n, device=dev, dtype=torch.float32)
+        o = 0
+        for p in self.params:
+            p.grad = self.flat[o:o + p.numel()].view(p.shape)
+            o += p.numel()
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self._work = None
+
+    def zero(self):
+        self.flat.zero_()
+
+    def check_views(self):
+        """autograd must have accumulated IN PLACE into the flat buffer"""
+        base = self.flat.data_ptr()
+        o = 0
+        for p in self.params:
+            if p.grad is None or p.grad.data_ptr() != base + 4 * o:
+                return False
+            o += p.numel()
+        return True
+
+    def all_reduce(self, async_op=False):
+        """sum over ranks; returns the scale the optimiser must apply (1/world)"""
+        if self.world > 1:
+            self._work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+            if not async_op:
+                self._work = None
+        return 1.0 / self.world
+
+    def wait(self):
+        if self._work is not None:
+            self._work.wait()
+            self._work = None
+
+
+def broadcast_parameters(module, src=0, group=None):
+    """make every rank start from rank ``src``'s weights (one flat broadcast)"""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return
+    ps = [p.data for p in module.parameters()]
+    flat = torch.cat([p.reshape(-1) for p in ps])
+    dist.broadcast(flat, src=src, group=group)
+    o = 0
+    for p in ps:
+        p.copy_(flat[o:o + p.numel()].view(p.shape))
+        o += p.numel()

@@ -335,3 +335,97 @@ def opt_step(params, grads, s1, s2, norms, kind, lr, clip, grad_scale, a1, b2, e
     tab = _opt_table(params, grads, s1, s2)
     check(lib.ag_opt_step(_p(tab), len(params), _p(norms), kind, lr, clip, grad_scale, a1, b2, eps,
                           step, _stream()), 'ag_opt_step')
+
+
+# ------------------------------------------------------------------------------------
+# per-kernel timing hook for bench.py's roofline figure: HIP events recorded on the launch
+# stream around the launches of ONE kernel class (or all of them in the discovery pass).
+# ------------------------------------------------------------------------------------
+class Profiler(object):
+    enabled = False
+    only = None          # kernel-class key to time, or None = every class
+    records = []         # (key, flops, bytes, ev_start, ev_stop)
+
+    @classmethod
+    def start(cls, only=None):
+        cls.enabled, cls.only, cls.records = True, only, []
+
+    @classmethod
+    def stop(cls):
+        cls.enabled = False
+        torch.cuda.synchronize()
+        out = {}
+        for key, fl, by, e0, e1 in cls.records:
+            r = out.setdefault(key, dict(n=0, ms=0.0, flops=0.0, bytes=0.0))
+            r['n'] += 1
+            r['ms'] += e0.elapsed_time(e1)
+            r['flops'] += fl
+            r['bytes'] += by
+        cls.records = []
+        return out
+
+
+def _cdiv(a, b):
+    return (a + b - 1) // b
+
+
+def _work_gemm(A, B, Cm, ta=False, tb=False, *a_, **kw):
+    M, N = Cm.shape
+    Kd = A.size(0) if ta else A.size(1)
+    big = _cdiv(M, 128) * _cdiv(N, 128)
+    tile = '2,2,2,2' if (M > 64 and N > 64 and big >= 192) else '1,1,2,2'
+    key = 'gemm_kernel<%s,%d,%d>' % (tile, int(ta), int(tb))
+    return key, 2.0 * M * N * Kd, 4.0 * (M * Kd + N * Kd + M * N)
+
+
+def _work_conv(x, wp, y, K_, stride, pad, mode, *a_, **kw):
+    B, Cc, Lin = x.shape
+    _, O, Lout = y.shape
+    rows = O if mode == 0 else O * stride
+    ncnt = Lout if mode == 0 else _cdiv(Lout, stride)
+    if rows <= 32:
+        tile = '1,2,1,4'
+    elif rows <= 64:
+        tile = '2,1,1,4'
+    elif ncnt <= 64:
+        tile = '2,1,2,2'
+    else:
+        tile = '2,2,2,2'
+    macs = B * O * Lout * Cc * K_ if mode == 0 else B * Cc * Lin * O * K_
+    return 'conv_engine_kernel<%s>' % tile, 2.0 * macs, 4.0 * (x.numel() + y.numel() + wp.numel())
+
+
+def _work_wgrad(sh, lg, dw, K_, stride, pad):
+    B, A, Lsh = sh.shape
+    Cc = lg.size(1)
+    tile = '1,1,1,4' if A <= 32 else ('1,1,2,2' if (A <= 64 or Cc * K_ <= 64) else '2,2,2,2')
+    return 'conv_wgrad_kernel<%s>' % tile, 2.0 * B * A * Lsh * Cc * K_, 4.0 * (sh.numel() + lg.numel() + dw.numel())
+
+
+def _instrument(name, work):
+    fn = globals()[name]
+
+    def wrapped(*a, **k):
+        if not Profiler.enabled:
+            return fn(*a, **k)
+        key, fl, by = work(*a, **k) if work is not None else (name, 0.0, 0.0)
+        if Profiler.only is not None and key != Profiler.only:
+            return fn(*a, **k)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = fn(*a, **k)
+        e1.record()
+        Profiler.records.append((key, fl, by, e0, e1))
+        return r
+    wrapped.__name__ = name
+    wrapped.__doc__ = fn.__doc__
+    wrapped.__module__ = __name__
+    globals()[name] = wrapped
+
+
+for _n, _w in (('gemm', _work_gemm), ('conv_engine', _work_conv), ('conv_wgrad', _work_wgrad),
+               ('channel_sum', None), ('leaky_bwd', None), ('col_sum', None), ('lstm_cell_fwd', None),
+               ('lstm_cell_bwd', None), ('weight_norm_fwd', None), ('weight_norm_bwd', None),
+               ('bce_logits_fwd', None), ('bce_logits_bwd', None), ('act_fwd', None), ('act_bwd', None),
+               ('axpby', None), ('grad_norms', None), ('opt_step', None)):
+    _instrument(_n, _w)

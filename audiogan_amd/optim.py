@@ -40,6 +40,9 @@ class _Fused(object):
 
     def zero_grad(self):
         """keeps .grad allocated (stable pointers -> cached descriptor tables)"""
+        if getattr(self, 'bucket', None) is not None:
+            self.bucket.zero()
+            return
         for p in self.params:
             if p.grad is not None:
                 p.grad.detach_()

@@ -1,0 +1,214 @@
+#!/usr/bin/env python
+"""bench.py -- audio-samples/sec per G+D train step (BASELINE.json metric) on N x MI355X.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (config.workload): BASELINE configs[1] "C2" -- the full audiogan.py Generator +
+Discriminator (default structs, audiogan.py:368,:476; embed 100, noise 100, state 1024,
+frame_size 256 -> T=32), batch 64 PER GPU, 8192-sample synthetic white-noise clips, fp32.
+One "step" = one canonical G+D step: critic iteration (G fwd, D(real),
+D(fake), BCE, backward, per-parameter clip, optimiser) + generator iteration (G fwd, D(fake),
+BCE, backward through D into G, clip, optimiser).  Inputs are resident in HBM before the
+timed region.  N > 1: pure data parallelism, one process per GPU, one RCCL all-reduce per
+network per step (weak scaling: per-GPU batch fixed).
+
+Rank 0 prints ONE JSON line (contract in the task description) with two extra objects:
+  roofline     -- the kernel class with the largest share of GPU time, timed live with HIP
+                  events on the launch stream during the timed steps
+  cpu_baseline -- the CPU oracle (oracle/audiogan_oracle.py, kind "port") running the same
+                  step on a bounded sample of the workload on this host's cores
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import warnings
+
+warnings.filterwarnings('ignore', category=FutureWarning)
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+L = 8192
+FRAME = 256
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32 matrix peak (spec)
+PEAK_HBM_GBS = 8000.0
+
+
+def build_models(A, dev, opt_kind, seed=0):
+    from audiogan_amd import optim
+    torch.manual_seed(seed)
+    g = A.Generator(frame_size=FRAME, embed_size=100, noise_size=100, state_size=1024).to(dev)
+    d = A.Discriminator(state_size=1024, embed_size=100).to(dev)
+    opt_g = optim.make_optimizer(list(g.parameters()), opt_kind, 1e-4)
+    opt_d = optim.make_optimizer(list(d.parameters()), opt_kind, 1e-4)
+    return g, d, opt_g, opt_d
+
+
+def synthetic_batch(batch, dev, seed):
+    """white-noise clips U(-1,1), peak-normalised like dataset.py:68-71; z, c, instance noise from
+    a seeded host generator"""
+    rs = np.random.RandomState(seed)
+    x = rs.uniform(-1, 1, size=(batch, L))
+    x = (x / np.abs(x).max(1, keepdims=True)).astype(np.float32)
+    gen = torch.Generator().manual_seed(seed)
+    T = L // FRAME
+    out = dict(real=torch.from_numpy(x), real_len=torch.full((batch,), L, dtype=torch.long),
+               c=torch.randn(batch, 100, generator=gen), z=torch.randn(batch, T, 100, generator=gen),
+               noise_real=torch.randn(batch, L, generator=gen) * 0.01,
+               noise_fake=torch.randn(batch, L, generator=gen) * 0.01)
+    return {k: v.to(dev) for k, v in out.items()}
+
+
+def one_step(train, g, d, opt_g, opt_d, b, hook_d=None, hook_g=None):
+    train.d_step(g, d, opt_d, b['real'], b['real_len'], b['c'], b['z'], b['noise_real'], b['noise_fake'],
+                 1.0, grad_hook=hook_d)
+    train.g_step(g, d, opt_g, b['c'], b['z'], b['noise_fake'], 0.1, grad_hook=hook_g)
+
+
+def cpu_baseline(batch, steps, opt_kind):
+    """the oracle's canonical step on `batch` clips of the same workload, all host cores"""
+    from oracle import audiogan_oracle as O
+    torch.manual_seed(0)
+    g = O.Generator(frame_size=FRAME, embed_size=100, noise_size=100, state_size=1024)
+    d = O.Discriminator(state_size=1024, embed_size=100)
+    og, od = O.make_optimizer(list(g.parameters()), opt_kind, 1e-4), O.make_optimizer(list(d.parameters()), opt_kind, 1e-4)
+    b = synthetic_batch(batch, torch.device('cpu'), 0)
+    stop = torch.zeros(batch, L // FRAME, dtype=torch.long)
+    cores = torch.get_num_threads()
+    times = []
+    for i in range(steps + 1):
+        t0 = time.perf_counter()
+        O.d_step(g, d, od, b['real'], b['real_len'], b['c'], b['z'], b['noise_real'], b['noise_fake'], 1.0, stop=stop)
+        O.g_step(g, d, og, b['c'], b['z'], b['noise_fake'], 0.1, stop=stop)
+        if i > 0:
+            times.append(time.perf_counter() - t0)
+    t = float(np.median(times))
+    return dict(value=batch * L / t, unit='audio-samples/sec', cores=cores, kind='port',
+                sample='%d of the 64 clips per step, %d timed steps after 1 warm-up (median %.2f s/step), '
+                       'torch %s CPU, %s' % (batch, steps, t, torch.__version__, opt_kind))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=64, help='clips per GPU')
+    ap.add_argument('--opt', default='adam', choices=['adam', 'rmsprop'],
+                    help='adam = north_star; rmsprop = audiogan.py:693-694')
+    ap.add_argument('--cpu-batch', type=int, default=16)
+    ap.add_argument('--cpu-steps', type=int, default=2)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d '
+                             '--master-addr 127.0.0.1 --master-port 29500 bench.py --gpus %d ...'
+                             % (args.gpus, args.gpus))
+    assert torch.cuda.is_available(), 'bench.py needs a GPU (no CPU fallback)'
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=dev)
+
+    import audiogan_amd as A
+    from audiogan_amd import train, ddp, kernels as K
+
+    g, d, opt_g, opt_d = build_models(A, dev, args.opt)
+    hook_d = hook_g = None
+    if world > 1:
+        ddp.broadcast_parameters(g)
+        ddp.broadcast_parameters(d)
+        bd, bg = ddp.GradBucket(list(d.parameters())), ddp.GradBucket(list(g.parameters()))
+        opt_d.bucket, opt_g.bucket = bd, bg
+        hook_d, hook_g = bd.all_reduce, bg.all_reduce
+    batch = synthetic_batch(args.batch, dev, seed=1000 + rank)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    # ---- warm-up; the first warm-up step doubles as the discovery pass for the roofline kernel
+    dominant, disc = None, None
+    for i in range(max(args.warmup, 1)):
+        prof = (i == max(args.warmup, 1) - 1) and not args.no_roofline
+        if prof:
+            torch.cuda.synchronize()
+            K.Profiler.start(only=None)
+        one_step(train, g, d, opt_g, opt_d, batch, hook_d, hook_g)
+        if prof:
+            disc = K.Profiler.stop()
+            dominant = max(disc.items(), key=lambda kv: kv[1]['ms'])[0]
+    # ---- timed region: exactly K steps between barrier+synchronize on both sides
+    if dominant is not None:
+        K.Profiler.start(only=dominant)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step(train, g, d, opt_g, opt_d, batch, hook_d, hook_g)
+    sync()
+    dt = time.perf_counter() - t0
+    rec = K.Profiler.stop() if dominant is not None else {}
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        value = world * args.batch * L / (dt / args.steps)
+        out = {
+            'metric': 'audio-samples/sec per G+D train step (8 kHz, 8192-sample clips)',
+            'value': value, 'unit': 'audio-samples/sec', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': ms, 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'C2: full audiogan.py Conv1d/LSTM G + D, batch %d per GPU, 8192-sample '
+                                   'white-noise clips, frame_size 256 (T=32), canonical G+D step, %s, '
+                                   'per-parameter clip d=1 g=0.1' % (args.batch, args.opt),
+                       'global_batch': world * args.batch, 'clip_len': L,
+                       'parallelism': 'dp%d' % world},
+        }
+        if dominant is not None and dominant in rec:
+            r = rec[dominant]
+            avg_ms = r['ms'] / r['n']
+            tf = r['flops'] / r['n'] / (avg_ms * 1e-3) / 1e12
+            gbs = r['bytes'] / r['n'] / (avg_ms * 1e-3) / 1e9
+            share = disc[dominant]['ms'] / sum(v['ms'] for v in disc.values())
+            mfma_bound = tf / PEAK_F32_MFMA_TFLOPS >= gbs / PEAK_HBM_GBS
+            out['roofline'] = {
+                'kernel': dominant, 'bound': 'mfma' if mfma_bound else 'hbm',
+                'achieved': tf if mfma_bound else gbs,
+                'peak': PEAK_F32_MFMA_TFLOPS if mfma_bound else PEAK_HBM_GBS,
+                'unit': 'TFLOP/s' if mfma_bound else 'GB/s',
+                'frac': (tf / PEAK_F32_MFMA_TFLOPS) if mfma_bound else (gbs / PEAK_HBM_GBS),
+                'traffic': None, 'launches_per_step': r['n'] / args.steps, 'avg_launch_us': avg_ms * 1e3,
+                'share_of_gpu_time': share,
+                'algorithmic_per_launch': {'flops': r['flops'] / r['n'], 'bytes': r['bytes'] / r['n']},
+            }
+            out['kernel_time_shares'] = {k: round(v['ms'] / sum(x['ms'] for x in disc.values()), 4)
+                                         for k, v in sorted(disc.items(), key=lambda kv: -kv[1]['ms'])[:8]}
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(args.cpu_batch, args.cpu_steps, args.opt)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
