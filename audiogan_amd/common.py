@@ -1,0 +1,90 @@
+"""Pieces shared by the autograd blocks: the weight-norm group and scratch helpers."""
+import torch
+
+from . import kernels as K
+
+# bumped whenever parameters are rewritten through raw pointers (fused optimiser)
+PARAM_EPOCH = [0]
+
+
+class Prepared(object):
+    __slots__ = ('w', 'wpa', 'wpb')
+
+    def __init__(self, w=None, wpa=None, wpb=None):
+        self.w, self.wpa, self.wpb = w, wpa, wpb
+
+
+class WNGroup(object):
+    """All weight-normed tensors of one block.  ``prepare`` materialises w = g*v/||v|| for
+    every tensor (and the conv-engine layouts of 3-D weights) with ONE launch into
+    persistent buffers; ``backward`` turns dW into (dv, dg) with one launch."""
+
+    def __init__(self):
+        self.items = []   # dict(v=Parameter, g=Parameter, stride=int, engine=bool)
+        self._bufs = None
+        self._key = None
+
+    def add(self, v, g, stride=1, engine=False):
+        self.items.append(dict(v=v, g=g, stride=stride, engine=engine))
+        return len(self.items) - 1
+
+    def params(self):
+        out = []
+        for it in self.items:
+            out += [it['v'], it['g']]
+        return out
+
+    def _alloc(self, dev):
+        bufs = []
+        for it in self.items:
+            v = it['v']
+            p = Prepared(w=torch.empty_like(v.data))
+            if it['engine']:
+                d0, d1, kk = v.shape
+                p.wpa = torch.zeros(K.wpa_numel(d0, d1, kk), device=dev)
+                p.wpb = torch.zeros(K.wpb_numel(d0, d1, kk, it['stride']), device=dev)
+            bufs.append(p)
+        self._bufs = bufs
+        self._key = None
+
+    def prepare(self):
+        dev = self.items[0]['v'].device
+        if self._bufs is None or self._bufs[0].w.device != dev:
+            self._alloc(dev)
+        key = (PARAM_EPOCH[0],) + tuple((it['v'].data_ptr(), it['v']._version, it['g'].data_ptr(),
+                                         it['g']._version) for it in self.items)
+        if key != self._key:
+            ents = []
+            for it, p in zip(self.items, self._bufs):
+                ents.append(dict(v=it['v'].data, g=it['g'].data.view(-1), w=p.w, wpa=p.wpa, wpb=p.wpb,
+                                 stride=it['stride']))
+            K.weight_norm_fwd(ents)
+            self._key = key
+        return self._bufs
+
+    def backward(self, dws):
+        """dws[i]: gradient wrt the materialised w of item i (same shape as v), or None.
+        Returns the flat list [dv0, dg0, dv1, dg1, ...]."""
+        ents, outs = [], []
+        for it, dw in zip(self.items, dws):
+            if dw is None:
+                outs += [None, None]
+                continue
+            dv = torch.empty_like(it['v'].data)
+            dg = torch.empty_like(it['g'].data)
+            ents.append(dict(v=it['v'].data, g=it['g'].data.view(-1), dw=dw, dv=dv, dg=dg.view(-1)))
+            outs += [dv, dg]
+        if ents:
+            K.weight_norm_bwd(ents)
+        return outs
+
+
+def _zeros_like_list(tensors):
+    """one flat zero buffer, viewed as the given shapes (one memset instead of many)"""
+    n = sum(t.numel() for t in tensors)
+    flat = torch.zeros(n, device=tensors[0].device, dtype=torch.float32)
+    out, o = [], 0
+    for t in tensors:
+        out.append(flat[o:o + t.numel()].view(t.shape))
+        o += t.numel()
+    return out

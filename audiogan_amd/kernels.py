@@ -429,3 +429,117 @@ for _n, _w in (('gemm', _work_gemm), ('conv_engine', _work_conv), ('conv_wgrad',
                ('bce_logits_fwd', None), ('bce_logits_bwd', None), ('act_fwd', None), ('act_bwd', None),
                ('axpby', None), ('grad_norms', None), ('opt_step', None)):
     _instrument(_n, _w)
+
+
+# ------------------------------------------------------------------------------------
+# skinny products / fused recurrent steps (lstm_step.hip)
+# ------------------------------------------------------------------------------------
+def _al16(t):
+    return t.data_ptr() % 16 == 0
+
+
+def skinny_ok(A, B, tb):
+    """can ag_skinny_gemm take this product? (M <= 64, K % 8 == 0, 16-byte aligned rows)"""
+    M, Kd = A.shape
+    ok = M <= 64 and Kd % 8 == 0 and A.stride(1) == 1 and A.stride(0) % 4 == 0 and _al16(A)
+    if tb:
+        ok = ok and B.stride(1) == 1 and B.stride(0) % 4 == 0 and _al16(B)
+    return ok
+
+
+def skinny_gemm(A, B, Cm, tb=False, beta=0.0, bias=None, act=ACT_NONE, slope=LEAKY_SLOPE, atomic=False):
+    """Cm[M<=64,N] = act(A @ op(B) + beta*Cm + bias), or with atomic=True: Cm += A @ op(B) (+bias)"""
+    lda, ldb, ldc = _mat(A, 'A'), _mat(B, 'B'), _mat(Cm, 'C')
+    M, N = Cm.shape
+    Kd = A.size(1)
+    assert A.size(0) == M and (B.size(1) if tb else B.size(0)) == Kd and (B.size(0) if tb else B.size(1)) == N
+    if bias is not None:
+        _chk(bias, 'bias')
+        assert bias.numel() == N and bias.is_contiguous()
+    check(lib.ag_skinny_gemm(_p(A), lda, _p(B), ldb, int(tb), _p(Cm), ldc, M, N, Kd, beta, _p(bias), act,
+                             slope, int(atomic), _stream()), 'ag_skinny_gemm')
+
+
+def lstm_step_ok(B, H, x=None, wx=None):
+    ok = B <= 64 and H % 8 == 0
+    if x is not None:
+        ok = ok and x.size(1) % 8 == 0 and x.stride(1) == 1 and x.stride(0) % 4 == 0 and _al16(x) \
+            and wx.stride(1) == 1 and wx.stride(0) % 4 == 0 and _al16(wx)
+    return ok
+
+
+def lstm_step_fwd(gates_pre, x, wx, h_prev, whh, c_prev, c_out, h_out, first_step):
+    """fused LSTMCell step; gates_pre [B,4H] contiguous is overwritten with the activated gates"""
+    for t_, n in ((gates_pre, 'gates_pre'), (h_prev, 'h_prev'), (whh, 'whh'), (c_prev, 'c_prev'),
+                  (c_out, 'c_out'), (h_out, 'h_out')):
+        _chk(t_, n)
+        assert t_.is_contiguous()
+    B, H4 = gates_pre.shape
+    H = H4 // 4
+    ldx = ldwx = Kx = 0
+    if x is not None:
+        ldx, ldwx, Kx = _mat(x, 'x'), _mat(wx, 'wx'), x.size(1)
+        assert wx.size(0) == 4 * H and wx.size(1) == Kx
+    check(lib.ag_lstm_step_fwd(_p(gates_pre), _p(x), ldx, _p(wx), ldwx, Kx, _p(h_prev), _p(whh), _p(c_prev),
+                               _p(c_out), _p(h_out), B, H, int(first_step), _stream()), 'ag_lstm_step_fwd')
+
+
+def _ptr_table(tensors):
+    arr = (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+    return arr
+
+
+def lstm_seq_fwd(pre, whh, c_all, hbuf, y, valid):
+    """pre/whh/c_all/hbuf: lists (one per direction) of contiguous tensors; see ag_lstm_seq_fwd"""
+    ndir = len(pre)
+    T, B, H4 = pre[0].shape
+    H = H4 // 4
+    for d in range(ndir):
+        for t_, shp in ((pre[d], (T, B, 4 * H)), (whh[d], (4 * H, H)), (c_all[d], (T + 1, B, H)),
+                        (hbuf[d], (2, B, H))):
+            _chk(t_, 'lstm_seq tensor')
+            assert t_.is_contiguous() and tuple(t_.shape) == shp, (tuple(t_.shape), shp)
+    _chk(y, 'y'); _chk(valid, 'valid', torch.int64)
+    assert y.is_contiguous() and tuple(y.shape) == (T, B, ndir * H)
+    check(lib.ag_lstm_seq_fwd(_ptr_table(pre), _ptr_table(whh), _ptr_table(c_all), _ptr_table(hbuf), _p(y),
+                              _p(valid), T, B, H, ndir, _stream()), 'ag_lstm_seq_fwd')
+
+
+def lstm_seq_bwd(gates, whh, c_all, dy, dgates, dhbuf, dcbuf, valid):
+    ndir = len(gates)
+    T, B, H4 = gates[0].shape
+    H = H4 // 4
+    for d in range(ndir):
+        for t_, shp in ((gates[d], (T, B, 4 * H)), (whh[d], (4 * H, H)), (c_all[d], (T + 1, B, H)),
+                        (dgates[d], (T, B, 4 * H)), (dhbuf[d], (2, B, H)), (dcbuf[d], (2, B, H))):
+            _chk(t_, 'lstm_seq tensor')
+            assert t_.is_contiguous() and tuple(t_.shape) == shp, (tuple(t_.shape), shp)
+    _chk(dy, 'dy'); _chk(valid, 'valid', torch.int64)
+    assert dy.is_contiguous() and tuple(dy.shape) == (T, B, ndir * H)
+    check(lib.ag_lstm_seq_bwd(_ptr_table(gates), _ptr_table(whh), _ptr_table(c_all), _p(dy),
+                              _ptr_table(dgates), _ptr_table(dhbuf), _ptr_table(dcbuf), _p(valid), T, B, H,
+                              ndir, _stream()), 'ag_lstm_seq_bwd')
+
+
+def _work_skinny(A, B, Cm, tb=False, *a_, **kw):
+    M, N = Cm.shape
+    return 'skinny_gemm_kernel<%d>' % (2 if M > 32 else 1), 2.0 * M * N * A.size(1), \
+        4.0 * (A.numel() + N * A.size(1) + M * N)
+
+
+def _work_step(gates_pre, x, wx, h_prev, whh, *a_, **kw):
+    B, H4 = gates_pre.shape
+    Kd = H4 // 4 + (x.size(1) if x is not None else 0)
+    return 'lstm_step_fwd_kernel<%d>' % (2 if B > 32 else 1), 2.0 * B * H4 * Kd, 4.0 * (H4 * Kd + 3 * B * H4)
+
+
+def _work_seq(pre, whh, *a_, **kw):
+    T, B, H4 = pre[0].shape
+    nd = len(pre)
+    return 'lstm_seq(%d dir x %d steps)' % (nd, T), 2.0 * nd * T * B * H4 * (H4 // 4), \
+        4.0 * nd * T * (H4 * (H4 // 4) + 3 * B * H4)
+
+
+for _n, _w in (('skinny_gemm', _work_skinny), ('lstm_step_fwd', _work_step), ('lstm_seq_fwd', _work_seq),
+               ('lstm_seq_bwd', _work_seq)):
+    _instrument(_n, _w)

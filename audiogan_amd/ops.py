@@ -15,8 +15,7 @@ import torch
 from . import kernels as K
 from .kernels import ACT_NONE, ACT_LEAKY, ACT_TANH
 
-# bumped whenever parameters are rewritten through raw pointers (fused optimiser)
-PARAM_EPOCH = [0]
+from .common import PARAM_EPOCH, Prepared, WNGroup, _zeros_like_list  # noqa: F401
 
 
 class ConvSpec(object):
@@ -30,78 +29,6 @@ class ConvSpec(object):
         if self.kind == 'conv':
             return (lin + 2 * self.pad - self.K) // self.stride + 1
         return (lin - 1) * self.stride - 2 * self.pad + self.K
-
-
-class Prepared(object):
-    __slots__ = ('w', 'wpa', 'wpb')
-
-    def __init__(self, w=None, wpa=None, wpb=None):
-        self.w, self.wpa, self.wpb = w, wpa, wpb
-
-
-class WNGroup(object):
-    """All weight-normed tensors of one block.  ``prepare`` materialises w = g*v/||v|| for
-    every tensor (and the conv-engine layouts of 3-D weights) with ONE launch into
-    persistent buffers; ``backward`` turns dW into (dv, dg) with one launch."""
-
-    def __init__(self):
-        self.items = []   # dict(v=Parameter, g=Parameter, stride=int, engine=bool)
-        self._bufs = None
-        self._key = None
-
-    def add(self, v, g, stride=1, engine=False):
-        self.items.append(dict(v=v, g=g, stride=stride, engine=engine))
-        return len(self.items) - 1
-
-    def params(self):
-        out = []
-        for it in self.items:
-            out += [it['v'], it['g']]
-        return out
-
-    def _alloc(self, dev):
-        bufs = []
-        for it in self.items:
-            v = it['v']
-            p = Prepared(w=torch.empty_like(v.data))
-            if it['engine']:
-                d0, d1, kk = v.shape
-                p.wpa = torch.zeros(K.wpa_numel(d0, d1, kk), device=dev)
-                p.wpb = torch.zeros(K.wpb_numel(d0, d1, kk, it['stride']), device=dev)
-            bufs.append(p)
-        self._bufs = bufs
-        self._key = None
-
-    def prepare(self):
-        dev = self.items[0]['v'].device
-        if self._bufs is None or self._bufs[0].w.device != dev:
-            self._alloc(dev)
-        key = (PARAM_EPOCH[0],) + tuple((it['v'].data_ptr(), it['v']._version, it['g'].data_ptr(),
-                                         it['g']._version) for it in self.items)
-        if key != self._key:
-            ents = []
-            for it, p in zip(self.items, self._bufs):
-                ents.append(dict(v=it['v'].data, g=it['g'].data.view(-1), w=p.w, wpa=p.wpa, wpb=p.wpb,
-                                 stride=it['stride']))
-            K.weight_norm_fwd(ents)
-            self._key = key
-        return self._bufs
-
-    def backward(self, dws):
-        """dws[i]: gradient wrt the materialised w of item i (same shape as v), or None.
-        Returns the flat list [dv0, dg0, dv1, dg1, ...]."""
-        ents, outs = [], []
-        for it, dw in zip(self.items, dws):
-            if dw is None:
-                outs += [None, None]
-                continue
-            dv = torch.empty_like(it['v'].data)
-            dg = torch.empty_like(it['g'].data)
-            ents.append(dict(v=it['v'].data, g=it['g'].data.view(-1), dw=dw, dv=dv, dg=dg.view(-1)))
-            outs += [dv, dg]
-        if ents:
-            K.weight_norm_bwd(ents)
-        return outs
 
 
 # --------------------------------------------------------------------------------------
@@ -129,17 +56,6 @@ def conv_wgrad(spec, x, dy, dw, db):
         K.conv_wgrad(x, dy, dw, spec.K, spec.stride, spec.pad)
     if db is not None:
         K.channel_sum(dy, db)
-
-
-def _zeros_like_list(tensors):
-    """one flat zero buffer, viewed as the given shapes (one memset instead of many)"""
-    n = sum(t.numel() for t in tensors)
-    flat = torch.zeros(n, device=tensors[0].device, dtype=torch.float32)
-    out, o = [], 0
-    for t in tensors:
-        out.append(flat[o:o + t.numel()].view(t.shape))
-        o += t.numel()
-    return out
 
 
 # --------------------------------------------------------------------------------------
@@ -280,99 +196,6 @@ class DConvStackFn(torch.autograd.Function):
 
 
 # --------------------------------------------------------------------------------------
-# LSTM layer over a padded sequence (uni- or bidirectional), NN.LSTM parameter layout
-# --------------------------------------------------------------------------------------
-class LSTMSeqFn(torch.autograd.Function):
-    """x: [T,B,F] contiguous; lengths: int64 [B] on device or None; weights per direction:
-    (w_ih [4H,F], w_hh [4H,H], b_ih [4H], b_hh [4H]).  Returns y [T,B,D*H] with zeros at
-    padded steps (pad_packed_sequence semantics, audiogan.py:214-229)."""
-
-    @staticmethod
-    def forward(ctx, x, lengths, ndir, *w):
-        T, B, F = x.shape
-        H = w[1].size(1)
-        dev = x.device
-        x2 = x.contiguous().view(T * B, F)
-        y = torch.empty(T, B, ndir * H, device=dev)
-        gates_all, c_all = [], []
-        for d in range(ndir):
-            w_ih, w_hh, b_ih, b_hh = w[4 * d:4 * d + 4]
-            bsum = b_ih.data + b_hh.data
-            g = torch.empty(T, B, 4 * H, device=dev)
-            K.gemm(x2, w_ih.data, g.view(T * B, 4 * H), tb=True, bias=bsum)
-            c = torch.empty(T + 1, B, H, device=dev)   # c[k+1] = cell after the k-th processed step
-            c[0].zero_()
-            h0 = torch.zeros(B, H, device=dev)
-            hstate = [h0, torch.empty(B, H, device=dev)]
-            order = range(T) if d == 0 else range(T - 1, -1, -1)
-            for k, t in enumerate(order):
-                hp, hn = hstate[k & 1], hstate[(k + 1) & 1]
-                if k > 0:
-                    K.gemm(hp, w_hh.data, g[t], tb=True, beta=1.0)
-                K.lstm_cell_fwd(g[t], c[k], c[k + 1], h_out=hn, y_out=y[t, :, d * H:(d + 1) * H],
-                                h_prev=hp, valid=lengths, t=t)
-            gates_all.append(g)
-            c_all.append(c)
-        ctx.ndir, ctx.has_len = ndir, lengths is not None
-        ctx.save_for_backward(x2, y, lengths if lengths is not None else x2.new_empty(0),
-                              *(gates_all + c_all + [t_.data for t_ in w]))
-        ctx.shape = (T, B, F, H)
-        return y
-
-    @staticmethod
-    def backward(ctx, dy):
-        T, B, F, H = ctx.shape
-        ndir = ctx.ndir
-        sv = ctx.saved_tensors
-        x2, y = sv[0], sv[1]
-        lengths = sv[2] if ctx.has_len else None
-        gates_all, c_all, w = sv[3:3 + ndir], sv[3 + ndir:3 + 2 * ndir], sv[3 + 2 * ndir:]
-        dev = x2.device
-        dy = dy.contiguous()
-        dx2 = torch.empty(T * B, F, device=dev)
-        outs = []
-        for d in range(ndir):
-            w_ih, w_hh = w[4 * d], w[4 * d + 1]
-            g, c = gates_all[d], c_all[d]
-            dg = torch.empty(T, B, 4 * H, device=dev)
-            dh = [torch.empty(B, H, device=dev), torch.empty(B, H, device=dev)]
-            dc = [torch.zeros(B, H, device=dev), torch.empty(B, H, device=dev)]
-            order = list(range(T)) if d == 0 else list(range(T - 1, -1, -1))
-            for k in reversed(range(T)):
-                t = order[k]
-                dyt = dy[t, :, d * H:(d + 1) * H]
-                cur, nxt = dh[k & 1], dh[(k + 1) & 1]
-                if k == T - 1:
-                    dh_in = None
-                else:
-                    # cur holds dh_pass written by step k+1; add that step's recurrent term
-                    K.gemm(dg[order[k + 1]], w_hh, cur, beta=1.0)
-                    dh_in = cur
-                K.lstm_cell_bwd(g[t], c[k], c[k + 1], dh_in, dyt,
-                                dc[(k + 1) & 1] if k < T - 1 else None, dg[t], dc[k & 1],
-                                dh_pass=nxt, valid=lengths, t=t)
-                # step k-1 reads its future term from dh[(k-1)&1] == nxt
-            dg2 = dg.view(T * B, 4 * H)
-            dw_ih = torch.empty_like(w_ih)
-            K.gemm(dg2, x2, dw_ih, ta=True)
-            # h_{prev}(step k) is the output of step k-1 in processing order (zero at padded steps)
-            dw_hh = torch.zeros_like(w_hh)
-            if T > 1:
-                if d == 0:
-                    K.gemm(dg[1:].view((T - 1) * B, 4 * H), y[:-1].view((T - 1) * B, ndir * H)[:, :H],
-                           dw_hh, ta=True)
-                else:
-                    K.gemm(dg[:-1].view((T - 1) * B, 4 * H),
-                           y[1:].view((T - 1) * B, ndir * H)[:, H:2 * H], dw_hh, ta=True)
-            db = torch.zeros(4 * H, device=dev)
-            K.col_sum(dg2, db)
-            K.gemm(dg2, w_ih, dx2, beta=0.0 if d == 0 else 1.0)
-            outs += [dw_ih, dw_hh, db, db.clone()]
-        dx = dx2.view(T, B, F) if ctx.needs_input_grad[0] else None
-        return (dx, None, None) + tuple(outs)
-
-
-# --------------------------------------------------------------------------------------
 # Discriminator heads: Residual x n  ->  Linear -> LeakyReLU -> Linear
 # --------------------------------------------------------------------------------------
 class DHead(object):
@@ -440,142 +263,7 @@ class DHeadFn(torch.autograd.Function):
         return (da if ctx.needs_input_grad[0] else None, None) + tuple(grads)
 
 
-# --------------------------------------------------------------------------------------
-# Generator recurrent front: T x [LSTMCell stack -> tanh(proj) fed back, stopper logit]
-# --------------------------------------------------------------------------------------
-class GFront(object):
-    """WN items: per layer [w_ih, w_hh, b_ih, b_hh] * num_layers, then [proj.w, proj.b, stop.w, stop.b]"""
-
-    def __init__(self, frame_size, num_layers, state_size):
-        self.fs, self.nl, self.ss = frame_size, num_layers, state_size
-        self.group = WNGroup()
-
-
-class GFrontFn(torch.autograd.Function):
-    """zc: [T,B,noise+embed] contiguous.  Returns x [B,T*fs], s [B,T].  Frame t's LSTM input is
-    [x_{t-1}, zc_t] (audiogan.py:439); the zc part of every frame's gate product is done in one
-    GEMM up front, only the fed-back x_{t-1} and h products stay in the sequential loop."""
-
-    @staticmethod
-    def forward(ctx, zc, front, *params):
-        T, B, Fz = zc.shape
-        fs, nl, S = front.fs, front.nl, front.ss
-        dev = zc.device
-        ctx.set_materialize_grads(False)
-        prep = front.group.prepare()
-        lw = [[p.w for p in prep[4 * l:4 * l + 4]] for l in range(nl)]
-        pw, pb, sw, sb = [p.w for p in prep[4 * nl:4 * nl + 4]]
-        x = torch.empty(B, T * fs, device=dev)
-        gates = [torch.empty(T, B, 4 * S, device=dev) for _ in range(nl)]
-        hs = [torch.empty(T, B, S, device=dev) for _ in range(nl)]
-        cs = [torch.empty(T + 1, B, S, device=dev) for _ in range(nl)]
-        for l in range(nl):
-            cs[l][0].zero_()
-        bsum = [lw[l][2] + lw[l][3] for l in range(nl)]
-        w_ih0 = lw[0][0]
-        # all frames at once: zc_t @ W_ih[:, fs:]^T + b_ih + b_hh
-        K.gemm(zc.contiguous().view(T * B, Fz), w_ih0[:, fs:], gates[0].view(T * B, 4 * S), tb=True,
-               bias=bsum[0])
-        for t in range(T):
-            if t > 0:
-                K.gemm(x[:, (t - 1) * fs:t * fs], w_ih0[:, :fs], gates[0][t], tb=True, beta=1.0)
-                K.gemm(hs[0][t - 1], lw[0][1], gates[0][t], tb=True, beta=1.0)
-            K.lstm_cell_fwd(gates[0][t], cs[0][t], cs[0][t + 1], h_out=hs[0][t])
-            for l in range(1, nl):
-                K.gemm(hs[l - 1][t], lw[l][0], gates[l][t], tb=True, bias=bsum[l])
-                if t > 0:
-                    K.gemm(hs[l][t - 1], lw[l][1], gates[l][t], tb=True, beta=1.0)
-                K.lstm_cell_fwd(gates[l][t], cs[l][t], cs[l][t + 1], h_out=hs[l][t])
-            K.gemm(hs[-1][t], pw, x[:, t * fs:(t + 1) * fs], tb=True, bias=pb, act=ACT_TANH)
-        s = torch.empty(T * B, 1, device=dev)
-        K.gemm(hs[-1].view(T * B, S), sw, s, tb=True, bias=sb)
-        ctx.front, ctx.key = front, front.group._key
-        ctx.dims = (T, B, Fz)
-        ctx.save_for_backward(zc, x, *(gates + hs + cs))
-        return x, s.view(T, B).t()
-
-    @staticmethod
-    def backward(ctx, dx, ds):
-        front = ctx.front
-        fs, nl, S = front.fs, front.nl, front.ss
-        T, B, Fz = ctx.dims
-        prep = front.group.prepare()
-        assert front.group._key == ctx.key, 'parameters changed between forward and backward'
-        sv = ctx.saved_tensors
-        zc, x = sv[0], sv[1]
-        gates, hs, cs = sv[2:2 + nl], sv[2 + nl:2 + 2 * nl], sv[2 + 2 * nl:2 + 3 * nl]
-        dev = zc.device
-        lw = [[p.w for p in prep[4 * l:4 * l + 4]] for l in range(nl)]
-        pw, sw = prep[4 * nl].w, prep[4 * nl + 2].w
-        dws = _zeros_like_list([it['v'] for it in front.group.items])
-        dx = dx.contiguous() if dx is not None else torch.zeros(B, T * fs, device=dev)
-        # stopper: s[t,b] = h_last[t,b] . sw + sb
-        dh_stop = None
-        if ds is not None:
-            ds_tb = ds.t().contiguous().view(T * B, 1)
-            K.gemm(ds_tb, hs[-1].view(T * B, S), dws[4 * nl + 2], ta=True)
-            K.col_sum(ds_tb, dws[4 * nl + 3])
-            dh_stop = torch.empty(T, B, S, device=dev)
-            K.gemm(ds_tb, sw, dh_stop.view(T * B, S))
-        dgs = [torch.empty(T, B, 4 * S, device=dev) for _ in range(nl)]
-        dxt = torch.empty(T, B, fs, device=dev)      # d(pre-tanh) of the projection, per frame
-        dh_rec = [torch.zeros(B, S, device=dev) for _ in range(nl)]   # dL/dh_l[t] from frame t+1
-        dcs = [[torch.zeros(B, S, device=dev), torch.empty(B, S, device=dev)] for _ in range(nl)]
-        dxfeed = torch.empty(B, fs, device=dev)      # dL/dx_t through the feedback into frame t+1
-        dh_cur = torch.empty(B, S, device=dev)
-        for t in reversed(range(T)):
-            # x_t = tanh(proj(h_last[t])) receives dx (output) + feedback from frame t+1
-            xt = x[:, t * fs:(t + 1) * fs]
-            gx = dxt[t]
-            gx.copy_(dx[:, t * fs:(t + 1) * fs])
-            if t < T - 1:
-                K.axpby(dxfeed, gx, 1.0, 1.0)
-            xt_c = xt.contiguous()
-            K.act_bwd(gx, xt_c, gx, ACT_TANH)
-            # dh_last = gx @ pw + recurrent + stopper
-            K.gemm(gx, pw, dh_cur, res=dh_rec[-1])
-            if dh_stop is not None:
-                K.axpby(dh_stop[t], dh_cur, 1.0, 1.0)
-            dh_l = dh_cur
-            for l in reversed(range(nl)):
-                k2 = t & 1
-                K.lstm_cell_bwd(gates[l][t], cs[l][t], cs[l][t + 1], dh_l, None,
-                                dcs[l][(t + 1) & 1] if t < T - 1 else None, dgs[l][t], dcs[l][k2])
-                if t > 0:
-                    K.gemm(dgs[l][t], lw[l][1], dh_rec[l])          # into h_l[t-1]
-                if l > 0:
-                    # input of layer l at frame t is h_{l-1}[t]
-                    dh_l = torch.empty(B, S, device=dev)
-                    K.gemm(dgs[l][t], lw[l][0], dh_l, res=dh_rec[l - 1])
-                elif t > 0:
-                    K.gemm(dgs[0][t], lw[0][0][:, :fs], dxfeed)     # into x_{t-1}
-        # parameter gradients, one GEMM per tensor over all frames
-        dxt2 = dxt.view(T * B, fs)
-        K.gemm(dxt2, hs[-1].view(T * B, S), dws[4 * nl], ta=True)
-        K.col_sum(dxt2, dws[4 * nl + 1])
-        for l in range(nl):
-            dg2 = dgs[l].view(T * B, 4 * S)
-            dwih = dws[4 * l]
-            if l == 0:
-                K.gemm(dg2, zc.contiguous().view(T * B, Fz), dwih[:, fs:], ta=True)
-                if T > 1:
-                    # x_{t-1} for frames 1..T-1: gather the [B, (T-1)*fs] prefix as rows (t,b)
-                    xprev = x.view(B, T, fs)[:, :T - 1].transpose(0, 1).contiguous().view((T - 1) * B, fs)
-                    K.gemm(dgs[0][1:].view((T - 1) * B, 4 * S), xprev, dwih[:, :fs], ta=True)
-            else:
-                K.gemm(dg2, hs[l - 1].view(T * B, S), dwih, ta=True)
-            if T > 1:
-                K.gemm(dgs[l][1:].view((T - 1) * B, 4 * S), hs[l][:T - 1].view((T - 1) * B, S),
-                       dws[4 * l + 1], ta=True)
-            K.col_sum(dg2, dws[4 * l + 2])
-            dws[4 * l + 3].copy_(dws[4 * l + 2])
-        dzc = None
-        if ctx.needs_input_grad[0]:
-            dzc = torch.empty(T * B, Fz, device=dev)
-            K.gemm(dgs[0].view(T * B, 4 * S), lw[0][0][:, fs:], dzc)
-            dzc = dzc.view(T, B, Fz)
-        grads = front.group.backward(dws)
-        return (dzc, None) + tuple(grads)
+from .recurrent import LSTMSeqFn, GFront, GFrontFn  # noqa: E402,F401
 
 
 # --------------------------------------------------------------------------------------

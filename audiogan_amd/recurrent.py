@@ -1,0 +1,267 @@
+"""Recurrent blocks of the hot path.
+
+  LSTMSeqFn  NN.LSTM layer over a padded batch      audiogan.py:498-503, :543, :214-229, :315
+  GFrontFn   LSTMCell stack + tanh(proj) feedback   audiogan.py:377-386, :409-410, :428-460
+
+The per-time-step work is a product with only B (clips per GPU) rows.  When shapes allow
+(B <= 64, sizes multiples of 8, 16-byte aligned rows -- true for every BASELINE config) the
+steps run on the fused / skinny kernels of lstm_step.hip, a whole NN.LSTM layer being enqueued
+by ONE C call; other shapes take the generic GEMM + pointwise path.  Everything that does not
+depend on the recurrence (input projections, weight gradients, stopper head) is batched over
+all time steps into a few large GEMMs.
+"""
+import torch
+
+from . import kernels as K
+from .kernels import ACT_NONE, ACT_TANH
+from .common import WNGroup, _zeros_like_list
+
+
+def _small(A, B, Cm, tb=False, beta=0.0, bias=None, act=ACT_NONE, res=None):
+    """Cm = act(A @ op(B) + beta*Cm + bias + res) for a product with few rows"""
+    if res is None and K.skinny_ok(A, B, tb):
+        K.skinny_gemm(A, B, Cm, tb=tb, beta=beta, bias=bias, act=act)
+    else:
+        K.gemm(A, B, Cm, tb=tb, beta=beta, bias=bias, res=res, act=act)
+
+
+def _small_acc(A, B, Cm, tb=False):
+    """Cm += A @ op(B)"""
+    if K.skinny_ok(A, B, tb):
+        K.skinny_gemm(A, B, Cm, tb=tb, atomic=True)
+    else:
+        K.gemm(A, B, Cm, tb=tb, beta=1.0)
+
+
+# --------------------------------------------------------------------------------------
+# LSTM layer over a padded sequence (uni- or bidirectional), NN.LSTM parameter layout
+# --------------------------------------------------------------------------------------
+class LSTMSeqFn(torch.autograd.Function):
+    """x: [T,B,F]; lengths: int64 [B] on device or None; weights per direction:
+    (w_ih [4H,F], w_hh [4H,H], b_ih [4H], b_hh [4H]).  Returns y [T,B,D*H] with zeros at
+    padded steps (pad_packed_sequence semantics, audiogan.py:214-229)."""
+
+    @staticmethod
+    def forward(ctx, x, lengths, ndir, *w):
+        T, B, F = x.shape
+        H = w[1].size(1)
+        dev = x.device
+        x2 = x.contiguous().view(T * B, F)
+        y = torch.empty(T, B, ndir * H, device=dev)
+        gates_all, c_all, whh = [], [], []
+        for d in range(ndir):
+            w_ih, w_hh, b_ih, b_hh = w[4 * d:4 * d + 4]
+            g = torch.empty(T, B, 4 * H, device=dev)
+            K.gemm(x2, w_ih.data, g.view(T * B, 4 * H), tb=True, bias=b_ih.data + b_hh.data)
+            c = torch.empty(T + 1, B, H, device=dev)   # c[k+1] = cell after the k-th processed step
+            c[0].zero_()
+            gates_all.append(g)
+            c_all.append(c)
+            whh.append(w_hh.data.contiguous())
+        hbuf = [torch.empty(2, B, H, device=dev) for _ in range(ndir)]
+        if K.lstm_step_ok(B, H):
+            K.lstm_seq_fwd(gates_all, whh, c_all, hbuf, y, lengths)
+        else:
+            for d in range(ndir):
+                g, c = gates_all[d], c_all[d]
+                hbuf[d][0].zero_()
+                for k in range(T):
+                    t = k if d == 0 else T - 1 - k
+                    hp, hn = hbuf[d][k & 1], hbuf[d][(k + 1) & 1]
+                    if k > 0:
+                        K.gemm(hp, whh[d], g[t], tb=True, beta=1.0)
+                    K.lstm_cell_fwd(g[t], c[k], c[k + 1], h_out=hn, y_out=y[t, :, d * H:(d + 1) * H],
+                                    h_prev=hp, valid=lengths, t=t)
+        ctx.ndir, ctx.has_len = ndir, lengths is not None
+        ctx.save_for_backward(x2, y, lengths if lengths is not None else x2.new_empty(0),
+                              *(gates_all + c_all + [t_.data for t_ in w]))
+        ctx.shape = (T, B, F, H)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        T, B, F, H = ctx.shape
+        ndir = ctx.ndir
+        sv = ctx.saved_tensors
+        x2, y = sv[0], sv[1]
+        lengths = sv[2] if ctx.has_len else None
+        gates_all, c_all, w = list(sv[3:3 + ndir]), list(sv[3 + ndir:3 + 2 * ndir]), sv[3 + 2 * ndir:]
+        dev = x2.device
+        dy = dy.contiguous()
+        whh = [w[4 * d + 1].contiguous() for d in range(ndir)]
+        dgs = [torch.empty(T, B, 4 * H, device=dev) for _ in range(ndir)]
+        dhb = [torch.empty(2, B, H, device=dev) for _ in range(ndir)]
+        dcb = [torch.empty(2, B, H, device=dev) for _ in range(ndir)]
+        if B <= 64 and H % 2 == 0:
+            K.lstm_seq_bwd(gates_all, whh, c_all, dy, dgs, dhb, dcb, lengths)
+        else:
+            for d in range(ndir):
+                g, c, dg = gates_all[d], c_all[d], dgs[d]
+                for k in reversed(range(T)):
+                    t = k if d == 0 else T - 1 - k
+                    dpass = dhb[d][(k + 1) & 1]
+                    K.lstm_cell_bwd(g[t], c[k], c[k + 1], None if k == T - 1 else dhb[d][k & 1],
+                                    dy[t, :, d * H:(d + 1) * H], None if k == T - 1 else dcb[d][(k + 1) & 1],
+                                    dg[t], dcb[d][k & 1], dh_pass=dpass, valid=lengths, t=t)
+                    if k > 0:
+                        K.gemm(dg[t], whh[d], dpass, beta=1.0)
+        dx2 = torch.empty(T * B, F, device=dev)
+        outs = []
+        for d in range(ndir):
+            w_ih, w_hh = w[4 * d], w[4 * d + 1]
+            dg2 = dgs[d].view(T * B, 4 * H)
+            dw_ih = torch.empty_like(w_ih)
+            K.gemm(dg2, x2, dw_ih, ta=True)
+            # h_prev of processing step k is the layer output of step k-1 (zero at padded steps,
+            # where dgates is zero as well)
+            dw_hh = torch.zeros_like(w_hh)
+            if T > 1:
+                if d == 0:
+                    K.gemm(dgs[d][1:].view((T - 1) * B, 4 * H), y[:-1].view((T - 1) * B, ndir * H)[:, :H],
+                           dw_hh, ta=True)
+                else:
+                    K.gemm(dgs[d][:-1].view((T - 1) * B, 4 * H),
+                           y[1:].view((T - 1) * B, ndir * H)[:, H:2 * H], dw_hh, ta=True)
+            db = torch.zeros(4 * H, device=dev)
+            K.col_sum(dg2, db)
+            K.gemm(dg2, w_ih, dx2, beta=0.0 if d == 0 else 1.0)
+            outs += [dw_ih, dw_hh, db, db.clone()]
+        dx = dx2.view(T, B, F) if ctx.needs_input_grad[0] else None
+        return (dx, None, None) + tuple(outs)
+
+
+# --------------------------------------------------------------------------------------
+# Generator recurrent front: T x [LSTMCell stack -> tanh(proj) fed back, stopper logit]
+# --------------------------------------------------------------------------------------
+class GFront(object):
+    """WN items: per layer [w_ih, w_hh, b_ih, b_hh] * num_layers, then [proj.w, proj.b, stop.w, stop.b]"""
+
+    def __init__(self, frame_size, num_layers, state_size):
+        self.fs, self.nl, self.ss = frame_size, num_layers, state_size
+        self.group = WNGroup()
+
+
+class GFrontFn(torch.autograd.Function):
+    """zc: [T,B,noise+embed] contiguous.  Returns x [B,T*fs], s [B,T].  Frame t's LSTM input is
+    [x_{t-1}, zc_t] (audiogan.py:439); the zc part of every frame's gate product is done in one
+    GEMM up front, only the fed-back x_{t-1} and h products stay in the sequential loop."""
+
+    @staticmethod
+    def forward(ctx, zc, front, *params):
+        T, B, Fz = zc.shape
+        fs, nl, S = front.fs, front.nl, front.ss
+        dev = zc.device
+        ctx.set_materialize_grads(False)
+        prep = front.group.prepare()
+        lw = [[p.w for p in prep[4 * l:4 * l + 4]] for l in range(nl)]
+        pw, pb, sw, sb = [p.w for p in prep[4 * nl:4 * nl + 4]]
+        x = torch.empty(B, T * fs, device=dev)
+        gates = [torch.empty(T, B, 4 * S, device=dev) for _ in range(nl)]
+        hs = [torch.empty(T, B, S, device=dev) for _ in range(nl)]
+        cs = [torch.empty(T + 1, B, S, device=dev) for _ in range(nl)]
+        h0 = torch.zeros(B, S, device=dev)
+        for l in range(nl):
+            cs[l][0].zero_()
+        bsum = [lw[l][2] + lw[l][3] for l in range(nl)]
+        w_ih0 = lw[0][0]
+        wx, wz = w_ih0[:, :fs], w_ih0[:, fs:]
+        # all frames at once: zc_t @ W_ih[:, fs:]^T + b_ih + b_hh
+        K.gemm(zc.contiguous().view(T * B, Fz), wz, gates[0].view(T * B, 4 * S), tb=True, bias=bsum[0])
+        fused0 = K.lstm_step_ok(B, S, x[:, :fs], wx)
+        for t in range(T):
+            xprev = x[:, (t - 1) * fs:t * fs] if t > 0 else x[:, :fs]
+            if fused0:
+                K.lstm_step_fwd(gates[0][t], xprev, wx, hs[0][t - 1] if t > 0 else h0, lw[0][1], cs[0][t],
+                                cs[0][t + 1], hs[0][t], first_step=(t == 0))
+            else:
+                if t > 0:
+                    K.gemm(xprev, wx, gates[0][t], tb=True, beta=1.0)
+                    K.gemm(hs[0][t - 1], lw[0][1], gates[0][t], tb=True, beta=1.0)
+                K.lstm_cell_fwd(gates[0][t], cs[0][t], cs[0][t + 1], h_out=hs[0][t])
+            for l in range(1, nl):
+                _small(hs[l - 1][t], lw[l][0], gates[l][t], tb=True, bias=bsum[l])
+                if K.lstm_step_ok(B, S):
+                    K.lstm_step_fwd(gates[l][t], None, None, hs[l][t - 1] if t > 0 else h0, lw[l][1],
+                                    cs[l][t], cs[l][t + 1], hs[l][t], first_step=(t == 0))
+                else:
+                    if t > 0:
+                        K.gemm(hs[l][t - 1], lw[l][1], gates[l][t], tb=True, beta=1.0)
+                    K.lstm_cell_fwd(gates[l][t], cs[l][t], cs[l][t + 1], h_out=hs[l][t])
+            _small(hs[-1][t], pw, x[:, t * fs:(t + 1) * fs], tb=True, bias=pb, act=ACT_TANH)
+        s = torch.empty(T * B, 1, device=dev)
+        K.gemm(hs[-1].view(T * B, S), sw, s, tb=True, bias=sb)
+        ctx.front, ctx.key = front, front.group._key
+        ctx.dims = (T, B, Fz)
+        ctx.save_for_backward(zc, x, *(gates + hs + cs))
+        return x, s.view(T, B).t()
+
+    @staticmethod
+    def backward(ctx, dx, ds):
+        front = ctx.front
+        fs, nl, S = front.fs, front.nl, front.ss
+        T, B, Fz = ctx.dims
+        prep = front.group.prepare()
+        assert front.group._key == ctx.key, 'parameters changed between forward and backward'
+        sv = ctx.saved_tensors
+        zc, x = sv[0], sv[1]
+        gates, hs, cs = sv[2:2 + nl], sv[2 + nl:2 + 2 * nl], sv[2 + 2 * nl:2 + 3 * nl]
+        dev = zc.device
+        lw = [[p.w for p in prep[4 * l:4 * l + 4]] for l in range(nl)]
+        pw, sw = prep[4 * nl].w, prep[4 * nl + 2].w
+        wx = lw[0][0][:, :fs]
+        dws = _zeros_like_list([it['v'] for it in front.group.items])
+        # dxa[:, frame t] accumulates dL/dx_t: output gradient + feedback from frame t+1
+        dxa = dx.contiguous().clone() if dx is not None else torch.zeros(B, T * fs, device=dev)
+        # dha[l][t] accumulates dL/dh_l[t]: recurrent term from frame t+1, the layer above / the
+        # projection at frame t, and (top layer) the stopper head
+        dha = [torch.zeros(T, B, S, device=dev) for _ in range(nl)]
+        if ds is not None:
+            ds_tb = ds.t().contiguous().view(T * B, 1)
+            K.gemm(ds_tb, hs[-1].view(T * B, S), dws[4 * nl + 2], ta=True)
+            K.col_sum(ds_tb, dws[4 * nl + 3])
+            K.gemm(ds_tb, sw, dha[-1].view(T * B, S))
+        dgs = [torch.empty(T, B, 4 * S, device=dev) for _ in range(nl)]
+        dxt = torch.empty(T, B, fs, device=dev)      # d(pre-tanh) of the projection, per frame
+        dcs = [[torch.zeros(B, S, device=dev), torch.empty(B, S, device=dev)] for _ in range(nl)]
+        xt_c = torch.empty(B, fs, device=dev)
+        for t in reversed(range(T)):
+            gx = dxt[t]
+            gx.copy_(dxa[:, t * fs:(t + 1) * fs])
+            xt_c.copy_(x[:, t * fs:(t + 1) * fs])
+            K.act_bwd(gx, xt_c, gx, ACT_TANH)
+            _small_acc(gx, pw, dha[-1][t])                                   # through the projection
+            for l in reversed(range(nl)):
+                K.lstm_cell_bwd(gates[l][t], cs[l][t], cs[l][t + 1], dha[l][t], None,
+                                dcs[l][(t + 1) & 1] if t < T - 1 else None, dgs[l][t], dcs[l][t & 1])
+                if t > 0:
+                    _small_acc(dgs[l][t], lw[l][1], dha[l][t - 1])           # into h_l[t-1]
+                if l > 0:
+                    _small_acc(dgs[l][t], lw[l][0], dha[l - 1][t])           # into h_{l-1}[t]
+                elif t > 0:
+                    _small_acc(dgs[0][t], wx, dxa[:, (t - 1) * fs:t * fs])   # into x_{t-1}
+        # parameter gradients, one GEMM per tensor over all frames
+        dxt2 = dxt.view(T * B, fs)
+        K.gemm(dxt2, hs[-1].view(T * B, S), dws[4 * nl], ta=True)
+        K.col_sum(dxt2, dws[4 * nl + 1])
+        for l in range(nl):
+            dg2 = dgs[l].view(T * B, 4 * S)
+            dwih = dws[4 * l]
+            if l == 0:
+                K.gemm(dg2, zc.contiguous().view(T * B, Fz), dwih[:, fs:], ta=True)
+                if T > 1:
+                    xprev = x.view(B, T, fs)[:, :T - 1].transpose(0, 1).contiguous().view((T - 1) * B, fs)
+                    K.gemm(dgs[0][1:].view((T - 1) * B, 4 * S), xprev, dwih[:, :fs], ta=True)
+            else:
+                K.gemm(dg2, hs[l - 1].view(T * B, S), dwih, ta=True)
+            if T > 1:
+                K.gemm(dgs[l][1:].view((T - 1) * B, 4 * S), hs[l][:T - 1].view((T - 1) * B, S),
+                       dws[4 * l + 1], ta=True)
+            K.col_sum(dg2, dws[4 * l + 2])
+            dws[4 * l + 3].copy_(dws[4 * l + 2])
+        dzc = None
+        if ctx.needs_input_grad[0]:
+            dzc = torch.empty(T * B, Fz, device=dev)
+            K.gemm(dgs[0].view(T * B, 4 * S), lw[0][0][:, fs:], dzc)
+            dzc = dzc.view(T, B, Fz)
+        grads = front.group.backward(dws)
+        return (dzc, None) + tuple(grads)

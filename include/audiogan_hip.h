@@ -174,6 +174,37 @@ int ag_lstm_cell_bwd(const float* gates_act, int ldg, const float* c_prev, int l
                      float* dc_prev, int lddcp, float* dh_pass, int lddhp, const int64_t* valid_i64,
                      int t, int B, int H, void* stream);
 
+/* Skinny product for the sequential part of the recurrent layers (M = clips per GPU <= 64):
+ *   C[M,N] = act(A[M,K] * op(B) + beta*C + bias)         (accumulate_atomic == 0)
+ *   C[M,N] += A[M,K] * op(B) (+ bias)   K split over workgroups, fp32 atomics  (== 1)
+ * tb: 1 -> B stored [N,K] (Linear weight), 0 -> B stored [K,N].  Needs K % 8 == 0 and 16-byte
+ * aligned rows of A (and of B when tb == 1). */
+int ag_skinny_gemm(const float* A, int lda, const float* B, int ldb, int tb, float* C, int ldc,
+                   int M, int N, int K, float beta, const float* bias, int act, float slope,
+                   int accumulate_atomic, void* stream);
+
+/* One fused LSTMCell step (audiogan.py:439-442): gates_pre [B,4H] holds the part of the gate
+ * pre-activations that does not depend on the recurrence (z/c columns of W_ih + both biases);
+ * the kernel adds x[B,Kx]*wx^T (fed-back frame, columns [0,Kx) of W_ih) and h_prev*whh^T,
+ * applies the cell and overwrites gates_pre with the activated gates. first_step: x and h_prev
+ * are zero and skipped. */
+int ag_lstm_step_fwd(float* gates_pre, const float* x, int ldx, const float* wx, int ldwx, int Kx,
+                     const float* h_prev, const float* whh, const float* c_prev, float* c_out,
+                     float* h_out, int B, int H, int first_step, void* stream);
+
+/* A whole (bi)directional NN.LSTM layer over a padded batch (audiogan.py:498-503, :543 and the
+ * pack/unpack of :214-229 expressed as a per-clip valid length): T fused steps enqueued by one
+ * call.  Tables are HOST arrays of device pointers, one entry per direction.
+ *   pre[d]   [T,B,4H] x-projection + biases; overwritten with the activated gates
+ *   whh[d]   [4H,H];  c_all[d] [T+1,B,H] with c_all[d][0] = 0;  hbuf[d] [2,B,H] scratch
+ *   y        [T,B,ndir*H]; direction 1 walks the sequence backwards */
+int ag_lstm_seq_fwd(float* const* pre, const float* const* whh, float* const* c_all,
+                    float* const* hbuf, float* y, const int64_t* valid_i64, int T, int B, int H,
+                    int ndir, void* stream);
+int ag_lstm_seq_bwd(const float* const* gates, const float* const* whh, const float* const* c_all,
+                    const float* dy, float* const* dgates, float* const* dhbuf, float* const* dcbuf,
+                    const int64_t* valid_i64, int T, int B, int H, int ndir, void* stream);
+
 /* ---------------------------------------------------------------------------
  * Masked BCE-with-logits per sample (audiogan.py:187-197 + :204-211 + the
  * "/ nframes ... .mean()" at :739-740,766,780,864,897), fused:

@@ -280,3 +280,76 @@ def install(monkeypatch):
             continue
         assert hasattr(K, n), 'kernel model has %s but audiogan_amd.kernels does not' % n
         monkeypatch.setattr(K, n, globals()[n])
+
+
+# ---- skinny products / fused recurrent steps (same contracts as lstm_step.hip) -----------------
+def skinny_ok(A, B, tb):
+    M, Kd = A.shape
+    ok = M <= 64 and Kd % 8 == 0 and A.stride(1) == 1 and A.stride(0) % 4 == 0
+    if tb:
+        ok = ok and B.stride(1) == 1 and B.stride(0) % 4 == 0
+    return ok
+
+
+def skinny_gemm(A, B, Cm, tb=False, beta=0.0, bias=None, act=ACT_NONE, slope=LEAKY_SLOPE, atomic=False):
+    assert skinny_ok(A, B, tb)
+    out = A @ (B.t() if tb else B)
+    if atomic:
+        assert act == ACT_NONE
+        Cm.add_(out + (bias.view(1, -1) if bias is not None else 0.0))
+        return
+    if beta != 0.0:
+        out = out + beta * Cm
+    if bias is not None:
+        out = out + bias.view(1, -1)
+    Cm.copy_(_act(out, act, slope))
+
+
+def lstm_step_ok(B, H, x=None, wx=None):
+    ok = B <= 64 and H % 8 == 0
+    if x is not None:
+        ok = ok and x.size(1) % 8 == 0 and x.stride(0) % 4 == 0 and wx.stride(0) % 4 == 0
+    return ok
+
+
+def lstm_step_fwd(gates_pre, x, wx, h_prev, whh, c_prev, c_out, h_out, first_step):
+    if not first_step:
+        if x is not None:
+            gates_pre.add_(x @ wx.t())
+        gates_pre.add_(h_prev @ whh.t())
+    lstm_cell_fwd(gates_pre, c_prev, c_out, h_out=h_out)
+
+
+def lstm_seq_fwd(pre, whh, c_all, hbuf, y, valid):
+    ndir = len(pre)
+    T, B, H4 = pre[0].shape
+    H = H4 // 4
+    for d in range(ndir):
+        hbuf[d][0].zero_()
+        for k in range(T):
+            t = k if d == 0 else T - 1 - k
+            hp, hn = hbuf[d][k & 1], hbuf[d][(k + 1) & 1]
+            if k > 0:
+                pre[d][t].add_(hp @ whh[d].t())
+            lstm_cell_fwd(pre[d][t], c_all[d][k], c_all[d][k + 1], h_out=hn,
+                          y_out=y[t, :, d * H:(d + 1) * H], h_prev=hp, valid=valid, t=t)
+
+
+def lstm_seq_bwd(gates, whh, c_all, dy, dgates, dhbuf, dcbuf, valid):
+    ndir = len(gates)
+    T, B, H4 = gates[0].shape
+    H = H4 // 4
+    for d in range(ndir):
+        for k in reversed(range(T)):
+            t = k if d == 0 else T - 1 - k
+            dh = None if k == T - 1 else dhbuf[d][k & 1]
+            dcn = None if k == T - 1 else dcbuf[d][(k + 1) & 1]
+            dpass = dhbuf[d][(k + 1) & 1]
+            lstm_cell_bwd(gates[d][t], c_all[d][k], c_all[d][k + 1], dh, dy[t, :, d * H:(d + 1) * H], dcn,
+                          dgates[d][t], dcbuf[d][k & 1], dh_pass=dpass, valid=valid, t=t)
+            if k > 0:
+                dpass.add_(dgates[d][t] @ whh[d])
+
+
+ALL = [n for n, v in list(globals().items()) if callable(v) and not n.startswith('_')
+       and n not in ('F', 'install')]

@@ -304,3 +304,81 @@ def test_error_convention(K):
         K.conv_engine(x, torch.zeros(K.wpa_numel(4, 3, 3)).cuda(), torch.zeros(2, 4, 9999).cuda(), 3, 1, 1, 0)
     with pytest.raises(RuntimeError):
         K.act_fwd(torch.zeros(4), torch.zeros(4), K.ACT_LEAKY)   # CPU tensor: no fallback
+
+
+@pytest.mark.parametrize('shape', [(64, 2048, 512), (64, 512, 2048), (64, 256, 1024), (64, 1024, 4096),
+                                   (3, 40, 24), (33, 7, 8), (64, 4096, 256)])
+@pytest.mark.parametrize('tb', [True, False])
+def test_skinny_gemm(K, shape, tb):
+    M, N, Kd = shape
+    gen = torch.Generator().manual_seed(13)
+    A = torch.randn(M, Kd, generator=gen) / Kd ** 0.5
+    Bm = torch.randn((N, Kd) if tb else (Kd, N), generator=gen)
+    C0, bias = torch.randn(M, N, generator=gen), torch.randn(N, generator=gen)
+    prod = A @ (Bm.t() if tb else Bm)
+    Cd = dev(C0.clone())
+    K.skinny_gemm(dev(A), dev(Bm), Cd, tb=tb, beta=1.0, bias=dev(bias), act=K.ACT_TANH)
+    close(Cd, torch.tanh(prod + C0 + bias))
+    Cd = dev(C0.clone())
+    K.skinny_gemm(dev(A), dev(Bm), Cd, tb=tb, atomic=True)
+    close(Cd, prod + C0)
+    Cd = dev(C0.clone())
+    K.skinny_gemm(dev(A), dev(Bm), Cd, tb=tb)
+    close(Cd, prod)
+
+
+def test_skinny_rejects_unaligned(K):
+    with pytest.raises(ValueError):
+        K.skinny_gemm(torch.zeros(4, 12).cuda(), torch.zeros(5, 12).cuda(), torch.zeros(4, 5).cuda(), tb=True)
+    assert not K.skinny_ok(torch.zeros(4, 12).cuda(), torch.zeros(5, 12).cuda(), True)
+    assert not K.skinny_ok(torch.zeros(70, 16).cuda(), torch.zeros(5, 16).cuda(), True)
+
+
+@pytest.mark.parametrize('B,H,Kx', [(64, 1024, 256), (64, 512, 0), (5, 24, 16), (33, 64, 32)])
+def test_lstm_step_fwd(K, B, H, Kx):
+    gen = torch.Generator().manual_seed(14)
+    pre = torch.randn(B, 4 * H, generator=gen)
+    xfull = torch.randn(B, 3 * max(Kx, 8), generator=gen)
+    wfull = torch.randn(4 * H, max(Kx, 8) + 40, generator=gen) / 8
+    x, wx = (xfull[:, Kx:2 * Kx], wfull[:, :Kx]) if Kx else (None, None)
+    hp, cp = torch.randn(B, H, generator=gen), torch.randn(B, H, generator=gen)
+    whh = torch.randn(4 * H, H, generator=gen) / H ** 0.5
+    for first in (False, True):
+        rg, rc, rh = pre.clone(), torch.empty(B, H), torch.empty(B, H)
+        KM.lstm_step_fwd(rg, x, wx, hp, whh, cp, rc, rh, first)
+        g_d, c_d, h_d = dev(pre.clone()), torch.empty(B, H).cuda(), torch.empty(B, H).cuda()
+        xd, wd = dev(xfull), dev(wfull)
+        K.lstm_step_fwd(g_d, xd[:, Kx:2 * Kx] if Kx else None, wd[:, :Kx] if Kx else None, dev(hp), dev(whh),
+                        dev(cp), c_d, h_d, first)
+        close(g_d, rg, rtol=1e-4); close(c_d, rc, rtol=1e-4); close(h_d, rh, rtol=1e-4)
+
+
+@pytest.mark.parametrize('T,B,H,ndir,ragged', [(128, 64, 512, 2, True), (5, 3, 8, 2, True), (7, 33, 24, 1, False),
+                                               (1, 4, 16, 2, True)])
+def test_lstm_seq_fwd_bwd(K, T, B, H, ndir, ragged):
+    gen = torch.Generator().manual_seed(15)
+    pre = [torch.randn(T, B, 4 * H, generator=gen) for _ in range(ndir)]
+    whh = [torch.randn(4 * H, H, generator=gen) / H ** 0.5 for _ in range(ndir)]
+    valid = torch.randint(1, T + 1, (B,), generator=gen) if ragged else None
+    if ragged:
+        valid[0] = T
+    def run(mod, to):
+        p = [to(t.clone()) for t in pre]
+        w = [to(t) for t in whh]
+        c = [to(torch.zeros(T + 1, B, H)) for _ in range(ndir)]
+        hb = [to(torch.zeros(2, B, H)) for _ in range(ndir)]
+        y = to(torch.full((T, B, ndir * H), float('nan')))
+        v = to(valid) if valid is not None else None
+        mod.lstm_seq_fwd(p, w, c, hb, y, v)
+        dy = to(torch.randn(T, B, ndir * H, generator=torch.Generator().manual_seed(16)))
+        dg = [to(torch.full((T, B, 4 * H), float('nan'))) for _ in range(ndir)]
+        dh = [to(torch.zeros(2, B, H)) for _ in range(ndir)]
+        dc = [to(torch.zeros(2, B, H)) for _ in range(ndir)]
+        mod.lstm_seq_bwd(p, w, c, dy, dg, dh, dc, v)
+        return y, c, dg, p
+    yr, cr, dgr, pr = run(KM, lambda t: t)
+    y, c, dg, p = run(K, lambda t: t.cuda())
+    close(y, yr, rtol=1e-3, atol=1e-5)
+    for d in range(ndir):
+        close(c[d], cr[d], rtol=1e-3, atol=1e-5)
+        close(dg[d], dgr[d], rtol=2e-3, atol=2e-5)

@@ -172,3 +172,31 @@ def test_per_sample_bce_api():
     np.testing.assert_allclose(x.grad.numpy(), xo.grad.numpy(), rtol=1e-5, atol=1e-7)
     with pytest.raises(ValueError):
         A.binary_cross_entropy_with_logits_per_sample(x, torch.zeros(4, 3))
+
+
+def test_aligned_shapes_take_fused_paths_and_match_oracle():
+    """sizes that satisfy the fused-step / skinny-product requirements (multiples of 8)"""
+    torch.manual_seed(21)
+    gcfg = dict(frame_size=32, embed_size=8, noise_size=8, state_size=64, num_layers=2,
+                struct=[[17, 8, 16, 8], [9, 4, 16, 8]])
+    dcfg = dict(state_size=64, embed_size=8, num_layers=2, cnn_struct=[[7, 2, 8], [7, 2, 16]])
+    go, do = O.Generator(**gcfg), O.Discriminator(**dcfg)
+    g, d = M.Generator(**gcfg), M.Discriminator(**dcfg)
+    g.load_state_dict(go.state_dict()); d.load_state_dict(do.state_dict())
+    B, T = 5, 4
+    z, c = torch.randn(B, T, 8), torch.randn(B, 8)
+    lens = torch.tensor([128, 128, 77, 30, 128])
+    xo, so, _, _ = go(z=z, c=c, stop=torch.zeros(B, T, dtype=torch.long))
+    x, s, _, _ = g(z=z, c=c, stop='never')
+    np.testing.assert_allclose(x.detach().numpy(), xo.detach().numpy(), rtol=1e-4, atol=1e-5)
+    lo = do(xo, lens, c)[0]
+    l = d(x, lens, c)[0]
+    np.testing.assert_allclose(l.detach().numpy(), lo.detach().numpy(), rtol=1e-4, atol=1e-5)
+    w = torch.randn(lo.shape)
+    ((lo * w).sum() + (so * 0.3).sum()).backward()
+    ((l * w).sum() + (s * 0.3).sum()).backward()
+    for a, b in ((g, go), (d, do)):
+        for (k, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):
+            if k.split('.')[-1].startswith('bias') and k.endswith('_v'):
+                continue
+            np.testing.assert_allclose(p.grad.numpy(), q.grad.numpy(), rtol=5e-4, atol=2e-5, err_msg=k)
