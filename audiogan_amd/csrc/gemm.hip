@@ -21,6 +21,8 @@ struct GemmP {
   float alpha, beta, slope;
   int act;
   int vecA, vecB;  // 16-B vector loads allowed for A / B
+  int ksplit;      // > 1: grid.z K slices, fp32 atomic epilogue into a pre-initialised C
+  int kchunk;      // K per slice (multiple of GBK)
 };
 
 // operand stored [rows][K] (k contiguous): tile -> S[k][r]
@@ -99,7 +101,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  for (int k0 = 0; k0 < p.K; k0 += GBK) {
+  const int kbeg = blockIdx.z * p.kchunk;
+  const int kend = (kbeg + p.kchunk < p.K) ? kbeg + p.kchunk : p.K;
+  for (int k0 = kbeg; k0 < kend; k0 += GBK) {
     __syncthreads();
     if (TA == 0)
       load_kcontig<BM, PA>(As, p.A, p.lda, m0, p.M, k0, p.K, p.vecA, tid);
@@ -137,6 +141,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
         if (col >= p.N) continue;
         float v = p.alpha * acc[i][j][e];
         float* dst = p.C + (int64_t)row * p.ldc + col;
+        if (p.ksplit > 1) {
+          if (blockIdx.z == 0) {
+            if (p.bias) v += p.bias[col];
+            if (p.res) v += p.res[(int64_t)row * p.ldres + col];
+          }
+          atomicAdd(dst, v);
+          continue;
+        }
         if (p.beta != 0.f) v += p.beta * *dst;
         if (p.bias) v += p.bias[col];
         if (p.res) v += p.res[(int64_t)row * p.ldres + col];
@@ -148,7 +160,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
 template <int TM, int TN, int WM, int WN>
 static int launch_gemm(const GemmP& p, int ta, int tb, hipStream_t st) {
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
-  dim3 grid(ag_cdiv(p.N, BN), ag_cdiv(p.M, BM));
+  dim3 grid(ag_cdiv(p.N, BN), ag_cdiv(p.M, BM), p.ksplit);
   if (ta == 0 && tb == 0) hipLaunchKernelGGL((gemm_kernel<TM, TN, WM, WN, 0, 0>), grid, dim3(256), 0, st, p);
   if (ta == 0 && tb == 1) hipLaunchKernelGGL((gemm_kernel<TM, TN, WM, WN, 0, 1>), grid, dim3(256), 0, st, p);
   if (ta == 1 && tb == 0) hipLaunchKernelGGL((gemm_kernel<TM, TN, WM, WN, 1, 0>), grid, dim3(256), 0, st, p);
@@ -175,9 +187,37 @@ extern "C" int ag_gemm(const float* A, int lda, int ta, const float* B, int ldb,
   p.vecA = aligned16(A) && (lda % 4 == 0);
   p.vecB = aligned16(B) && (ldb % 4 == 0);
   hipStream_t st = (hipStream_t)stream;
+  p.ksplit = 1;
+  p.kchunk = ag_roundup(K, GBK);
   const int64_t big = (int64_t)ag_cdiv(M, 128) * ag_cdiv(N, 128);
-  if (M > 64 && N > 64 && big >= 192) return launch_gemm<2, 2, 2, 2>(p, ta, tb, st);  // 128x128
-  return launch_gemm<1, 1, 2, 2>(p, ta, tb, st);                                       // 64x64
+  const bool use128 = M > 64 && N > 64 && (big >= 192 || K >= 2048);
+  const int64_t tiles = use128 ? big : (int64_t)ag_cdiv(M, 64) * ag_cdiv(N, 64);
+  // few output tiles but a long reduction (weight gradients over all frames): slice K over
+  // grid.z and combine with atomics.  Needs a linear epilogue on a C that already holds beta*C.
+  if (tiles < 192 && K >= 1024 && act == AG_ACT_NONE && (beta == 0.f || beta == 1.f)) {
+    int ks = (int)(512 / tiles);
+    if (ks > K / 256) ks = K / 256;
+    if (ks > 32) ks = 32;
+    if (ks >= 2) {
+      p.ksplit = ks;
+      p.kchunk = ag_roundup(ag_cdiv(K, ks), GBK);
+      p.ksplit = ag_cdiv(K, p.kchunk);
+      if (beta == 0.f) {
+        if (ldc == N) {
+          if (hipMemsetAsync(C, 0, sizeof(float) * (size_t)M * N, st) != hipSuccess) {
+            ag_set_error("ag_gemm: memset failed");
+            return AG_ERR_LAUNCH;
+          }
+        } else if (hipMemset2DAsync(C, sizeof(float) * (size_t)ldc, 0, sizeof(float) * (size_t)N, M, st) !=
+                   hipSuccess) {
+          ag_set_error("ag_gemm: memset2D failed");
+          return AG_ERR_LAUNCH;
+        }
+      }
+    }
+  }
+  if (use128) return launch_gemm<2, 2, 2, 2>(p, ta, tb, st);  // 128x128
+  return launch_gemm<1, 1, 2, 2>(p, ta, tb, st);              // 64x64
 }
 
 // out[n] += sum_m X[m, n]

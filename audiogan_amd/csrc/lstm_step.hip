@@ -2,15 +2,17 @@
 // Generator, audiogan.py:437-443; NN.LSTM of the Discriminator, :498-503,:543).
 //
 // Per time step the work is a "skinny" product  [B<=64, K] x [K, N]  (B = clips per GPU):
-// far too small for a tiled GEMM grid, and strictly sequential over time.  Two kernels:
+// far too small for a tiled GEMM grid, and strictly sequential over time.  Kernels:
 //
-//  * skinny_gemm_kernel    C[M<=64, N] (+)= A[M,K] * op(B): every wave owns a 64x32 output
+//  * skinny_gemm_kernel    C[M<=64, N] (+)= A[M,K] * op(B): every wave owns a 32x32 output
 //    tile and a K slice; MFMA operands are fetched STRAIGHT from global/L2 as 16-byte
 //    row pieces (no LDS staging: nothing is reused inside a workgroup), K slices are summed
-//    through LDS inside a workgroup and with fp32 atomics across workgroups.
+//    through LDS inside a workgroup and with fp32 atomics across workgroups.  Up to two
+//    independent problems (the two directions of a bidirectional layer) share one launch.
 //  * lstm_step_fwd_kernel  one LSTM time step fused: gates = pre + [x,h] * [Wx|Whh]^T for the
 //    4 gates of 8 hidden units per workgroup, then the cell non-linearity in the epilogue.
 //    Both directions of a bidirectional layer run in the same launch (grid.y).
+//  * lstm_cell_bwd2_kernel the pointwise cell backward for both directions in one launch.
 //
 // MFMA k-slot trick: v_mfma_f32_32x32x2_f32 sums two k values per instruction, lane half h
 // supplying k-slot h.  Each lane loads a float4 A[row][8q+4h .. +3]; MFMA e (0..3) then
@@ -19,132 +21,133 @@
 
 #define SK_MAXW 16
 
-struct SkinnyP {
+struct SkinnyOne {
   const float* A;
   const float* B;
   float* C;
   const float* bias;
+};
+
+struct SkinnyP {
+  SkinnyOne q[2];
   int lda, ldb, ldc;
   int M, N, K;
   int tb;        // 1: B stored [N][K]; 0: B stored [K][N]
   int act;
   float slope, beta;
+  int mtiles;    // grid.z = nprob * mtiles
 };
 
-// accumulate A[0..64, k0..k1) x Brows over the wave's K range; brow = this lane's B row (tb=1)
-template <int MT>
-__device__ __forceinline__ void skinny_core_nt(f32x16 (&acc)[MT], const float* __restrict__ A, int lda,
-                                               int M, const float* __restrict__ brow, bool bok, int k0,
-                                               int k1, int l31, int h) {
-  const float* ar[MT];
-  bool aok[MT];
-#pragma unroll
-  for (int t = 0; t < MT; ++t) {
-    aok[t] = (32 * t + l31) < M;
-    ar[t] = A + (int64_t)(aok[t] ? 32 * t + l31 : 0) * lda + 4 * h;
-  }
+// A rows m0..m0+31 (k contiguous) x B rows (k contiguous), K range [k0,k1) (multiples of 8)
+__device__ __forceinline__ void skinny_core_nt(f32x16& acc, const float* __restrict__ arow, bool aok,
+                                               const float* __restrict__ brow, bool bok, int k0, int k1,
+                                               int h) {
+  const float* ar = arow + 4 * h;
   const float* br = brow + 4 * h;
-#pragma unroll 4
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
   for (int k = k0; k < k1; k += 8) {
-    f32x4 b = bok ? *reinterpret_cast<const f32x4*>(br + k) : f32x4{0.f, 0.f, 0.f, 0.f};
-    f32x4 a[MT];
+    const f32x4 b = bok ? *reinterpret_cast<const f32x4*>(br + k) : z;
+    const f32x4 a = aok ? *reinterpret_cast<const f32x4*>(ar + k) : z;
 #pragma unroll
-    for (int t = 0; t < MT; ++t)
-      a[t] = aok[t] ? *reinterpret_cast<const f32x4*>(ar[t] + k) : f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int e = 0; e < 4; ++e)
-#pragma unroll
-      for (int t = 0; t < MT; ++t)
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t][e], b[e], acc[t], 0, 0, 0);
+    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e], acc, 0, 0, 0);
   }
 }
 
 // B stored [K][N]: lane j reads B[k][n0+j] (coalesced along n)
-template <int MT>
-__device__ __forceinline__ void skinny_core_nn(f32x16 (&acc)[MT], const float* __restrict__ A, int lda,
-                                               int M, const float* __restrict__ bcol, int ldb, bool bok,
-                                               int k0, int k1, int l31, int h) {
-  const float* ar[MT];
-  bool aok[MT];
-#pragma unroll
-  for (int t = 0; t < MT; ++t) {
-    aok[t] = (32 * t + l31) < M;
-    ar[t] = A + (int64_t)(aok[t] ? 32 * t + l31 : 0) * lda + 4 * h;
-  }
-#pragma unroll 2
+__device__ __forceinline__ void skinny_core_nn(f32x16& acc, const float* __restrict__ arow, bool aok,
+                                               const float* __restrict__ bcol, int ldb, bool bok, int k0,
+                                               int k1, int h) {
+  const float* ar = arow + 4 * h;
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
   for (int k = k0; k < k1; k += 8) {
     float b[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) b[e] = bok ? bcol[(int64_t)(k + 4 * h + e) * ldb] : 0.f;
-    f32x4 a[MT];
+    const f32x4 a = aok ? *reinterpret_cast<const f32x4*>(ar + k) : z;
 #pragma unroll
-    for (int t = 0; t < MT; ++t)
-      a[t] = aok[t] ? *reinterpret_cast<const f32x4*>(ar[t] + k) : f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int e = 0; e < 4; ++e)
-#pragma unroll
-      for (int t = 0; t < MT; ++t)
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t][e], b[e], acc[t], 0, 0, 0);
+    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e], acc, 0, 0, 0);
   }
 }
 
-// sum the per-wave accumulators through LDS; afterwards red[0][..] holds the block total
-template <int MT>
-__device__ __forceinline__ void block_reduce_acc(const f32x16 (&acc)[MT], float* red, int nw, int wid,
-                                                 int lane) {
-  float* mine = red + (size_t)wid * (MT * 16 * 64);
+// sum the per-wave 32x32 accumulators through LDS; afterwards red[0..1023] holds the block total,
+// element (e, lane) at red[e*64 + lane]
+__device__ __forceinline__ void block_reduce_acc(const f32x16& acc, float* red, int nw, int wid, int lane) {
+  float* mine = red + (size_t)wid * 1024;
 #pragma unroll
-  for (int t = 0; t < MT; ++t)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) mine[(t * 16 + e) * 64 + lane] = acc[t][e];
+  for (int e = 0; e < 16; ++e) mine[e * 64 + lane] = acc[e];
   __syncthreads();
-  const int nout = MT * 16 * 64;
-  for (int o = threadIdx.x; o < nout; o += blockDim.x) {
+  for (int o = threadIdx.x; o < 1024; o += blockDim.x) {
     float s = red[o];
-    for (int w = 1; w < nw; ++w) s += red[(size_t)w * nout + o];
+    for (int w = 1; w < nw; ++w) s += red[(size_t)w * 1024 + o];
     red[o] = s;
   }
   __syncthreads();
 }
 
-template <int MT>
 __global__ __launch_bounds__(1024) void skinny_gemm_kernel(const SkinnyP p) {
   extern __shared__ float red[];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const int l31 = lane & 31, h = lane >> 5;
+  const SkinnyOne& Q = p.q[blockIdx.z / p.mtiles];
+  const int m0 = (blockIdx.z % p.mtiles) * 32;
   const int n0 = blockIdx.x * 32;
   const int W = gridDim.y * nw, wg = blockIdx.y * nw + wid;
   const int KU = p.K >> 3;
   const int k0 = (int)((int64_t)KU * wg / W) * 8, k1 = (int)((int64_t)KU * (wg + 1) / W) * 8;
-  f32x16 acc[MT];
+  f32x16 acc;
 #pragma unroll
-  for (int t = 0; t < MT; ++t)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
-  const bool bok = (n0 + l31) < p.N;
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  const bool bok = (n0 + l31) < p.N, aok = (m0 + l31) < p.M;
+  const float* arow = Q.A + (int64_t)(aok ? m0 + l31 : 0) * p.lda;
   if (p.tb)
-    skinny_core_nt<MT>(acc, p.A, p.lda, p.M, p.B + (int64_t)(bok ? n0 + l31 : 0) * p.ldb, bok, k0, k1, l31, h);
+    skinny_core_nt(acc, arow, aok, Q.B + (int64_t)(bok ? n0 + l31 : 0) * p.ldb, bok, k0, k1, h);
   else
-    skinny_core_nn<MT>(acc, p.A, p.lda, p.M, p.B + (bok ? n0 + l31 : 0), p.ldb, bok, k0, k1, l31, h);
-  block_reduce_acc<MT>(acc, red, nw, wid, lane);
-  const int nout = MT * 16 * 64;
+    skinny_core_nn(acc, arow, aok, Q.B + (bok ? n0 + l31 : 0), p.ldb, bok, k0, k1, h);
+  block_reduce_acc(acc, red, nw, wid, lane);
   const bool direct = gridDim.y == 1;
-  for (int o = threadIdx.x; o < nout; o += blockDim.x) {
-    const int ln = o & 63, e = (o >> 6) & 15, t = o >> 10;
-    const int m = 32 * t + (e & 3) + 8 * (e >> 2) + 4 * (ln >> 5);
+  for (int o = threadIdx.x; o < 1024; o += blockDim.x) {
+    const int ln = o & 63, e = o >> 6;
+    const int m = m0 + (e & 3) + 8 * (e >> 2) + 4 * (ln >> 5);
     const int n = n0 + (ln & 31);
     if (m >= p.M || n >= p.N) continue;
-    float* dst = p.C + (int64_t)m * p.ldc + n;
+    float* dst = Q.C + (int64_t)m * p.ldc + n;
     float v = red[o];
     if (direct) {
       if (p.beta != 0.f) v += p.beta * *dst;
-      if (p.bias) v += p.bias[n];
+      if (Q.bias) v += Q.bias[n];
       *dst = ag_apply_act(v, p.act, p.slope);
     } else {
-      if (p.bias && blockIdx.y == 0) v += p.bias[n];
+      if (Q.bias && blockIdx.y == 0) v += Q.bias[n];
       atomicAdd(dst, v);
     }
   }
+}
+
+static int launch_skinny(SkinnyP& p, int nprob, int accumulate_atomic, hipStream_t st) {
+  const int gx = ag_cdiv(p.N, 32);
+  const int KU = p.K / 8;
+  p.mtiles = ag_cdiv(p.M, 32);
+  const int gz = nprob * p.mtiles;
+  int nw, gy;
+  if (accumulate_atomic) {
+    // C already holds the value to add to; spread K over ~1024 waves on the chip
+    nw = 4;
+    gy = ag_cdiv(1024, gx * gz * nw);
+    if (gy * nw > KU) gy = ag_cdiv(KU, nw);
+    if (gy < 2) gy = 2;  // keep the atomic epilogue (C holds the addend)
+  } else {
+    gy = 1;
+    nw = ag_cdiv(2048, gx * gz);
+    if (nw < 4) nw = 4;
+    if (nw > SK_MAXW) nw = SK_MAXW;
+    if (nw > KU) nw = KU;
+  }
+  const size_t lds = (size_t)nw * 1024 * sizeof(float);
+  hipLaunchKernelGGL(skinny_gemm_kernel, dim3(gx, gy, gz), dim3(64 * nw), lds, st, p);
+  AG_CHECK_LAUNCH("ag_skinny_gemm");
+  return AG_OK;
 }
 
 extern "C" int ag_skinny_gemm(const float* A, int lda, const float* B, int ldb, int tb, float* C, int ldc,
@@ -156,40 +159,11 @@ extern "C" int ag_skinny_gemm(const float* A, int lda, const float* B, int ldb, 
   if (tb) AG_REQUIRE(ldb % 4 == 0 && ((uintptr_t)B & 15) == 0, "ag_skinny_gemm: B must be 16-B aligned");
   AG_REQUIRE(!(accumulate_atomic && act != AG_ACT_NONE), "ag_skinny_gemm: atomic mode has a linear epilogue");
   SkinnyP p;
-  p.A = A; p.B = B; p.C = C; p.bias = bias;
+  p.q[0].A = A; p.q[0].B = B; p.q[0].C = C; p.q[0].bias = bias;
+  p.q[1] = p.q[0];
   p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.M = M; p.N = N; p.K = K; p.tb = tb; p.act = act;
   p.slope = slope; p.beta = beta;
-  const int gx = ag_cdiv(N, 32);
-  const int KU = K / 8;
-  int nw, gy;
-  if (accumulate_atomic) {
-    // C already holds the value to add to (beta == 1 semantics); spread K over ~512 waves
-    nw = 4;
-    gy = ag_cdiv(512, gx * nw);
-    if (gy * nw > KU) gy = ag_cdiv(KU, nw);
-    if (gy < 1) gy = 1;
-    if (gy == 1) gy = 2;  // keep the atomic epilogue (C holds the addend)
-  } else {
-    gy = 1;
-    nw = ag_cdiv(1024, gx * 2);  // aim at ~4 waves per CU overall, at least 4 per block
-    if (nw < 4) nw = 4;
-    if (nw > SK_MAXW) nw = SK_MAXW;
-    if (nw > KU) nw = KU;
-  }
-  const int MT = M > 32 ? 2 : 1;
-  const size_t lds = (size_t)nw * MT * 16 * 64 * sizeof(float);
-  hipStream_t st = (hipStream_t)stream;
-  if (MT == 2) {
-    if (lds > 64 * 1024)
-      (void)hipFuncSetAttribute((const void*)skinny_gemm_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(skinny_gemm_kernel<2>, dim3(gx, gy), dim3(64 * nw), lds, st, p);
-  } else {
-    if (lds > 64 * 1024)
-      (void)hipFuncSetAttribute((const void*)skinny_gemm_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(skinny_gemm_kernel<1>, dim3(gx, gy), dim3(64 * nw), lds, st, p);
-  }
-  AG_CHECK_LAUNCH("ag_skinny_gemm");
-  return AG_OK;
+  return launch_skinny(p, 1, accumulate_atomic, (hipStream_t)stream);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -217,7 +191,6 @@ struct LstmStepP {
   int skip_h;          // 1: h_prev is known to be zero (first step) -> skip that product
 };
 
-template <int MT>
 __global__ __launch_bounds__(512) void lstm_step_fwd_kernel(const LstmStepP p) {
   extern __shared__ float red[];
   const LstmDir& D = p.d[blockIdx.y];
@@ -225,15 +198,15 @@ __global__ __launch_bounds__(512) void lstm_step_fwd_kernel(const LstmStepP p) {
   const int l31 = lane & 31, h = lane >> 5;
   const int H = p.H, B = p.B;
   const int u0 = blockIdx.x * 8;
+  const int m0 = blockIdx.z * 32;
   // column j of this workgroup's 32-wide tile = gate (j>>3), hidden unit u0 + (j&7)
   const int unit = u0 + (l31 & 7);
-  const bool bok = unit < H;
+  const bool bok = unit < H, aok = (m0 + l31) < B;
   const int row = (l31 >> 3) * H + (bok ? unit : 0);
-  f32x16 acc[MT];
+  const int arow_i = aok ? m0 + l31 : 0;
+  f32x16 acc;
 #pragma unroll
-  for (int t = 0; t < MT; ++t)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
   // split the concatenated K axis [x | h] over the waves in units of 8
   const int KxU = D.x ? (D.Kx >> 3) : 0;
   const int KhU = p.skip_h ? 0 : (H >> 3);
@@ -241,23 +214,23 @@ __global__ __launch_bounds__(512) void lstm_step_fwd_kernel(const LstmStepP p) {
   const int s0 = (int)((int64_t)KU * wid / nw), s1 = (int)((int64_t)KU * (wid + 1) / nw);
   if (s0 < KxU) {
     const int e1 = s1 < KxU ? s1 : KxU;
-    skinny_core_nt<MT>(acc, D.x, D.ldx, B, D.wx + (int64_t)row * D.ldwx, bok, s0 * 8, e1 * 8, l31, h);
+    skinny_core_nt(acc, D.x + (int64_t)arow_i * D.ldx, aok, D.wx + (int64_t)row * D.ldwx, bok, s0 * 8,
+                   e1 * 8, h);
   }
   if (s1 > KxU) {
     const int b0 = (s0 > KxU ? s0 : KxU) - KxU;
-    skinny_core_nt<MT>(acc, D.h_prev, H, B, D.whh + (int64_t)row * H, bok, b0 * 8, (s1 - KxU) * 8, l31, h);
+    skinny_core_nt(acc, D.h_prev + (int64_t)arow_i * H, aok, D.whh + (int64_t)row * H, bok, b0 * 8,
+                   (s1 - KxU) * 8, h);
   }
-  block_reduce_acc<MT>(acc, red, nw, wid, lane);
+  block_reduce_acc(acc, red, nw, wid, lane);
   // epilogue: (m, unit) pairs; the 4 gates of a pair sit at columns uu, 8+uu, 16+uu, 24+uu
-  const int npair = MT * 32 * 8;
-  for (int q = threadIdx.x; q < npair; q += blockDim.x) {
-    const int uu = q & 7, m = q >> 3;
-    const int u = u0 + uu;
+  for (int q = threadIdx.x; q < 256; q += blockDim.x) {
+    const int uu = q & 7, mm = q >> 3;
+    const int u = u0 + uu, m = m0 + mm;
     if (m >= B || u >= H) continue;
-    const int t = m >> 5, mm = m & 31;
     // inverse of row = (e&3) + 8*(e>>2) + 4*(lane>>5)
     const int hh = (mm >> 2) & 1, e = (mm & 3) + 4 * (mm >> 3);
-    const float* rr = red + (size_t)(t * 16 + e) * 64 + 32 * hh;
+    const float* rr = red + (size_t)e * 64 + 32 * hh;
     float* pre = D.pre + (int64_t)m * 4 * H;
     const float cp = D.c_prev[(int64_t)m * H + u];
     if (p.valid && D.t >= p.valid[m]) {
@@ -284,16 +257,9 @@ __global__ __launch_bounds__(512) void lstm_step_fwd_kernel(const LstmStepP p) {
 
 static int launch_lstm_step(const LstmStepP& p, int ndir, hipStream_t st) {
   const int nw = 8;
-  const int MT = p.B > 32 ? 2 : 1;
-  const size_t lds = (size_t)nw * MT * 16 * 64 * sizeof(float);
-  dim3 grid(ag_cdiv(p.H, 8), ndir);
-  if (MT == 2) {
-    if (lds > 64 * 1024)
-      (void)hipFuncSetAttribute((const void*)lstm_step_fwd_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(lstm_step_fwd_kernel<2>, grid, dim3(64 * nw), lds, st, p);
-  } else {
-    hipLaunchKernelGGL(lstm_step_fwd_kernel<1>, grid, dim3(64 * nw), lds, st, p);
-  }
+  const size_t lds = (size_t)nw * 1024 * sizeof(float);
+  dim3 grid(ag_cdiv(p.H, 8), ndir, ag_cdiv(p.B, 32));
+  hipLaunchKernelGGL(lstm_step_fwd_kernel, grid, dim3(64 * nw), lds, st, p);
   AG_CHECK_LAUNCH("ag_lstm_step_fwd");
   return AG_OK;
 }
@@ -369,9 +335,57 @@ extern "C" int ag_lstm_seq_fwd(float* const* pre, const float* const* whh, float
   return AG_OK;
 }
 
-// Whole layer backward through time: per step one pointwise cell backward per direction and one
-// K-split skinny product  dh_{k-1} += dgates_k * W_hh  (atomics into the buffer that already
-// holds the pass-through term of padded rows).
+// ------------------------------------------------------------------------------------------
+// backward through time
+// ------------------------------------------------------------------------------------------
+struct CellBwdDir {
+  const float* ga;      // activated gates [B,4H]
+  const float* c_prev;  // [B,H]
+  const float* c_new;   // [B,H]
+  const float* dh;      // [B,H] gradient from later steps or NULL
+  const float* dy;      // [B,ldy] slice or NULL
+  const float* dc_next; // [B,H] or NULL
+  float* dgates;        // [B,4H]
+  float* dc_prev;       // [B,H]
+  float* dh_pass;       // [B,H]
+  int ldy, t;
+};
+struct CellBwd2P {
+  CellBwdDir d[2];
+  const int64_t* valid;
+  int B, H;
+};
+
+__global__ __launch_bounds__(256) void lstm_cell_bwd2_kernel(const CellBwd2P p) {
+  const CellBwdDir& D = p.d[blockIdx.z];
+  const int j = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y, H = p.H;
+  if (j >= H) return;
+  float* dg = D.dgates + (int64_t)b * 4 * H;
+  const float dhf = D.dh ? D.dh[(int64_t)b * H + j] : 0.f;
+  const float dcn = D.dc_next ? D.dc_next[(int64_t)b * H + j] : 0.f;
+  if (p.valid && D.t >= p.valid[b]) {
+    dg[j] = 0.f; dg[H + j] = 0.f; dg[2 * H + j] = 0.f; dg[3 * H + j] = 0.f;
+    D.dc_prev[(int64_t)b * H + j] = dcn;
+    D.dh_pass[(int64_t)b * H + j] = dhf;
+    return;
+  }
+  const float dhv = dhf + (D.dy ? D.dy[(int64_t)b * D.ldy + j] : 0.f);
+  const float* gr = D.ga + (int64_t)b * 4 * H;
+  const float ig = gr[j], fg = gr[H + j], gg = gr[2 * H + j], og = gr[3 * H + j];
+  const float cp = D.c_prev[(int64_t)b * H + j];
+  const float tc = tanhf(D.c_new[(int64_t)b * H + j]);
+  const float dc = dcn + dhv * og * (1.f - tc * tc);
+  dg[j] = dc * gg * ig * (1.f - ig);
+  dg[H + j] = dc * cp * fg * (1.f - fg);
+  dg[2 * H + j] = dc * ig * (1.f - gg * gg);
+  dg[3 * H + j] = dhv * tc * og * (1.f - og);
+  D.dc_prev[(int64_t)b * H + j] = dc * fg;
+  D.dh_pass[(int64_t)b * H + j] = 0.f;
+}
+
+// Whole layer backward through time: per step ONE pointwise launch and ONE K-split skinny
+// product  dh_{k-1} += dgates_k * W_hh  (atomics into the buffer that already holds the
+// pass-through term of padded rows); both directions share each launch.
 //   gates [ndir][T,B,4H] activated gates (from forward);  dgates [ndir][T,B,4H] (out)
 //   dy [T,B,ndir*H];  dhbuf/dcbuf [ndir][2][B,H] scratch
 extern "C" int ag_lstm_seq_bwd(const float* const* gates, const float* const* whh,
@@ -381,24 +395,36 @@ extern "C" int ag_lstm_seq_bwd(const float* const* gates, const float* const* wh
   AG_REQUIRE(gates && whh && c_all && dy && dgates && dhbuf && dcbuf, "ag_lstm_seq_bwd: null table");
   AG_REQUIRE(ndir == 1 || ndir == 2, "ag_lstm_seq_bwd: ndir must be 1 or 2");
   AG_REQUIRE(T > 0 && B > 0 && B <= 64 && (4 * H) % 8 == 0, "ag_lstm_seq_bwd: bad shape");
+  hipStream_t st = (hipStream_t)stream;
   const int64_t BH = (int64_t)B * H, BG = (int64_t)B * 4 * H;
   for (int k = T - 1; k >= 0; --k) {
+    CellBwd2P c;
+    c.valid = valid_i64; c.B = B; c.H = H;
+    SkinnyP s;
+    s.lda = 4 * H; s.ldb = H; s.ldc = H; s.M = B; s.N = H; s.K = 4 * H; s.tb = 0; s.act = AG_ACT_NONE;
+    s.slope = 0.f; s.beta = 1.f;
     for (int d = 0; d < ndir; ++d) {
       const int t = d == 0 ? k : T - 1 - k;
-      const float* dh = (k == T - 1) ? nullptr : dhbuf[d] + (k & 1) * BH;
-      const float* dcn = (k == T - 1) ? nullptr : dcbuf[d] + ((k + 1) & 1) * BH;
-      float* dpass = dhbuf[d] + ((k + 1) & 1) * BH;
-      float* dg = dgates[d] + (int64_t)t * BG;
-      int rc = ag_lstm_cell_bwd(gates[d] + (int64_t)t * BG, 4 * H, c_all[d] + (int64_t)k * BH, H,
-                                c_all[d] + (int64_t)(k + 1) * BH, H, dh, H,
-                                dy + (int64_t)t * B * ndir * H + (int64_t)d * H, ndir * H, dcn, H, dg, 4 * H,
-                                dcbuf[d] + (k & 1) * BH, H, dpass, H, valid_i64, t, B, H, stream);
+      CellBwdDir& D = c.d[d];
+      D.ga = gates[d] + (int64_t)t * BG;
+      D.c_prev = c_all[d] + (int64_t)k * BH;
+      D.c_new = c_all[d] + (int64_t)(k + 1) * BH;
+      D.dh = (k == T - 1) ? nullptr : dhbuf[d] + (k & 1) * BH;
+      D.dy = dy + (int64_t)t * B * ndir * H + (int64_t)d * H;
+      D.ldy = ndir * H;
+      D.dc_next = (k == T - 1) ? nullptr : dcbuf[d] + ((k + 1) & 1) * BH;
+      D.dgates = dgates[d] + (int64_t)t * BG;
+      D.dc_prev = dcbuf[d] + (k & 1) * BH;
+      D.dh_pass = dhbuf[d] + ((k + 1) & 1) * BH;
+      D.t = t;
+      s.q[d].A = D.dgates; s.q[d].B = whh[d]; s.q[d].C = D.dh_pass; s.q[d].bias = nullptr;
+    }
+    if (ndir == 1) { c.d[1] = c.d[0]; s.q[1] = s.q[0]; }
+    hipLaunchKernelGGL(lstm_cell_bwd2_kernel, dim3(ag_cdiv(H, 256), B, ndir), dim3(256), 0, st, c);
+    AG_CHECK_LAUNCH("ag_lstm_seq_bwd(cell)");
+    if (k > 0) {
+      int rc = launch_skinny(s, ndir, 1, st);
       if (rc != AG_OK) return rc;
-      if (k > 0) {
-        rc = ag_skinny_gemm(dg, 4 * H, whh[d], H, 0, dpass, H, B, H, 4 * H, 1.f, nullptr, AG_ACT_NONE, 0.f,
-                            1, stream);
-        if (rc != AG_OK) return rc;
-      }
     }
   }
   return AG_OK;

@@ -298,7 +298,7 @@ extern "C" int ag_axpby(const float* x, float* y, int64_t n, float a, float b, v
 // fused optimiser (audiogan.py:232-253 check_grad/clip_grad, :693-694 RMSprop;
 // computation_graph.py:58-59 Adam).  grid.y = tensor, grid.x = chunk.
 // ------------------------------------------------------------------------------------------
-#define OPT_CHUNKS 32
+#define OPT_CHUNKS 256
 
 __global__ __launch_bounds__(256) void grad_norms_kernel(const ag_opt_desc* __restrict__ descs,
                                                          float* __restrict__ sq, int32_t* __restrict__ flags,
@@ -356,6 +356,7 @@ __global__ __launch_bounds__(256) void opt_step_kernel(const ag_opt_desc* __rest
                                                        float eps, float bc1, float bc2sqrt) {
   const ag_opt_desc d = descs[blockIdx.y];
   const float nr = norms[blockIdx.y];
+  if ((int64_t)blockIdx.x * 256 >= d.n) return;
   const bool do_clip = clip > 0.f && nr > clip;
   const float div = do_clip ? nr / clip : 1.f;  // reference: grad /= (norm / clip), audiogan.py:252
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < d.n; i += (int64_t)gridDim.x * 256) {

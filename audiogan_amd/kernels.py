@@ -373,7 +373,7 @@ def _work_gemm(A, B, Cm, ta=False, tb=False, *a_, **kw):
     M, N = Cm.shape
     Kd = A.size(0) if ta else A.size(1)
     big = _cdiv(M, 128) * _cdiv(N, 128)
-    tile = '2,2,2,2' if (M > 64 and N > 64 and big >= 192) else '1,1,2,2'
+    tile = '2,2,2,2' if (M > 64 and N > 64 and (big >= 192 or Kd >= 2048)) else '1,1,2,2'
     key = 'gemm_kernel<%s,%d,%d>' % (tile, int(ta), int(tb))
     return key, 2.0 * M * N * Kd, 4.0 * (M * Kd + N * Kd + M * N)
 
@@ -523,14 +523,14 @@ def lstm_seq_bwd(gates, whh, c_all, dy, dgates, dhbuf, dcbuf, valid):
 
 def _work_skinny(A, B, Cm, tb=False, *a_, **kw):
     M, N = Cm.shape
-    return 'skinny_gemm_kernel<%d>' % (2 if M > 32 else 1), 2.0 * M * N * A.size(1), \
+    return 'skinny_gemm_kernel', 2.0 * M * N * A.size(1), \
         4.0 * (A.numel() + N * A.size(1) + M * N)
 
 
 def _work_step(gates_pre, x, wx, h_prev, whh, *a_, **kw):
     B, H4 = gates_pre.shape
     Kd = H4 // 4 + (x.size(1) if x is not None else 0)
-    return 'lstm_step_fwd_kernel<%d>' % (2 if B > 32 else 1), 2.0 * B * H4 * Kd, 4.0 * (H4 * Kd + 3 * B * H4)
+    return 'lstm_step_fwd_kernel', 2.0 * B * H4 * Kd, 4.0 * (H4 * Kd + 3 * B * H4)
 
 
 def _work_seq(pre, whh, *a_, **kw):

@@ -107,10 +107,12 @@ class GTrunkFn(torch.autograd.Function):
         assert trunk.group._key == ctx.key, 'parameters changed between forward and backward'
         B, ctot, L = slab.shape
         dy = dy.contiguous().view(B, 1, L)
-        dws = _zeros_like_list([it['v'] for it in trunk.group.items])
+        wg = any(ctx.needs_input_grad[2:])
+        dws = _zeros_like_list([it['v'] for it in trunk.group.items]) if wg else None
         dslab = torch.empty_like(slab)
         # final conv (no activation)
-        conv_wgrad(trunk.final, slab, dy, dws[-2], dws[-1])
+        if wg:
+            conv_wgrad(trunk.final, slab, dy, dws[-2], dws[-1])
         conv_bwd_data(trunk.final, prep[-2], dy, dslab, accumulate=False)
         cin = ctot
         for i in reversed(range(len(trunk.bottlenecks))):
@@ -122,13 +124,15 @@ class GTrunkFn(torch.autograd.Function):
             add = dslab[:, cin - ds.cout:cin] if cin >= ds.cout else None
             K.leaky_bwd(dout, out_v, dout, add_into=add)          # dout now holds d(pre-activation)
             hid = hids[i]
-            conv_wgrad(ds, hid, dout, dws[4 * i + 2], dws[4 * i + 3])
+            if wg:
+                conv_wgrad(ds, hid, dout, dws[4 * i + 2], dws[4 * i + 3])
             dhid = torch.empty_like(hid)
             conv_bwd_data(ds, qw, dout, dhid)
             K.leaky_bwd(dhid, hid, dhid)
-            conv_wgrad(cs, slab[:, :cin], dhid, dws[4 * i], dws[4 * i + 1])
+            if wg:
+                conv_wgrad(cs, slab[:, :cin], dhid, dws[4 * i], dws[4 * i + 1])
             conv_bwd_data(cs, pw, dhid, dslab[:, :cin], accumulate=True)
-        grads = trunk.group.backward(dws)
+        grads = trunk.group.backward(dws) if wg else [None] * (2 * len(trunk.group.items))
         dx0 = dslab[:, 0, :].contiguous() if ctx.needs_input_grad[0] else None
         return (dx0, None) + tuple(grads)
 
@@ -169,7 +173,8 @@ class DConvStackFn(torch.autograd.Function):
         prep = stack.group.prepare()
         assert stack.group._key == ctx.key, 'parameters changed between forward and backward'
         B, L = x.shape
-        dws = _zeros_like_list([it['v'] for it in stack.group.items])
+        wg = any(ctx.needs_input_grad[3:])
+        dws = _zeros_like_list([it['v'] for it in stack.group.items]) if wg else None
         n = len(stack.specs)
         d = None
         for i in reversed(range(n)):
@@ -183,14 +188,15 @@ class DConvStackFn(torch.autograd.Function):
                 K.axpby(g.contiguous(), d, 1.0, 1.0)
             K.leaky_bwd(d, acts[i], d, lens=ctx.lens_list[i])
             xin = acts[i - 1] if i > 0 else x.contiguous().view(B, 1, L)
-            conv_wgrad(sp, xin, d, dws[2 * i], dws[2 * i + 1])
+            if wg:
+                conv_wgrad(sp, xin, d, dws[2 * i], dws[2 * i + 1])
             if i > 0 or ctx.needs_input_grad[0]:
                 dx = torch.empty_like(xin)
                 conv_bwd_data(sp, prep[2 * i], d, dx)
                 d = dx
             else:
                 d = None
-        grads = stack.group.backward(dws)
+        grads = stack.group.backward(dws) if wg else [None] * (2 * len(stack.group.items))
         dx0 = d.view(B, L) if (ctx.needs_input_grad[0] and d is not None) else None
         return (dx0, None, None) + tuple(grads)
 
@@ -238,28 +244,32 @@ class DHeadFn(torch.autograd.Function):
         hmid = saved[-1]
         acts = saved[:-1]          # acts[0] = input rows, acts[i] = output of residual i
         nr = head.n_res
-        dws = _zeros_like_list([it['v'] for it in head.group.items])
+        wg = any(ctx.needs_input_grad[2:])
+        dws = _zeros_like_list([it['v'] for it in head.group.items]) if wg else None
         dout = dout.contiguous()
         w0, w1 = prep[2 * nr].w, prep[2 * nr + 2].w
         # classifier[2]: out = hmid @ w1^T + b1
-        K.gemm(dout, hmid, dws[2 * nr + 2], ta=True)
-        K.col_sum(dout, dws[2 * nr + 3])
+        if wg:
+            K.gemm(dout, hmid, dws[2 * nr + 2], ta=True)
+            K.col_sum(dout, dws[2 * nr + 3])
         dh = torch.empty_like(hmid)
         K.gemm(dout, w1, dh)
         K.act_bwd(dh, hmid, dh, ACT_LEAKY)
         # classifier[0]
-        K.gemm(dh, acts[nr], dws[2 * nr], ta=True)
-        K.col_sum(dh, dws[2 * nr + 1])
+        if wg:
+            K.gemm(dh, acts[nr], dws[2 * nr], ta=True)
+            K.col_sum(dh, dws[2 * nr + 1])
         da = torch.empty_like(acts[nr])
         K.gemm(dh, w0, da)
         for i in reversed(range(nr)):
             K.act_bwd(da, acts[i + 1], da, ACT_LEAKY)      # da = d(pre-activation)
-            K.gemm(da, acts[i], dws[2 * i], ta=True)
-            K.col_sum(da, dws[2 * i + 1])
+            if wg:
+                K.gemm(da, acts[i], dws[2 * i], ta=True)
+                K.col_sum(da, dws[2 * i + 1])
             dprev = torch.empty_like(acts[i])
             K.gemm(da, prep[2 * i].w, dprev, res=da)       # W^T da + da (skip connection)
             da = dprev
-        grads = head.group.backward(dws)
+        grads = head.group.backward(dws) if wg else [None] * (2 * len(head.group.items))
         return (da if ctx.needs_input_grad[0] else None, None) + tuple(grads)
 
 

@@ -107,9 +107,14 @@ class LSTMSeqFn(torch.autograd.Function):
                         K.gemm(dg[t], whh[d], dpass, beta=1.0)
         dx2 = torch.empty(T * B, F, device=dev)
         outs = []
+        wg = any(ctx.needs_input_grad[3:])
         for d in range(ndir):
             w_ih, w_hh = w[4 * d], w[4 * d + 1]
             dg2 = dgs[d].view(T * B, 4 * H)
+            if not wg:
+                K.gemm(dg2, w_ih, dx2, beta=0.0 if d == 0 else 1.0)
+                outs += [None, None, None, None]
+                continue
             dw_ih = torch.empty_like(w_ih)
             K.gemm(dg2, x2, dw_ih, ta=True)
             # h_prev of processing step k is the layer output of step k-1 (zero at padded steps,
