@@ -72,8 +72,8 @@ SIGNATURES = {
     'ag_act_fwd': (C.c_int, [vp, vp, i64, C.c_int, f32, vp]),
     'ag_act_bwd': (C.c_int, [vp, vp, vp, i64, C.c_int, f32, vp]),
     'ag_axpby': (C.c_int, [vp, vp, i64, f32, f32, vp]),
-    'ag_grad_norms': (C.c_int, [vp, C.c_int, vp, vp, vp, f32, vp]),
-    'ag_opt_step': (C.c_int, [vp, C.c_int, vp, C.c_int, f32, f32, f32, f32, f32, f32, C.c_int, vp]),
+    'ag_grad_norms': (C.c_int, [vp, C.c_int, vp, vp, vp, f32, vp, vp]),
+    'ag_opt_step': (C.c_int, [vp, C.c_int, vp, C.c_int, f32, f32, f32, f32, f32, f32, C.c_int, vp, vp]),
 }
 
 

@@ -320,7 +320,8 @@ __global__ __launch_bounds__(256) void grad_norms_kernel(const ag_opt_desc* __re
 }
 
 __global__ void grad_norms_finish_kernel(float* __restrict__ sq_to_norm, float* __restrict__ norm_sum,
-                                         int n) {
+                                         int n, int32_t* __restrict__ step_dev) {
+  if (threadIdx.x == 0 && step_dev) step_dev[0] += 1;
   // single block: norms[i] = sqrt(sq[i]); norm_sum = sum_i norms[i] (deterministic order)
   __shared__ float red[17];
   float s = 0.f;
@@ -334,7 +335,7 @@ __global__ void grad_norms_finish_kernel(float* __restrict__ sq_to_norm, float* 
 }
 
 extern "C" int ag_grad_norms(const ag_opt_desc* descs_dev, int n, float* norms, float* norm_sum,
-                             int32_t* flags, float grad_scale, void* stream) {
+                             int32_t* flags, float grad_scale, int32_t* step_dev, void* stream) {
   AG_REQUIRE(descs_dev && norms && n > 0 && n <= 65535, "ag_grad_norms: bad args");
   hipStream_t st = (hipStream_t)stream;
   if (hipMemsetAsync(norms, 0, sizeof(float) * n, st) != hipSuccess) {
@@ -345,7 +346,7 @@ extern "C" int ag_grad_norms(const ag_opt_desc* descs_dev, int n, float* norms, 
   hipLaunchKernelGGL(grad_norms_kernel, dim3(OPT_CHUNKS, n), dim3(256), 0, st, descs_dev, norms, flags,
                      grad_scale);
   AG_CHECK_LAUNCH("ag_grad_norms");
-  hipLaunchKernelGGL(grad_norms_finish_kernel, dim3(1), dim3(256), 0, st, norms, norm_sum, n);
+  hipLaunchKernelGGL(grad_norms_finish_kernel, dim3(1), dim3(256), 0, st, norms, norm_sum, n, step_dev);
   AG_CHECK_LAUNCH("ag_grad_norms(finish)");
   return AG_OK;
 }
@@ -353,8 +354,14 @@ extern "C" int ag_grad_norms(const ag_opt_desc* descs_dev, int n, float* norms, 
 __global__ __launch_bounds__(256) void opt_step_kernel(const ag_opt_desc* __restrict__ descs,
                                                        const float* __restrict__ norms, int kind, float lr,
                                                        float clip, float gscale, float a1, float b2,
-                                                       float eps, float bc1, float bc2sqrt) {
+                                                       float eps, float bc1, float bc2sqrt,
+                                                       const int32_t* __restrict__ step_dev) {
   const ag_opt_desc d = descs[blockIdx.y];
+  if (step_dev && kind == AG_OPT_ADAM) {
+    const float st = (float)step_dev[0];
+    bc1 = 1.f - powf(a1, st);
+    bc2sqrt = sqrtf(1.f - powf(b2, st));
+  }
   const float nr = norms[blockIdx.y];
   if ((int64_t)blockIdx.x * 256 >= d.n) return;
   const bool do_clip = clip > 0.f && nr > clip;
@@ -379,17 +386,17 @@ __global__ __launch_bounds__(256) void opt_step_kernel(const ag_opt_desc* __rest
 
 extern "C" int ag_opt_step(const ag_opt_desc* descs_dev, int n, const float* norms, int kind, float lr,
                            float clip, float grad_scale, float alpha_or_beta1, float beta2, float eps,
-                           int step, void* stream) {
+                           int step, const int32_t* step_dev, void* stream) {
   AG_REQUIRE(descs_dev && norms && n > 0 && n <= 65535, "ag_opt_step: bad args");
   AG_REQUIRE(kind == AG_OPT_RMSPROP || kind == AG_OPT_ADAM, "ag_opt_step: bad optimiser kind");
   float bc1 = 1.f, bc2s = 1.f;
-  if (kind == AG_OPT_ADAM) {
+  if (kind == AG_OPT_ADAM && !step_dev) {
     AG_REQUIRE(step >= 1, "ag_opt_step: Adam step must be >= 1");
     bc1 = (float)(1.0 - pow((double)alpha_or_beta1, (double)step));
     bc2s = (float)sqrt(1.0 - pow((double)beta2, (double)step));
   }
   hipLaunchKernelGGL(opt_step_kernel, dim3(OPT_CHUNKS, n), dim3(256), 0, (hipStream_t)stream, descs_dev,
-                     norms, kind, lr, clip, grad_scale, alpha_or_beta1, beta2, eps, bc1, bc2s);
+                     norms, kind, lr, clip, grad_scale, alpha_or_beta1, beta2, eps, bc1, bc2s, step_dev);
   AG_CHECK_LAUNCH("ag_opt_step");
   return AG_OK;
 }

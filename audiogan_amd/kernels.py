@@ -66,11 +66,42 @@ def _table(kind, structs, device):
     key = (kind, raw, str(device))
     t = _table_cache.get(key)
     if t is None:
-        if len(_table_cache) > 512:
+        if len(_table_cache) > 4096:
             _table_cache.clear()
-        t = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
-        _table_cache[key] = t
-    return t
+        src = torch.frombuffer(bytearray(raw), dtype=torch.uint8)
+        if torch.device(device).type == 'cuda':
+            # staged through a pre-allocated pinned arena + async copy: legal inside hipGraph
+            # capture (the copy becomes a graph node that re-reads the arena slot on replay, so
+            # slots are never recycled)
+            host = _pinned_slot(len(raw))
+            host.copy_(src)
+            t = torch.empty(len(raw), dtype=torch.uint8, device=device)
+            t.copy_(host, non_blocking=True)
+        else:
+            host, t = src, src.to(device)
+        _table_cache[key] = (t, host)
+        return t
+    return t[0]
+
+
+_arena = {'buf': None, 'off': 0}
+
+
+def _pinned_slot(n):
+    n = (n + 63) // 64 * 64
+    a = _arena
+    if a['buf'] is None or a['off'] + n > a['buf'].numel():
+        a['buf'] = torch.empty(max(4 << 20, n), dtype=torch.uint8).pin_memory()
+        a['off'] = 0
+    s = a['buf'][a['off']:a['off'] + n]
+    a['off'] += n
+    return s[:n]
+
+
+def reserve_table_arena():
+    """allocate the pinned staging arena now (call before hipGraph capture)"""
+    if _arena['buf'] is None:
+        _pinned_slot(64)
 
 
 # ------------------------------------------------------------------------------------
@@ -322,19 +353,21 @@ def _opt_table(params, grads, s1, s2):
     return _table('opt', descs, params[0].device)
 
 
-def grad_norms(params, grads, s1, s2, norms, norm_sum, flags, grad_scale=1.0):
+def grad_norms(params, grads, s1, s2, norms, norm_sum, flags, grad_scale=1.0, step_dev=None):
     """norms[i] = ||grads[i]*grad_scale||; norm_sum[0] = sum_i norms[i]; flags |= NaN/BIG bits"""
     tab = _opt_table(params, grads, s1, s2)
     _chk(norms, 'norms'); _chk(norm_sum, 'norm_sum'); _chk(flags, 'flags', torch.int32)
     assert norms.numel() >= len(params)
+    _chk(step_dev, 'step_dev', torch.int32)
     check(lib.ag_grad_norms(_p(tab), len(params), _p(norms), _p(norm_sum), _p(flags), grad_scale,
-                            _stream()), 'ag_grad_norms')
+                            _p(step_dev), _stream()), 'ag_grad_norms')
 
 
-def opt_step(params, grads, s1, s2, norms, kind, lr, clip, grad_scale, a1, b2, eps, step):
+def opt_step(params, grads, s1, s2, norms, kind, lr, clip, grad_scale, a1, b2, eps, step, step_dev=None):
     tab = _opt_table(params, grads, s1, s2)
+    _chk(step_dev, 'step_dev', torch.int32)
     check(lib.ag_opt_step(_p(tab), len(params), _p(norms), kind, lr, clip, grad_scale, a1, b2, eps,
-                          step, _stream()), 'ag_opt_step')
+                          step, _p(step_dev), _stream()), 'ag_opt_step')
 
 
 # ------------------------------------------------------------------------------------

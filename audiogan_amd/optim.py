@@ -36,7 +36,8 @@ class _Fused(object):
         self._state = dict(s1=s1, s2=s2 if flat2 is not None else None,
                            norms=torch.zeros(len(self.params), device=dev),
                            norm_sum=torch.zeros(1, device=dev),
-                           flags=torch.zeros(1, dtype=torch.int32, device=dev))
+                           flags=torch.zeros(1, dtype=torch.int32, device=dev),
+                           step=torch.full((1,), self.step_count, dtype=torch.int32, device=dev))
 
     def zero_grad(self):
         """keeps .grad allocated (stable pointers -> cached descriptor tables)"""
@@ -50,6 +51,7 @@ class _Fused(object):
 
     def state_dict(self):
         self._ensure()
+        self.step_count = int(self._state['step'].item())
         return dict(step=self.step_count, lr=self.lr,
                     s1=[t.clone() for t in self._state['s1']],
                     s2=[t.clone() for t in self._state['s2']] if self._state['s2'] else None)
@@ -57,6 +59,7 @@ class _Fused(object):
     def load_state_dict(self, sd):
         self._ensure()
         self.step_count, self.lr = sd['step'], sd['lr']
+        self._state['step'].fill_(self.step_count)
         for a, b in zip(self._state['s1'], sd['s1']):
             a.copy_(b)
         if self._state['s2']:
@@ -83,7 +86,7 @@ class _Fused(object):
         s1 = [l[2] for l in live]
         s2 = [l[3] for l in live] if st['s2'] else None
         self.step_count += 1
-        K.grad_norms(ps, gs, s1, s2, st['norms'], st['norm_sum'], st['flags'], grad_scale)
+        K.grad_norms(ps, gs, s1, s2, st['norms'], st['norm_sum'], st['flags'], grad_scale, st['step'])
         if check:
             f = int(st['flags'].item())
             assert not (f & 1), 'NaN in gradients (check_grad)'
@@ -104,7 +107,7 @@ class RMSprop(_Fused):
 
     def _launch(self, ps, gs, s1, s2, norms, clip, gscale):
         K.opt_step(ps, gs, s1, None, norms, K.OPT_RMSPROP, self.lr, float(clip), float(gscale),
-                   self.alpha, 0.0, self.eps, self.step_count)
+                   self.alpha, 0.0, self.eps, self.step_count, self._state['step'])
 
 
 class Adam(_Fused):
@@ -117,7 +120,7 @@ class Adam(_Fused):
 
     def _launch(self, ps, gs, s1, s2, norms, clip, gscale):
         K.opt_step(ps, gs, s1, s2, norms, K.OPT_ADAM, self.lr, float(clip), float(gscale),
-                   self.betas[0], self.betas[1], self.eps, self.step_count)
+                   self.betas[0], self.betas[1], self.eps, self.step_count, self._state['step'])
 
 
 def make_optimizer(params, kind, lr):

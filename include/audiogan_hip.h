@@ -252,11 +252,14 @@ typedef struct ag_opt_desc {
 #define AG_FLAG_NAN 1
 #define AG_FLAG_BIG 2
 
+/* step_dev (optional): device-side optimiser step counter, incremented by ag_grad_norms and
+ * read by ag_opt_step for Adam's bias correction, so a captured hipGraph of the train step
+ * advances it on every replay.  When NULL the host value `step` is used. */
 int ag_grad_norms(const ag_opt_desc* descs_dev, int n, float* norms, float* norm_sum,
-                  int32_t* flags, float grad_scale, void* stream);
+                  int32_t* flags, float grad_scale, int32_t* step_dev, void* stream);
 int ag_opt_step(const ag_opt_desc* descs_dev, int n, const float* norms, int kind, float lr,
                 float clip, float grad_scale, float alpha_or_beta1, float beta2, float eps, int step,
-                void* stream);
+                const int32_t* step_dev, void* stream);
 
 #ifdef __cplusplus
 }

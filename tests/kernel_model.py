@@ -232,7 +232,9 @@ def axpby(x, y, a, b):
     y.copy_(a * x + (b * y if b != 0.0 else 0.0))
 
 
-def grad_norms(params, grads, s1, s2, norms, norm_sum, flags, grad_scale=1.0):
+def grad_norms(params, grads, s1, s2, norms, norm_sum, flags, grad_scale=1.0, step_dev=None):
+    if step_dev is not None:
+        step_dev.add_(1)
     f = 0
     tot = 0.0
     for i, g in enumerate(grads):
@@ -250,7 +252,9 @@ def grad_norms(params, grads, s1, s2, norms, norm_sum, flags, grad_scale=1.0):
         flags.fill_(f)
 
 
-def opt_step(params, grads, s1, s2, norms, kind, lr, clip, grad_scale, a1, b2, eps, step):
+def opt_step(params, grads, s1, s2, norms, kind, lr, clip, grad_scale, a1, b2, eps, step, step_dev=None):
+    if step_dev is not None:
+        step = int(step_dev.item())
     for i, p in enumerate(params):
         g = grads[i].reshape(-1) * grad_scale
         n = norms[i]
