@@ -297,21 +297,21 @@ extern "C" int ag_lstm_step_fwd(float* gates_pre, const float* x, int ldx, const
 //   y     [T,B,ndir*H] layer output.  Direction 1 runs the sequence in reverse.
 extern "C" int ag_lstm_seq_fwd(float* const* pre, const float* const* whh, float* const* c_all,
                                float* const* hbuf, float* y, const int64_t* valid_i64, int T, int B, int H,
-                               int ndir, void* stream) {
+                               int ndir, int k_begin, int k_end, void* stream) {
   AG_REQUIRE(pre && whh && c_all && hbuf && y, "ag_lstm_seq_fwd: null table");
   AG_REQUIRE(ndir == 1 || ndir == 2, "ag_lstm_seq_fwd: ndir must be 1 or 2");
-  AG_REQUIRE(T > 0, "ag_lstm_seq_fwd: empty sequence");
+  AG_REQUIRE(T > 0 && 0 <= k_begin && k_begin <= k_end && k_end <= T, "ag_lstm_seq_fwd: bad step range");
   for (int d = 0; d < ndir; ++d)
     AG_REQUIRE(step_ok(B, H, 0, 0, 0, nullptr, nullptr, whh[d], hbuf[d]),
                "ag_lstm_seq_fwd: needs B<=64, H%%8==0 and 16-B aligned buffers");
   hipStream_t st = (hipStream_t)stream;
   const int64_t BH = (int64_t)B * H;
-  for (int d = 0; d < ndir; ++d)
+  for (int d = 0; d < ndir && k_begin == 0; ++d)
     if (hipMemsetAsync(hbuf[d], 0, sizeof(float) * BH, st) != hipSuccess) {
       ag_set_error("ag_lstm_seq_fwd: memset failed");
       return AG_ERR_LAUNCH;
     }
-  for (int k = 0; k < T; ++k) {
+  for (int k = k_begin; k < k_end; ++k) {
     LstmStepP p;
     p.valid = valid_i64; p.B = B; p.H = H; p.skip_h = (k == 0);
     for (int d = 0; d < ndir; ++d) {
@@ -391,13 +391,14 @@ __global__ __launch_bounds__(256) void lstm_cell_bwd2_kernel(const CellBwd2P p) 
 extern "C" int ag_lstm_seq_bwd(const float* const* gates, const float* const* whh,
                                const float* const* c_all, const float* dy, float* const* dgates,
                                float* const* dhbuf, float* const* dcbuf, const int64_t* valid_i64, int T,
-                               int B, int H, int ndir, void* stream) {
+                               int B, int H, int ndir, int k_begin, int k_end, void* stream) {
   AG_REQUIRE(gates && whh && c_all && dy && dgates && dhbuf && dcbuf, "ag_lstm_seq_bwd: null table");
   AG_REQUIRE(ndir == 1 || ndir == 2, "ag_lstm_seq_bwd: ndir must be 1 or 2");
   AG_REQUIRE(T > 0 && B > 0 && B <= 64 && (4 * H) % 8 == 0, "ag_lstm_seq_bwd: bad shape");
+  AG_REQUIRE(0 <= k_begin && k_begin <= k_end && k_end <= T, "ag_lstm_seq_bwd: bad step range");
   hipStream_t st = (hipStream_t)stream;
   const int64_t BH = (int64_t)B * H, BG = (int64_t)B * 4 * H;
-  for (int k = T - 1; k >= 0; --k) {
+  for (int k = k_end - 1; k >= k_begin; --k) {
     CellBwd2P c;
     c.valid = valid_i64; c.B = B; c.H = H;
     SkinnyP s;

@@ -87,15 +87,15 @@ def _table(kind, structs, device):
 _arena = {'buf': None, 'off': 0}
 
 
-def _pinned_slot(n):
-    n = (n + 63) // 64 * 64
+def _pinned_slot(nbytes):
+    n = (nbytes + 63) // 64 * 64
     a = _arena
     if a['buf'] is None or a['off'] + n > a['buf'].numel():
         a['buf'] = torch.empty(max(4 << 20, n), dtype=torch.uint8).pin_memory()
         a['off'] = 0
     s = a['buf'][a['off']:a['off'] + n]
     a['off'] += n
-    return s[:n]
+    return s[:nbytes]
 
 
 def reserve_table_arena():
@@ -524,6 +524,15 @@ def _ptr_table(tensors):
 
 def lstm_seq_fwd(pre, whh, c_all, hbuf, y, valid):
     """pre/whh/c_all/hbuf: lists (one per direction) of contiguous tensors; see ag_lstm_seq_fwd"""
+    T = pre[0].size(0)
+    if Profiler.enabled:      # one call per step so that every launch can be timed on its own
+        for k_ in range(T):
+            _lstm_seq_fwd_range(pre, whh, c_all, hbuf, y, valid, k_, k_ + 1)
+    else:
+        _lstm_seq_fwd_range(pre, whh, c_all, hbuf, y, valid, 0, T)
+
+
+def _lstm_seq_fwd_range(pre, whh, c_all, hbuf, y, valid, k0, k1):
     ndir = len(pre)
     T, B, H4 = pre[0].shape
     H = H4 // 4
@@ -535,10 +544,19 @@ def lstm_seq_fwd(pre, whh, c_all, hbuf, y, valid):
     _chk(y, 'y'); _chk(valid, 'valid', torch.int64)
     assert y.is_contiguous() and tuple(y.shape) == (T, B, ndir * H)
     check(lib.ag_lstm_seq_fwd(_ptr_table(pre), _ptr_table(whh), _ptr_table(c_all), _ptr_table(hbuf), _p(y),
-                              _p(valid), T, B, H, ndir, _stream()), 'ag_lstm_seq_fwd')
+                              _p(valid), T, B, H, ndir, k0, k1, _stream()), 'ag_lstm_seq_fwd')
 
 
 def lstm_seq_bwd(gates, whh, c_all, dy, dgates, dhbuf, dcbuf, valid):
+    T = gates[0].size(0)
+    if Profiler.enabled:
+        for k_ in reversed(range(T)):
+            _lstm_seq_bwd_range(gates, whh, c_all, dy, dgates, dhbuf, dcbuf, valid, k_, k_ + 1)
+    else:
+        _lstm_seq_bwd_range(gates, whh, c_all, dy, dgates, dhbuf, dcbuf, valid, 0, T)
+
+
+def _lstm_seq_bwd_range(gates, whh, c_all, dy, dgates, dhbuf, dcbuf, valid, k0, k1):
     ndir = len(gates)
     T, B, H4 = gates[0].shape
     H = H4 // 4
@@ -551,7 +569,7 @@ def lstm_seq_bwd(gates, whh, c_all, dy, dgates, dhbuf, dcbuf, valid):
     assert dy.is_contiguous() and tuple(dy.shape) == (T, B, ndir * H)
     check(lib.ag_lstm_seq_bwd(_ptr_table(gates), _ptr_table(whh), _ptr_table(c_all), _p(dy),
                               _ptr_table(dgates), _ptr_table(dhbuf), _ptr_table(dcbuf), _p(valid), T, B, H,
-                              ndir, _stream()), 'ag_lstm_seq_bwd')
+                              ndir, k0, k1, _stream()), 'ag_lstm_seq_bwd')
 
 
 def _work_skinny(A, B, Cm, tb=False, *a_, **kw):
@@ -566,13 +584,19 @@ def _work_step(gates_pre, x, wx, h_prev, whh, *a_, **kw):
     return 'lstm_step_fwd_kernel', 2.0 * B * H4 * Kd, 4.0 * (H4 * Kd + 3 * B * H4)
 
 
-def _work_seq(pre, whh, *a_, **kw):
+def _work_seq_fwd(pre, whh, *a_, **kw):
     T, B, H4 = pre[0].shape
     nd = len(pre)
-    return 'lstm_seq(%d dir x %d steps)' % (nd, T), 2.0 * nd * T * B * H4 * (H4 // 4), \
-        4.0 * nd * T * (H4 * (H4 // 4) + 3 * B * H4)
+    return 'lstm_step_fwd_kernel', 2.0 * nd * B * H4 * (H4 // 4), 4.0 * nd * (H4 * (H4 // 4) + 3 * B * H4)
 
 
-for _n, _w in (('skinny_gemm', _work_skinny), ('lstm_step_fwd', _work_step), ('lstm_seq_fwd', _work_seq),
-               ('lstm_seq_bwd', _work_seq)):
+def _work_seq_bwd(gates, whh, *a_, **kw):
+    T, B, H4 = gates[0].shape
+    nd = len(gates)
+    return 'lstm_cell_bwd2_kernel + skinny_gemm_kernel (one step)', 2.0 * nd * B * H4 * (H4 // 4), \
+        4.0 * nd * (H4 * (H4 // 4) + 4 * B * H4)
+
+
+for _n, _w in (('skinny_gemm', _work_skinny), ('lstm_step_fwd', _work_step),
+               ('_lstm_seq_fwd_range', _work_seq_fwd), ('_lstm_seq_bwd_range', _work_seq_bwd)):
     _instrument(_n, _w)

@@ -197,13 +197,16 @@ int ag_lstm_step_fwd(float* gates_pre, const float* x, int ldx, const float* wx,
  * call.  Tables are HOST arrays of device pointers, one entry per direction.
  *   pre[d]   [T,B,4H] x-projection + biases; overwritten with the activated gates
  *   whh[d]   [4H,H];  c_all[d] [T+1,B,H] with c_all[d][0] = 0;  hbuf[d] [2,B,H] scratch
- *   y        [T,B,ndir*H]; direction 1 walks the sequence backwards */
+ *   y        [T,B,ndir*H]; direction 1 walks the sequence backwards
+ * Processing steps [k_begin, k_end) are enqueued (0, T for the whole layer; the state buffers
+ * carry over between calls, forward in increasing and backward in decreasing step order). */
 int ag_lstm_seq_fwd(float* const* pre, const float* const* whh, float* const* c_all,
                     float* const* hbuf, float* y, const int64_t* valid_i64, int T, int B, int H,
-                    int ndir, void* stream);
+                    int ndir, int k_begin, int k_end, void* stream);
 int ag_lstm_seq_bwd(const float* const* gates, const float* const* whh, const float* const* c_all,
                     const float* dy, float* const* dgates, float* const* dhbuf, float* const* dcbuf,
-                    const int64_t* valid_i64, int T, int B, int H, int ndir, void* stream);
+                    const int64_t* valid_i64, int T, int B, int H, int ndir, int k_begin, int k_end,
+                    void* stream);
 
 /* ---------------------------------------------------------------------------
  * Masked BCE-with-logits per sample (audiogan.py:187-197 + :204-211 + the
