@@ -38,11 +38,19 @@ struct ConvP {
   int tapoff[MAX_TAPS];
 };
 
-template <int TILES_O, int TILES_T, int WAVES_O, int WAVES_T>
+// under-aligned vector types: mode-1 outputs start at u = s*n + r - pad, which is only
+// guaranteed to be 4-byte aligned (gfx950 global accesses need dword alignment only)
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
+
+// TAPS/S0 > 0: taps and polyphase factor known at compile time (tap loop fully unrolled, LDS
+// offsets are immediates).  S0 = stride for mode 0, 0 for mode 1.  TAPS == 0: generic runtime loop.
+template <int TILES_O, int TILES_T, int WAVES_O, int WAVES_T, int TAPS, int S0>
 __global__ __launch_bounds__(256) void conv_engine_kernel(const ConvP p) {
   static_assert(WAVES_O * WAVES_T == 4, "4 waves per workgroup");
   constexpr int OT = 32 * TILES_O * WAVES_O;
   constexpr int TT = 32 * TILES_T * WAVES_T;
+  constexpr int SD = S0 > 0 ? S0 : 1;
   extern __shared__ float smem[];
   float* xs = smem;                                // [CC][sp][rowlen]
   float* ws = smem + (size_t)p.CC * p.chs;         // [CC][taps][OT]
@@ -57,7 +65,8 @@ __global__ __launch_bounds__(256) void conv_engine_kernel(const ConvP p) {
   const int row0 = blockIdx.y * OT;
   const int n0 = p.n_lo + blockIdx.x * TT;
   const ag_conv_args& a = p.a;
-  const int base = (a.mode == 0) ? (a.stride * n0 - a.pad) : (n0 - (p.taps - 1));
+  const int taps = TAPS > 0 ? TAPS : p.taps;
+  const int base = (a.mode == 0) ? (a.stride * n0 - a.pad) : (n0 - (taps - 1));
   const float* xb = a.x + (int64_t)b * a.x_bs;
 
   f32x16 acc[TILES_O][TILES_T];
@@ -69,6 +78,7 @@ __global__ __launch_bounds__(256) void conv_engine_kernel(const ConvP p) {
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   const int span = p.sp * p.ncols;
+  const int rowlen = p.rowlen, chs = p.chs;
   for (int c0 = 0; c0 < p.Cpad; c0 += p.CC) {
     __syncthreads();
     // ---- stage the input tile: wave w takes channels w, w+4, ...; lanes run along time
@@ -76,34 +86,40 @@ __global__ __launch_bounds__(256) void conv_engine_kernel(const ConvP p) {
       const int c = c0 + cc;
       const bool cok = c < a.C;
       const float* xc = xb + (int64_t)c * a.x_cs;
-      float* xr = xs + cc * p.chs;
+      float* xr = xs + cc * chs;
       for (int rem = lane; rem < span; rem += 64) {
         const int g = base + rem;
         float v = 0.f;
         if (cok && g >= 0 && g < a.Lin) v = xc[g];
         int r, qq;
-        if (p.sp_shift >= 0) {
+        if (S0 > 0) {
+          r = rem % SD;
+          qq = rem / SD;
+        } else if (TAPS > 0) {
+          r = 0;
+          qq = rem;
+        } else if (p.sp_shift >= 0) {
           r = rem & (p.sp - 1);
           qq = rem >> p.sp_shift;
         } else {
           qq = rem / p.sp;
           r = rem - qq * p.sp;
         }
-        xr[r * p.rowlen + qq] = v;
+        xr[r * rowlen + qq] = v;
       }
     }
     // ---- stage the weight chunk: ws[cc][tau][row] <- wp[c][tau][row0 + row]
     {
-      const int n4 = p.CC * p.taps * (OT / 4);
+      const int n4 = p.CC * taps * (OT / 4);
       for (int idx = tid; idx < n4; idx += 256) {
         const int r4 = idx % (OT / 4);
         const int ct = idx / (OT / 4);  // cc * taps + tau
-        const int cc = ct / p.taps;
+        const int cc = ct / taps;
         const int c = c0 + cc;
         const int row = row0 + r4 * 4;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (c < p.Cpad && row < p.Mpad)
-          v = *reinterpret_cast<const f32x4*>(a.wp + ((int64_t)c0 * p.taps + ct) * p.Mpad + row);
+          v = *reinterpret_cast<const f32x4*>(a.wp + ((int64_t)c0 * taps + ct) * p.Mpad + row);
         *reinterpret_cast<f32x4*>(ws + (size_t)ct * OT + r4 * 4) = v;
       }
     }
@@ -111,20 +127,37 @@ __global__ __launch_bounds__(256) void conv_engine_kernel(const ConvP p) {
     // ---- MFMA over (channel pair, tap)
     const int npair = p.CC >> 1;
     for (int cp = 0; cp < npair; ++cp) {
-      const float* wrow = ws + (size_t)((2 * cp + h) * p.taps) * OT + wrow0 + l31;
-      const float* xrow = xs + (2 * cp + h) * p.chs + wcol0 + l31;
-      for (int tau = 0; tau < p.taps; ++tau) {
-        float av[TILES_O], bv[TILES_T];
+      const float* wrow = ws + (size_t)((2 * cp + h) * taps) * OT + wrow0 + l31;
+      const float* xrow = xs + (2 * cp + h) * chs + wcol0 + l31;
+      if (TAPS > 0) {
 #pragma unroll
-        for (int i = 0; i < TILES_O; ++i) av[i] = wrow[tau * OT + 32 * i];
-        const int off = p.tapoff[tau];
+        for (int tau = 0; tau < TAPS; ++tau) {
+          const int off = S0 > 0 ? ((tau % SD) * rowlen + tau / SD) : (TAPS - 1 - tau);
+          float av[TILES_O], bv[TILES_T];
 #pragma unroll
-        for (int j = 0; j < TILES_T; ++j) bv[j] = xrow[off + 32 * j];
+          for (int i = 0; i < TILES_O; ++i) av[i] = wrow[tau * OT + 32 * i];
 #pragma unroll
-        for (int i = 0; i < TILES_O; ++i)
+          for (int j = 0; j < TILES_T; ++j) bv[j] = xrow[off + 32 * j];
 #pragma unroll
-          for (int j = 0; j < TILES_T; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+          for (int i = 0; i < TILES_O; ++i)
+#pragma unroll
+            for (int j = 0; j < TILES_T; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+        }
+      } else {
+        for (int tau = 0; tau < taps; ++tau) {
+          float av[TILES_O], bv[TILES_T];
+#pragma unroll
+          for (int i = 0; i < TILES_O; ++i) av[i] = wrow[tau * OT + 32 * i];
+          const int off = p.tapoff[tau];
+#pragma unroll
+          for (int j = 0; j < TILES_T; ++j) bv[j] = xrow[off + 32 * j];
+#pragma unroll
+          for (int i = 0; i < TILES_O; ++i)
+#pragma unroll
+            for (int j = 0; j < TILES_T; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+        }
       }
     }
   }
@@ -133,33 +166,84 @@ __global__ __launch_bounds__(256) void conv_engine_kernel(const ConvP p) {
   const int64_t lenb = a.lens_i64 ? a.lens_i64[b] : (int64_t)1 << 60;
   float* yb = a.y + (int64_t)b * a.y_bs;
   const float* rb = a.res ? a.res + (int64_t)b * a.res_bs : nullptr;
+  if (a.mode == 0) {
+#pragma unroll
+    for (int i = 0; i < TILES_O; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int o = row0 + wrow0 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (o >= p.Mrows) continue;
+        const float bo = a.bias ? a.bias[o] : 0.f;
+#pragma unroll
+        for (int j = 0; j < TILES_T; ++j) {
+          const int t = n0 + wcol0 + 32 * j + l31;
+          if (t >= a.Lout) continue;
+          float v = acc[i][j][e] + bo;
+          if (rb) v += rb[(int64_t)o * a.res_cs + t];
+          v = ag_apply_act(v, a.act, a.slope);
+          if (t >= lenb) v = 0.f;
+          float* dst = yb + (int64_t)o * a.y_cs + t;
+          if (a.accumulate) v += *dst;
+          *dst = v;
+        }
+      }
+    }
+    return;
+  }
+  // mode 1: row = o*s + r, output position u = s*n + r - pad.  A lane holds 4 consecutive rows in
+  // registers 4g..4g+3, i.e. VW consecutive output positions of one channel -> vector stores.
+  const int s = a.stride;
+  const int VW = (s % 4 == 0) ? 4 : ((s % 2 == 0) ? 2 : 1);
 #pragma unroll
   for (int i = 0; i < TILES_O; ++i) {
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int row = row0 + wrow0 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
-      if (row >= p.Mrows) continue;
-      int o, r;
-      if (a.mode == 0) {
-        o = row;
-        r = 0;
-      } else {
-        o = row / a.stride;
-        r = row - o * a.stride;
-      }
-      const float bo = a.bias ? a.bias[o] : 0.f;
+    for (int g = 0; g < 4; ++g) {
+      const int rowb = row0 + wrow0 + 32 * i + 8 * g + 4 * h;
+      if (rowb >= p.Mrows) continue;
 #pragma unroll
       for (int j = 0; j < TILES_T; ++j) {
         const int n = n0 + wcol0 + 32 * j + l31;
-        const int t = (a.mode == 0) ? n : (a.stride * n + r - a.pad);
-        if (t < 0 || t >= a.Lout) continue;
-        float v = acc[i][j][e] + bo;
-        if (rb) v += rb[(int64_t)o * a.res_cs + t];
-        v = ag_apply_act(v, a.act, a.slope);
-        if (t >= lenb) v = 0.f;
-        float* dst = yb + (int64_t)o * a.y_cs + t;
-        if (a.accumulate) v += *dst;
-        *dst = v;
+        const float v4[4] = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+        for (int sub = 0; sub < 4; sub += VW) {
+          const int row = rowb + sub;
+          if (row >= p.Mrows) break;
+          const int o = row / s, r = row - o * s;
+          const int u0 = s * n + r - a.pad;
+          const float bo = a.bias ? a.bias[o] : 0.f;
+          float* dst = yb + (int64_t)o * a.y_cs + u0;
+          const float* rsrc = rb ? rb + (int64_t)o * a.res_cs + u0 : nullptr;
+          float v[4];
+          if (VW == 4) { v[0] = v4[0] + bo; v[1] = v4[1] + bo; v[2] = v4[2] + bo; v[3] = v4[3] + bo; }
+          else if (VW == 2) { v[0] = (sub ? v4[2] : v4[0]) + bo; v[1] = (sub ? v4[3] : v4[1]) + bo; v[2] = v[3] = 0.f; }
+          else { v[0] = (sub == 0 ? v4[0] : sub == 1 ? v4[1] : sub == 2 ? v4[2] : v4[3]) + bo; v[1] = v[2] = v[3] = 0.f; }
+          const bool full = u0 >= 0 && u0 + VW <= a.Lout;
+          if (full && VW == 4) {
+            if (rsrc) { const f32x4u rv = *reinterpret_cast<const f32x4u*>(rsrc); v[0] += rv[0]; v[1] += rv[1]; v[2] += rv[2]; v[3] += rv[3]; }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { v[q] = ag_apply_act(v[q], a.act, a.slope); if (u0 + q >= lenb) v[q] = 0.f; }
+            if (a.accumulate) { const f32x4u ov = *reinterpret_cast<const f32x4u*>(dst); v[0] += ov[0]; v[1] += ov[1]; v[2] += ov[2]; v[3] += ov[3]; }
+            f32x4u out = {v[0], v[1], v[2], v[3]};
+            *reinterpret_cast<f32x4u*>(dst) = out;
+          } else if (full && VW == 2) {
+            if (rsrc) { const f32x2u rv = *reinterpret_cast<const f32x2u*>(rsrc); v[0] += rv[0]; v[1] += rv[1]; }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) { v[q] = ag_apply_act(v[q], a.act, a.slope); if (u0 + q >= lenb) v[q] = 0.f; }
+            if (a.accumulate) { const f32x2u ov = *reinterpret_cast<const f32x2u*>(dst); v[0] += ov[0]; v[1] += ov[1]; }
+            f32x2u out = {v[0], v[1]};
+            *reinterpret_cast<f32x2u*>(dst) = out;
+          } else {
+            for (int q = 0; q < VW; ++q) {
+              const int u = u0 + q;
+              if (u < 0 || u >= a.Lout) continue;
+              float w = v[q];
+              if (rsrc) w += rsrc[q];
+              w = ag_apply_act(w, a.act, a.slope);
+              if (u >= lenb) w = 0.f;
+              if (a.accumulate) w += dst[q];
+              dst[q] = w;
+            }
+          }
+        }
       }
     }
   }
@@ -181,6 +265,16 @@ extern "C" int64_t ag_wpb_numel(int d0, int d1, int K, int stride) {
   return (int64_t)ag_roundup(d0, 2) * ag_cdiv(K, stride) * ag_roundup(d1 * stride, 32);
 }
 
+template <int TO, int TTL, int WO, int WT, int TAPS, int S0>
+static int launch_one(ConvP& p, size_t lds, dim3 grid, hipStream_t st) {
+  auto kern = conv_engine_kernel<TO, TTL, WO, WT, TAPS, S0>;
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
+  AG_CHECK_LAUNCH("ag_conv1d_engine");
+  return AG_OK;
+}
+
 template <int TO, int TTL, int WO, int WT>
 static int launch_cfg(ConvP& p, hipStream_t st) {
   constexpr int OT = 32 * TO * WO, TT = 32 * TTL * WT;
@@ -197,11 +291,11 @@ static int launch_cfg(ConvP& p, hipStream_t st) {
   p.chs = p.sp * p.rowlen;
   for (int t = 0; t < p.taps; ++t)
     p.tapoff[t] = (a.mode == 0) ? ((t % a.stride) * p.rowlen + t / a.stride) : (p.taps - 1 - t);
-  // channels per chunk: as many (even, <= 16) as fit in 48 KiB of LDS
+  // channels per chunk: as many (even, <= 32) as fit in 48 KiB of LDS
   const size_t per_c = (size_t)(p.chs + p.taps * OT) * sizeof(float);
   int cc = (int)((48 * 1024) / per_c) & ~1;
   if (cc < 2) cc = 2;
-  if (cc > 16) cc = 16;
+  if (cc > 32) cc = 32;
   if (cc > p.Cpad) cc = p.Cpad;
   p.CC = cc;
   const size_t lds = (size_t)cc * per_c;
@@ -210,13 +304,19 @@ static int launch_cfg(ConvP& p, hipStream_t st) {
     return AG_ERR_UNSUPPORTED;
   }
   dim3 grid(ag_cdiv(p.n_cnt, TT), ag_cdiv(p.Mrows, OT), a.B);
-  auto kern = conv_engine_kernel<TO, TTL, WO, WT>;
-  if (lds > 64 * 1024)
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)lds);
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
-  AG_CHECK_LAUNCH("ag_conv1d_engine");
-  return AG_OK;
+  const int key = a.mode == 0 ? p.taps * 100 + a.stride : p.taps * 100;
+  switch (key) {
+    case 1708: return launch_one<TO, TTL, WO, WT, 17, 8>(p, lds, grid, st);  // G1.conv
+    case 904:  return launch_one<TO, TTL, WO, WT, 9, 4>(p, lds, grid, st);   // G2-4.conv
+    case 702:  return launch_one<TO, TTL, WO, WT, 7, 2>(p, lds, grid, st);   // D convs
+    case 301:  return launch_one<TO, TTL, WO, WT, 3, 1>(p, lds, grid, st);   // G5.final
+    case 1608: return launch_one<TO, TTL, WO, WT, 16, 8>(p, lds, grid, st);  // G1.deconv backward-data
+    case 804:  return launch_one<TO, TTL, WO, WT, 8, 4>(p, lds, grid, st);   // G2-4.deconv backward-data
+    case 200:  return launch_one<TO, TTL, WO, WT, 2, 0>(p, lds, grid, st);   // deconv fwd (k16 s8, k8 s4)
+    case 300:  return launch_one<TO, TTL, WO, WT, 3, 0>(p, lds, grid, st);   // conv bwd-data k17 s8, k9 s4, k3 s1
+    case 400:  return launch_one<TO, TTL, WO, WT, 4, 0>(p, lds, grid, st);   // conv bwd-data k7 s2
+    default:   return launch_one<TO, TTL, WO, WT, 0, 0>(p, lds, grid, st);
+  }
 }
 
 extern "C" int ag_conv1d_engine(const ag_conv_args* args, void* stream) {

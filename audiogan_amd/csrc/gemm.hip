@@ -6,6 +6,8 @@
 //
 // LDS tiles are k-major (As[k][m], Bs[k][n]) so that both MFMA operands are unit-stride,
 // conflict-free ds_read_b32; the loaders transpose k-contiguous operands on the way in.
+#include <type_traits>
+
 #include "common.h"
 
 #define GBK 16
@@ -25,68 +27,93 @@ struct GemmP {
   int kchunk;      // K per slice (multiple of GBK)
 };
 
+// Tile loaders, split into "global -> registers" and "registers -> LDS" so that the loads of
+// tile i+1 are in flight while tile i is being multiplied (one barrier per k-step, two LDS buffers).
 // operand stored [rows][K] (k contiguous): tile -> S[k][r]
-template <int ROWS, int PITCH>
-__device__ __forceinline__ void load_kcontig(float* S, const float* __restrict__ G, int ld, int r0,
-                                             int nrows, int k0, int K, bool vec, int tid) {
-  constexpr int ITER = ROWS * (GBK / 4) / 256;
+template <int ROWS>
+struct KContig {
+  static constexpr int ITER = ROWS * (GBK / 4) / 256;
   static_assert(ITER >= 1, "tile too small");
+  f32x4 v[ITER];
+  __device__ __forceinline__ void load(const float* __restrict__ G, int ld, int r0, int nrows, int k0, int K,
+                                       bool vec, int tid) {
 #pragma unroll
-  for (int it = 0; it < ITER; ++it) {
-    const int idx = tid + it * 256;
-    const int r = idx >> 2, kq = idx & 3;
-    const int gr = r0 + r, gk = k0 + kq * 4;
-    float v[4] = {0.f, 0.f, 0.f, 0.f};
-    if (gr < nrows) {
-      const float* src = G + (int64_t)gr * ld + gk;
-      if (vec && gk + 3 < K) {
-        const f32x4 q = *reinterpret_cast<const f32x4*>(src);
-        v[0] = q[0]; v[1] = q[1]; v[2] = q[2]; v[3] = q[3];
-      } else {
+    for (int it = 0; it < ITER; ++it) {
+      const int idx = tid + it * 256;
+      const int r = idx >> 2, kq = idx & 3;
+      const int gr = r0 + r, gk = k0 + kq * 4;
+      f32x4 q = {0.f, 0.f, 0.f, 0.f};
+      if (gr < nrows) {
+        const float* src = G + (int64_t)gr * ld + gk;
+        if (vec && gk + 3 < K) {
+          q = *reinterpret_cast<const f32x4*>(src);
+        } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (gk + e < K) v[e] = src[e];
+          for (int e = 0; e < 4; ++e)
+            if (gk + e < K) q[e] = src[e];
+        }
       }
+      v[it] = q;
     }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) S[(kq * 4 + e) * PITCH + r] = v[e];
   }
-}
+  template <int PITCH>
+  __device__ __forceinline__ void store(float* S, int tid) const {
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      const int idx = tid + it * 256;
+      const int r = idx >> 2, kq = idx & 3;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) S[(kq * 4 + e) * PITCH + r] = v[it][e];
+    }
+  }
+};
 
 // operand stored [K][rows] (row index contiguous): tile -> S[k][r]
-template <int ROWS, int PITCH>
-__device__ __forceinline__ void load_rcontig(float* S, const float* __restrict__ G, int ld, int r0,
-                                             int nrows, int k0, int K, bool vec, int tid) {
-  constexpr int R4 = ROWS / 4;
-  constexpr int ITER = GBK * R4 / 256;
+template <int ROWS>
+struct RContig {
+  static constexpr int R4 = ROWS / 4;
+  static constexpr int ITER = GBK * R4 / 256;
   static_assert(ITER >= 1, "tile too small");
+  f32x4 v[ITER];
+  __device__ __forceinline__ void load(const float* __restrict__ G, int ld, int r0, int nrows, int k0, int K,
+                                       bool vec, int tid) {
 #pragma unroll
-  for (int it = 0; it < ITER; ++it) {
-    const int idx = tid + it * 256;
-    const int k = idx / R4, r = (idx % R4) * 4;
-    const int gk = k0 + k, gr = r0 + r;
-    f32x4 q = {0.f, 0.f, 0.f, 0.f};
-    if (gk < K) {
-      const float* src = G + (int64_t)gk * ld + gr;
-      if (vec && gr + 3 < nrows) {
-        q = *reinterpret_cast<const f32x4*>(src);
-      } else {
+    for (int it = 0; it < ITER; ++it) {
+      const int idx = tid + it * 256;
+      const int k = idx / R4, r = (idx % R4) * 4;
+      const int gk = k0 + k, gr = r0 + r;
+      f32x4 q = {0.f, 0.f, 0.f, 0.f};
+      if (gk < K) {
+        const float* src = G + (int64_t)gk * ld + gr;
+        if (vec && gr + 3 < nrows) {
+          q = *reinterpret_cast<const f32x4*>(src);
+        } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (gr + e < nrows) q[e] = src[e];
+          for (int e = 0; e < 4; ++e)
+            if (gr + e < nrows) q[e] = src[e];
+        }
       }
+      v[it] = q;
     }
-    *reinterpret_cast<f32x4*>(S + k * PITCH + r) = q;
   }
-}
+  template <int PITCH>
+  __device__ __forceinline__ void store(float* S, int tid) const {
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      const int idx = tid + it * 256;
+      const int k = idx / R4, r = (idx % R4) * 4;
+      *reinterpret_cast<f32x4*>(S + k * PITCH + r) = v[it];
+    }
+  }
+};
 
 template <int TM, int TN, int WM, int WN, int TA, int TB>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
   static_assert(WM * WN == 4, "4 waves");
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
   constexpr int PA = BM + 4, PB = BN + 4;
-  __shared__ __attribute__((aligned(16))) float As[GBK * PA];
-  __shared__ __attribute__((aligned(16))) float Bs[GBK * PB];
+  __shared__ __attribute__((aligned(16))) float As[2][GBK * PA];
+  __shared__ __attribute__((aligned(16))) float Bs[2][GBK * PB];
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l31 = lane & 31, h = lane >> 5;
@@ -101,32 +128,44 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+  typename std::conditional<TA == 0, KContig<BM>, RContig<BM>>::type la;
+  typename std::conditional<TB == 1, KContig<BN>, RContig<BN>>::type lb;
+
   const int kbeg = blockIdx.z * p.kchunk;
   const int kend = (kbeg + p.kchunk < p.K) ? kbeg + p.kchunk : p.K;
+  la.load(p.A, p.lda, m0, p.M, kbeg, p.K, p.vecA, tid);
+  lb.load(p.B, p.ldb, n0, p.N, kbeg, p.K, p.vecB, tid);
+  la.template store<PA>(As[0], tid);
+  lb.template store<PB>(Bs[0], tid);
+  __syncthreads();
+  int buf = 0;
   for (int k0 = kbeg; k0 < kend; k0 += GBK) {
-    __syncthreads();
-    if (TA == 0)
-      load_kcontig<BM, PA>(As, p.A, p.lda, m0, p.M, k0, p.K, p.vecA, tid);
-    else
-      load_rcontig<BM, PA>(As, p.A, p.lda, m0, p.M, k0, p.K, p.vecA, tid);
-    if (TB == 1)
-      load_kcontig<BN, PB>(Bs, p.B, p.ldb, n0, p.N, k0, p.K, p.vecB, tid);
-    else
-      load_rcontig<BN, PB>(Bs, p.B, p.ldb, n0, p.N, k0, p.K, p.vecB, tid);
-    __syncthreads();
+    const bool more = k0 + GBK < kend;
+    if (more) {
+      la.load(p.A, p.lda, m0, p.M, k0 + GBK, p.K, p.vecA, tid);
+      lb.load(p.B, p.ldb, n0, p.N, k0 + GBK, p.K, p.vecB, tid);
+    }
+    const float* Ac = As[buf];
+    const float* Bc = Bs[buf];
 #pragma unroll
     for (int kk = 0; kk < GBK; kk += 2) {
       float av[TM], bv[TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) av[i] = As[(kk + h) * PA + wm0 + 32 * i + l31];
+      for (int i = 0; i < TM; ++i) av[i] = Ac[(kk + h) * PA + wm0 + 32 * i + l31];
 #pragma unroll
-      for (int j = 0; j < TN; ++j) bv[j] = Bs[(kk + h) * PB + wn0 + 32 * j + l31];
+      for (int j = 0; j < TN; ++j) bv[j] = Bc[(kk + h) * PB + wn0 + 32 * j + l31];
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
     }
+    if (more) {
+      la.template store<PA>(As[buf ^ 1], tid);
+      lb.template store<PB>(Bs[buf ^ 1], tid);
+    }
+    __syncthreads();
+    buf ^= 1;
   }
 
 #pragma unroll

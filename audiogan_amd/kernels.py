@@ -425,7 +425,12 @@ def _work_conv(x, wp, y, K_, stride, pad, mode, *a_, **kw):
     else:
         tile = '2,2,2,2'
     macs = B * O * Lout * Cc * K_ if mode == 0 else B * Cc * Lin * O * K_
-    return 'conv_engine_kernel<%s>' % tile, 2.0 * macs, 4.0 * (x.numel() + y.numel() + wp.numel())
+    taps = K_ if mode == 0 else _cdiv(K_, stride)
+    ts = (taps, stride if mode == 0 else 0)
+    if ts not in ((17, 8), (9, 4), (7, 2), (3, 1), (16, 8), (8, 4), (2, 0), (3, 0), (4, 0)):
+        ts = (0, 0)
+    return 'conv_engine_kernel<%s,%d,%d>' % (tile, ts[0], ts[1]), 2.0 * macs, \
+        4.0 * (x.numel() + y.numel() + wp.numel())
 
 
 def _work_wgrad(sh, lg, dw, K_, stride, pad):
