@@ -46,19 +46,20 @@ typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
 // TAPS/S0 > 0: taps and polyphase factor known at compile time (tap loop fully unrolled, LDS
 // offsets are immediates).  S0 = stride for mode 0, 0 for mode 1.  TAPS == 0: generic runtime loop.
 template <int TILES_O, int TILES_T, int WAVES_O, int WAVES_T, int TAPS, int S0>
-__global__ __launch_bounds__(256) void conv_engine_kernel(const ConvP p) {
-  static_assert(WAVES_O * WAVES_T == 4, "4 waves per workgroup");
+__global__ __launch_bounds__(512) void conv_engine_kernel(const ConvP p) {
+  // 8 waves: waves 0-3 run the MFMAs of chunk i out of LDS buffer i&1 while waves 4-7 stage
+  // chunk i+1 (global -> LDS, polyphase de-interleave) into the other buffer; one barrier per
+  // chunk.  Staging VALU/VMEM work co-issues with the MFMA pipe of the compute waves.
+  static_assert(WAVES_O * WAVES_T == 4, "4 compute waves per workgroup");
   constexpr int OT = 32 * TILES_O * WAVES_O;
   constexpr int TT = 32 * TILES_T * WAVES_T;
   constexpr int SD = S0 > 0 ? S0 : 1;
   extern __shared__ float smem[];
-  float* xs = smem;                                // [CC][sp][rowlen]
-  float* ws = smem + (size_t)p.CC * p.chs;         // [CC][taps][OT]
-
   const int tid = threadIdx.x;
   const int lane = tid & 63, wid = tid >> 6;
   const int l31 = lane & 31, h = lane >> 5;
-  const int wo = wid / WAVES_T, wt = wid % WAVES_T;
+  const int cw = wid & 3;                          // index inside the role group
+  const int wo = cw / WAVES_T, wt = cw % WAVES_T;
   const int wrow0 = wo * (32 * TILES_O), wcol0 = wt * (32 * TILES_T);
 
   const int b = blockIdx.z;
@@ -79,10 +80,15 @@ __global__ __launch_bounds__(256) void conv_engine_kernel(const ConvP p) {
 
   const int span = p.sp * p.ncols;
   const int rowlen = p.rowlen, chs = p.chs;
-  for (int c0 = 0; c0 < p.Cpad; c0 += p.CC) {
-    __syncthreads();
-    // ---- stage the input tile: wave w takes channels w, w+4, ...; lanes run along time
-    for (int cc = wid; cc < p.CC; cc += 4) {
+  const size_t bufsz = (size_t)p.CC * (chs + taps * OT);   // floats per LDS buffer
+  const int nchunk = (p.Cpad + p.CC - 1) / p.CC;
+
+  // stage chunk starting at channel c0 into buffer `buf`, using `nsw` waves (this wave = `sw`)
+  auto stage = [&](int c0, int buf, int sw, int nsw) {
+    float* xs = smem + buf * bufsz;                  // [CC][sp][rowlen]
+    float* ws = xs + (size_t)p.CC * chs;             // [CC][taps][OT]
+    // input tile: a wave takes channels sw, sw+nsw, ...; lanes run along time
+    for (int cc = sw; cc < p.CC; cc += nsw) {
       const int c = c0 + cc;
       const bool cok = c < a.C;
       const float* xc = xb + (int64_t)c * a.x_cs;
@@ -108,10 +114,10 @@ __global__ __launch_bounds__(256) void conv_engine_kernel(const ConvP p) {
         xr[r * rowlen + qq] = v;
       }
     }
-    // ---- stage the weight chunk: ws[cc][tau][row] <- wp[c][tau][row0 + row]
+    // weight chunk: ws[cc][tau][row] <- wp[c][tau][row0 + row]
     {
       const int n4 = p.CC * taps * (OT / 4);
-      for (int idx = tid; idx < n4; idx += 256) {
+      for (int idx = sw * 64 + lane; idx < n4; idx += nsw * 64) {
         const int r4 = idx % (OT / 4);
         const int ct = idx / (OT / 4);  // cc * taps + tau
         const int cc = ct / taps;
@@ -123,7 +129,18 @@ __global__ __launch_bounds__(256) void conv_engine_kernel(const ConvP p) {
         *reinterpret_cast<f32x4*>(ws + (size_t)ct * OT + r4 * 4) = v;
       }
     }
-    __syncthreads();
+  };
+
+  stage(0, 0, wid, 8);
+  __syncthreads();
+  for (int ci = 0; ci < nchunk; ++ci) {
+    if (wid >= 4) {
+      if (ci + 1 < nchunk) stage((ci + 1) * p.CC, (ci + 1) & 1, cw, 4);
+      __syncthreads();
+      continue;
+    }
+    const float* xs = smem + (ci & 1) * bufsz;
+    const float* ws = xs + (size_t)p.CC * chs;
     // ---- MFMA over (channel pair, tap)
     const int npair = p.CC >> 1;
     for (int cp = 0; cp < npair; ++cp) {
@@ -160,7 +177,9 @@ __global__ __launch_bounds__(256) void conv_engine_kernel(const ConvP p) {
         }
       }
     }
+    __syncthreads();
   }
+  if (wid >= 4) return;
 
   // ---- epilogue: bias + residual + activation + length mask (+ accumulate)
   const int64_t lenb = a.lens_i64 ? a.lens_i64[b] : (int64_t)1 << 60;
@@ -270,7 +289,7 @@ static int launch_one(ConvP& p, size_t lds, dim3 grid, hipStream_t st) {
   auto kern = conv_engine_kernel<TO, TTL, WO, WT, TAPS, S0>;
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
+  hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, p);
   AG_CHECK_LAUNCH("ag_conv1d_engine");
   return AG_OK;
 }
@@ -287,18 +306,19 @@ static int launch_cfg(ConvP& p, hipStream_t st) {
     const int want = 32 / p.sp;  // rowlen == want (mod 32): polyphase rows land on disjoint banks
     rl = p.ncols + ((want - p.ncols) % 32 + 32) % 32;
   }
+  if ((p.sp & 1) && (rl & 1)) rl += 1;  // CC (even) * chs must be a multiple of 4 floats: 16-B aligned weight rows
   p.rowlen = rl;
   p.chs = p.sp * p.rowlen;
   for (int t = 0; t < p.taps; ++t)
     p.tapoff[t] = (a.mode == 0) ? ((t % a.stride) * p.rowlen + t / a.stride) : (p.taps - 1 - t);
-  // channels per chunk: as many (even, <= 32) as fit in 48 KiB of LDS
+  // channels per chunk: as many (even, <= 32) as fit in 2 x 36 KiB of LDS (two buffers)
   const size_t per_c = (size_t)(p.chs + p.taps * OT) * sizeof(float);
-  int cc = (int)((48 * 1024) / per_c) & ~1;
+  int cc = (int)((36 * 1024) / per_c) & ~1;
   if (cc < 2) cc = 2;
   if (cc > 32) cc = 32;
   if (cc > p.Cpad) cc = p.Cpad;
   p.CC = cc;
-  const size_t lds = (size_t)cc * per_c;
+  const size_t lds = 2 * (size_t)cc * per_c;
   if (lds > 160 * 1024) {
     ag_set_error("conv engine: tile needs %zu B of LDS", lds);
     return AG_ERR_UNSUPPORTED;
