@@ -70,14 +70,6 @@ __global__ __launch_bounds__(512) void conv_engine_kernel(const ConvP p) {
   const int base = (a.mode == 0) ? (a.stride * n0 - a.pad) : (n0 - (taps - 1));
   const float* xb = a.x + (int64_t)b * a.x_bs;
 
-  f32x16 acc[TILES_O][TILES_T];
-#pragma unroll
-  for (int i = 0; i < TILES_O; ++i)
-#pragma unroll
-    for (int j = 0; j < TILES_T; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
   const int span = p.sp * p.ncols;
   const int rowlen = p.rowlen, chs = p.chs;
   const size_t bufsz = (size_t)p.CC * (chs + taps * OT);   // floats per LDS buffer
@@ -87,52 +79,82 @@ __global__ __launch_bounds__(512) void conv_engine_kernel(const ConvP p) {
   auto stage = [&](int c0, int buf, int sw, int nsw) {
     float* xs = smem + buf * bufsz;                  // [CC][sp][rowlen]
     float* ws = xs + (size_t)p.CC * chs;             // [CC][taps][OT]
-    // input tile: a wave takes channels sw, sw+nsw, ...; lanes run along time
-    for (int cc = sw; cc < p.CC; cc += nsw) {
-      const int c = c0 + cc;
-      const bool cok = c < a.C;
-      const float* xc = xb + (int64_t)c * a.x_cs;
-      float* xr = xs + cc * chs;
-      for (int rem = lane; rem < span; rem += 64) {
-        const int g = base + rem;
-        float v = 0.f;
-        if (cok && g >= 0 && g < a.Lin) v = xc[g];
-        int r, qq;
-        if (S0 > 0) {
-          r = rem % SD;
-          qq = rem / SD;
-        } else if (TAPS > 0) {
-          r = 0;
-          qq = rem;
-        } else if (p.sp_shift >= 0) {
-          r = rem & (p.sp - 1);
-          qq = rem >> p.sp_shift;
-        } else {
-          qq = rem / p.sp;
-          r = rem - qq * p.sp;
+    // Staging is latency-bound: ALL global loads of a round (UX input samples + UW weight
+    // float4 per lane) are issued before the first LDS write, so a chunk costs one or two
+    // dependent memory round trips instead of one per loop iteration.
+    constexpr int UX = 4, UW = 4;
+    const int step = nsw * 64;
+    const int xtot = p.CC * span, wtot = p.CC * taps * (OT / 4);
+    int xe = sw * 64 + lane, we = xe;
+    while (xe < xtot || we < wtot) {
+      float xv[UX];
+      f32x4 wv[UW];
+#pragma unroll
+      for (int u = 0; u < UX; ++u) {
+        const int e = xe + u * step;
+        xv[u] = 0.f;
+        if (e < xtot) {
+          const int cc = e / span, rem = e - cc * span;
+          const int g = base + rem, c = c0 + cc;
+          if (c < a.C && g >= 0 && g < a.Lin) xv[u] = xb[(int64_t)c * a.x_cs + g];
         }
-        xr[r * rowlen + qq] = v;
       }
-    }
-    // weight chunk: ws[cc][tau][row] <- wp[c][tau][row0 + row]
-    {
-      const int n4 = p.CC * taps * (OT / 4);
-      for (int idx = sw * 64 + lane; idx < n4; idx += nsw * 64) {
-        const int r4 = idx % (OT / 4);
-        const int ct = idx / (OT / 4);  // cc * taps + tau
-        const int cc = ct / taps;
-        const int c = c0 + cc;
-        const int row = row0 + r4 * 4;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (c < p.Cpad && row < p.Mpad)
-          v = *reinterpret_cast<const f32x4*>(a.wp + ((int64_t)c0 * taps + ct) * p.Mpad + row);
-        *reinterpret_cast<f32x4*>(ws + (size_t)ct * OT + r4 * 4) = v;
+#pragma unroll
+      for (int u = 0; u < UW; ++u) {
+        const int idx = we + u * step;
+        wv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (idx < wtot) {
+          const int r4 = idx % (OT / 4), ct = idx / (OT / 4);  // ct = cc * taps + tau
+          const int c = c0 + ct / taps, row = row0 + r4 * 4;
+          if (c < p.Cpad && row < p.Mpad)
+            wv[u] = *reinterpret_cast<const f32x4*>(a.wp + ((int64_t)c0 * taps + ct) * p.Mpad + row);
+        }
       }
+#pragma unroll
+      for (int u = 0; u < UX; ++u) {
+        const int e = xe + u * step;
+        if (e < xtot) {
+          const int cc = e / span, rem = e - cc * span;
+          int r, qq;
+          if (S0 > 0) {
+            r = rem % SD;
+            qq = rem / SD;
+          } else if (TAPS > 0) {
+            r = 0;
+            qq = rem;
+          } else if (p.sp_shift >= 0) {
+            r = rem & (p.sp - 1);
+            qq = rem >> p.sp_shift;
+          } else {
+            qq = rem / p.sp;
+            r = rem - qq * p.sp;
+          }
+          xs[cc * chs + r * rowlen + qq] = xv[u];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < UW; ++u) {
+        const int idx = we + u * step;
+        if (idx < wtot) {
+          const int r4 = idx % (OT / 4), ct = idx / (OT / 4);
+          *reinterpret_cast<f32x4*>(ws + (size_t)ct * OT + r4 * 4) = wv[u];
+        }
+      }
+      xe += UX * step;
+      we += UW * step;
     }
   };
 
   stage(0, 0, wid, 8);
   __syncthreads();
+  f32x16 acc[TILES_O][TILES_T];
+#pragma unroll
+  for (int i = 0; i < TILES_O; ++i)
+#pragma unroll
+    for (int j = 0; j < TILES_T; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
   for (int ci = 0; ci < nchunk; ++ci) {
     if (wid >= 4) {
       if (ci + 1 < nchunk) stage((ci + 1) * p.CC, (ci + 1) & 1, cw, 4);
@@ -372,8 +394,33 @@ extern "C" int ag_conv1d_engine(const ag_conv_args* args, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   // tile choice: wide in rows for fat layers, wide in time for thin ones
   if (p.Mrows <= 32) return launch_cfg<1, 2, 1, 4>(p, st);   // 32 x 256
-  if (p.Mrows <= 64) return launch_cfg<2, 1, 1, 4>(p, st);   // 64 x 128
+  // A transposed conv with pad % stride != 0 has n_cnt = L/s + 1 columns: give the ragged last
+  // column(s) to a narrow tile instead of a whole extra 128-wide one.
+  const int tail = p.n_cnt % 128, main_cols = p.n_cnt - tail;
+  if (p.Mrows <= 64) {
+    if (tail > 0 && tail <= 32 && main_cols > 0) {
+      ConvP q = p;
+      q.n_cnt = main_cols;
+      int rc = launch_cfg<2, 1, 1, 4>(q, st);
+      if (rc != AG_OK) return rc;
+      q = p;
+      q.n_lo += main_cols;
+      q.n_cnt = tail;
+      return launch_cfg<1, 1, 2, 2>(q, st);                   // 64 x 64
+    }
+    return launch_cfg<2, 1, 1, 4>(p, st);                     // 64 x 128
+  }
   if (p.n_cnt <= 64) return launch_cfg<2, 1, 2, 2>(p, st);   // 128 x 64
+  if (tail > 0 && tail <= 32 && main_cols > 0) {
+    ConvP q = p;
+    q.n_cnt = main_cols;
+    int rc = launch_cfg<2, 2, 2, 2>(q, st);
+    if (rc != AG_OK) return rc;
+    q = p;
+    q.n_lo += main_cols;
+    q.n_cnt = tail;
+    return launch_cfg<1, 1, 4, 1>(q, st);                     // 128 x 32
+  }
   return launch_cfg<2, 2, 2, 2>(p, st);                       // 128 x 128
 }
 
