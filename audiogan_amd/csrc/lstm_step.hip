@@ -154,7 +154,7 @@ extern "C" int ag_skinny_gemm(const float* A, int lda, const float* B, int ldb, 
                               int M, int N, int K, float beta, const float* bias, int act, float slope,
                               int accumulate_atomic, void* stream) {
   AG_REQUIRE(A && B && C, "ag_skinny_gemm: null tensor");
-  AG_REQUIRE(M > 0 && M <= 64 && N > 0 && K > 0, "ag_skinny_gemm: needs 0 < M <= 64");
+  AG_REQUIRE(M > 0 && M <= 256 && N > 0 && K > 0, "ag_skinny_gemm: needs 0 < M <= 256");
   AG_REQUIRE(K % 8 == 0 && lda % 4 == 0 && ((uintptr_t)A & 15) == 0, "ag_skinny_gemm: A must be 16-B aligned, K%%8==0");
   if (tb) AG_REQUIRE(ldb % 4 == 0 && ((uintptr_t)B & 15) == 0, "ag_skinny_gemm: B must be 16-B aligned");
   AG_REQUIRE(!(accumulate_atomic && act != AG_ACT_NONE), "ag_skinny_gemm: atomic mode has a linear epilogue");
@@ -204,6 +204,20 @@ __global__ __launch_bounds__(512) void lstm_step_fwd_kernel(const LstmStepP p) {
   const bool bok = unit < H, aok = (m0 + l31) < B;
   const int row = (l31 >> 3) * H + (bok ? unit : 0);
   const int arow_i = aok ? m0 + l31 : 0;
+  // epilogue operands of this thread's (clip, unit) pair are requested FIRST so that their
+  // latency overlaps the product (one dependent memory round trip less per time step)
+  const int euu = threadIdx.x & 7, emm = (threadIdx.x >> 3) & 31;
+  const int eu = u0 + euu, em = m0 + emm;
+  const bool epi = threadIdx.x < 256 && em < B && eu < H;
+  float pre4[4] = {0.f, 0.f, 0.f, 0.f}, cp = 0.f, hp = 0.f;
+  bool padded = false;
+  if (epi) {
+    const float* pre = D.pre + (int64_t)em * 4 * H + eu;
+    pre4[0] = pre[0]; pre4[1] = pre[H]; pre4[2] = pre[2 * H]; pre4[3] = pre[3 * H];
+    cp = D.c_prev[(int64_t)em * H + eu];
+    padded = p.valid && D.t >= p.valid[em];
+    if (padded) hp = D.h_prev[(int64_t)em * H + eu];
+  }
   f32x16 acc;
 #pragma unroll
   for (int e = 0; e < 16; ++e) acc[e] = 0.f;
@@ -224,34 +238,32 @@ __global__ __launch_bounds__(512) void lstm_step_fwd_kernel(const LstmStepP p) {
   }
   block_reduce_acc(acc, red, nw, wid, lane);
   // epilogue: (m, unit) pairs; the 4 gates of a pair sit at columns uu, 8+uu, 16+uu, 24+uu
-  for (int q = threadIdx.x; q < 256; q += blockDim.x) {
-    const int uu = q & 7, mm = q >> 3;
-    const int u = u0 + uu, m = m0 + mm;
-    if (m >= B || u >= H) continue;
+  if (!epi) return;
+  {
     // inverse of row = (e&3) + 8*(e>>2) + 4*(lane>>5)
-    const int hh = (mm >> 2) & 1, e = (mm & 3) + 4 * (mm >> 3);
+    const int hh = (emm >> 2) & 1, e = (emm & 3) + 4 * (emm >> 3);
     const float* rr = red + (size_t)e * 64 + 32 * hh;
-    float* pre = D.pre + (int64_t)m * 4 * H;
-    const float cp = D.c_prev[(int64_t)m * H + u];
-    if (p.valid && D.t >= p.valid[m]) {
-      D.h_out[(int64_t)m * H + u] = D.h_prev[(int64_t)m * H + u];
-      D.c_out[(int64_t)m * H + u] = cp;
-      if (D.y_out) D.y_out[(int64_t)m * D.ldy + u] = 0.f;
-      continue;
+    float* pre = D.pre + (int64_t)em * 4 * H + eu;
+    const int64_t o = (int64_t)em * H + eu;
+    if (padded) {
+      D.h_out[o] = hp;
+      D.c_out[o] = cp;
+      if (D.y_out) D.y_out[(int64_t)em * D.ldy + eu] = 0.f;
+      return;
     }
-    const float ig = ag_sigmoid(pre[u] + rr[uu]);
-    const float fg = ag_sigmoid(pre[H + u] + rr[8 + uu]);
-    const float gg = tanhf(pre[2 * H + u] + rr[16 + uu]);
-    const float og = ag_sigmoid(pre[3 * H + u] + rr[24 + uu]);
+    const float ig = ag_sigmoid(pre4[0] + rr[euu]);
+    const float fg = ag_sigmoid(pre4[1] + rr[8 + euu]);
+    const float gg = tanhf(pre4[2] + rr[16 + euu]);
+    const float og = ag_sigmoid(pre4[3] + rr[24 + euu]);
     const float cn = fg * cp + ig * gg;
     const float hn = og * tanhf(cn);
-    pre[u] = ig;
-    pre[H + u] = fg;
-    pre[2 * H + u] = gg;
-    pre[3 * H + u] = og;
-    D.c_out[(int64_t)m * H + u] = cn;
-    D.h_out[(int64_t)m * H + u] = hn;
-    if (D.y_out) D.y_out[(int64_t)m * D.ldy + u] = hn;
+    pre[0] = ig;
+    pre[H] = fg;
+    pre[2 * H] = gg;
+    pre[3 * H] = og;
+    D.c_out[o] = cn;
+    D.h_out[o] = hn;
+    if (D.y_out) D.y_out[(int64_t)em * D.ldy + eu] = hn;
   }
 }
 
@@ -266,7 +278,7 @@ static int launch_lstm_step(const LstmStepP& p, int ndir, hipStream_t st) {
 
 static bool step_ok(int B, int H, int Kx, int ldx, int ldwx, const void* x, const void* wx, const void* whh,
                     const void* h) {
-  if (B > 64 || H % 8 != 0) return false;
+  if (B > 256 || H % 8 != 0) return false;
   if (((uintptr_t)whh & 15) || ((uintptr_t)h & 15)) return false;
   if (x && (Kx % 8 != 0 || ldx % 4 != 0 || ldwx % 4 != 0 || ((uintptr_t)x & 15) || ((uintptr_t)wx & 15)))
     return false;
@@ -280,7 +292,7 @@ extern "C" int ag_lstm_step_fwd(float* gates_pre, const float* x, int ldx, const
                                 float* h_out, int B, int H, int first_step, void* stream) {
   AG_REQUIRE(gates_pre && h_prev && whh && c_prev && c_out && h_out, "ag_lstm_step_fwd: null tensor");
   AG_REQUIRE(step_ok(B, H, Kx, ldx, ldwx, x, wx, whh, h_prev),
-             "ag_lstm_step_fwd: needs B<=64, H%%8==0, Kx%%8==0 and 16-B aligned rows");
+             "ag_lstm_step_fwd: needs B<=256, H%%8==0, Kx%%8==0 and 16-B aligned rows");
   LstmStepP p;
   p.valid = nullptr; p.B = B; p.H = H; p.skip_h = first_step ? 1 : 0;
   LstmDir& d = p.d[0];
@@ -303,7 +315,7 @@ extern "C" int ag_lstm_seq_fwd(float* const* pre, const float* const* whh, float
   AG_REQUIRE(T > 0 && 0 <= k_begin && k_begin <= k_end && k_end <= T, "ag_lstm_seq_fwd: bad step range");
   for (int d = 0; d < ndir; ++d)
     AG_REQUIRE(step_ok(B, H, 0, 0, 0, nullptr, nullptr, whh[d], hbuf[d]),
-               "ag_lstm_seq_fwd: needs B<=64, H%%8==0 and 16-B aligned buffers");
+               "ag_lstm_seq_fwd: needs B<=256, H%%8==0 and 16-B aligned buffers");
   hipStream_t st = (hipStream_t)stream;
   const int64_t BH = (int64_t)B * H;
   for (int d = 0; d < ndir && k_begin == 0; ++d)
@@ -394,7 +406,7 @@ extern "C" int ag_lstm_seq_bwd(const float* const* gates, const float* const* wh
                                int B, int H, int ndir, int k_begin, int k_end, void* stream) {
   AG_REQUIRE(gates && whh && c_all && dy && dgates && dhbuf && dcbuf, "ag_lstm_seq_bwd: null table");
   AG_REQUIRE(ndir == 1 || ndir == 2, "ag_lstm_seq_bwd: ndir must be 1 or 2");
-  AG_REQUIRE(T > 0 && B > 0 && B <= 64 && (4 * H) % 8 == 0, "ag_lstm_seq_bwd: bad shape");
+  AG_REQUIRE(T > 0 && B > 0 && B <= 256 && (4 * H) % 8 == 0, "ag_lstm_seq_bwd: bad shape");
   AG_REQUIRE(0 <= k_begin && k_begin <= k_end && k_end <= T, "ag_lstm_seq_bwd: bad step range");
   hipStream_t st = (hipStream_t)stream;
   const int64_t BH = (int64_t)B * H, BG = (int64_t)B * 4 * H;

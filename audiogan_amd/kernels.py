@@ -479,7 +479,7 @@ def _al16(t):
 def skinny_ok(A, B, tb):
     """can ag_skinny_gemm take this product? (M <= 64, K % 8 == 0, 16-byte aligned rows)"""
     M, Kd = A.shape
-    ok = M <= 64 and Kd % 8 == 0 and A.stride(1) == 1 and A.stride(0) % 4 == 0 and _al16(A)
+    ok = M <= 256 and Kd % 8 == 0 and A.stride(1) == 1 and A.stride(0) % 4 == 0 and _al16(A)
     if tb:
         ok = ok and B.stride(1) == 1 and B.stride(0) % 4 == 0 and _al16(B)
     return ok
@@ -499,7 +499,7 @@ def skinny_gemm(A, B, Cm, tb=False, beta=0.0, bias=None, act=ACT_NONE, slope=LEA
 
 
 def lstm_step_ok(B, H, x=None, wx=None):
-    ok = B <= 64 and H % 8 == 0
+    ok = B <= 256 and H % 8 == 0
     if x is not None:
         ok = ok and x.size(1) % 8 == 0 and x.stride(1) == 1 and x.stride(0) % 4 == 0 and _al16(x) \
             and wx.stride(1) == 1 and wx.stride(0) % 4 == 0 and _al16(wx)

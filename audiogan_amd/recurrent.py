@@ -92,7 +92,7 @@ class LSTMSeqFn(torch.autograd.Function):
         dgs = [torch.empty(T, B, 4 * H, device=dev) for _ in range(ndir)]
         dhb = [torch.empty(2, B, H, device=dev) for _ in range(ndir)]
         dcb = [torch.empty(2, B, H, device=dev) for _ in range(ndir)]
-        if B <= 64 and H % 2 == 0:
+        if B <= 256 and H % 2 == 0:
             K.lstm_seq_bwd(gates_all, whh, c_all, dy, dgs, dhb, dcb, lengths)
         else:
             for d in range(ndir):

@@ -7,16 +7,24 @@ from .losses import masked_bce_mean
 
 
 def d_step(g, d, opt_d, real, real_len, c, z, noise_real, noise_fake, dgradclip=1.0, stop='never',
-           grad_hook=None, check=False):
+           grad_hook=None, check=False, batch_real_fake=True):
     """One critic iteration: G forward without grad, D(real) vs 0.9, D(fake) vs 0
     (audiogan.py:723-728, 739-740, 748-751, 761-766, 780-788)."""
     with torch.no_grad():
         fake, _, _, fake_len = g(z=z, c=c, stop=stop)
         fake = fake + noise_fake
-    cls_d, _, _, nf_d = d(real + noise_real, real_len, c)
-    loss_d, _ = masked_bce_mean(cls_d, 0.9, nf_d)
-    cls_g, _, _, nf_g = d(fake, fake_len, c)
-    loss_g, _ = masked_bce_mean(cls_g, 0.0, nf_g)
+    B = real.size(0)
+    if batch_real_fake and fake.size(1) == real.size(1):
+        # D has no cross-sample op, so D(cat(real, fake)) == cat(D(real), D(fake)): one pass over
+        # 2B clips halves the number of strictly sequential biLSTM steps of the critic iteration
+        cls, _, _, nf = d(torch.cat([real + noise_real, fake], 0), torch.cat([real_len.to(fake_len.device), fake_len], 0),
+                          torch.cat([c, c], 0))
+        cls_d, cls_g, nf_d, nf_g = cls[:B], cls[B:], nf[:B], nf[B:]
+    else:
+        cls_d, _, _, nf_d = d(real + noise_real, real_len, c)
+        cls_g, _, _, nf_g = d(fake, fake_len, c)
+    loss_d, _ = masked_bce_mean(cls_d, 0.9, nf_d.contiguous())
+    loss_g, _ = masked_bce_mean(cls_g, 0.0, nf_g.contiguous())
     loss = loss_d + loss_g
     opt_d.zero_grad()
     loss.backward()

@@ -174,7 +174,7 @@ int ag_lstm_cell_bwd(const float* gates_act, int ldg, const float* c_prev, int l
                      float* dc_prev, int lddcp, float* dh_pass, int lddhp, const int64_t* valid_i64,
                      int t, int B, int H, void* stream);
 
-/* Skinny product for the sequential part of the recurrent layers (M = clips per GPU <= 64):
+/* Skinny product for the sequential part of the recurrent layers (M = clips per call <= 256):
  *   C[M,N] = act(A[M,K] * op(B) + beta*C + bias)         (accumulate_atomic == 0)
  *   C[M,N] += A[M,K] * op(B) (+ bias)   K split over workgroups, fp32 atomics  (== 1)
  * tb: 1 -> B stored [N,K] (Linear weight), 0 -> B stored [K,N].  Needs K % 8 == 0 and 16-byte

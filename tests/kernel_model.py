@@ -289,7 +289,7 @@ def install(monkeypatch):
 # ---- skinny products / fused recurrent steps (same contracts as lstm_step.hip) -----------------
 def skinny_ok(A, B, tb):
     M, Kd = A.shape
-    ok = M <= 64 and Kd % 8 == 0 and A.stride(1) == 1 and A.stride(0) % 4 == 0
+    ok = M <= 256 and Kd % 8 == 0 and A.stride(1) == 1 and A.stride(0) % 4 == 0
     if tb:
         ok = ok and B.stride(1) == 1 and B.stride(0) % 4 == 0
     return ok
@@ -310,7 +310,7 @@ def skinny_gemm(A, B, Cm, tb=False, beta=0.0, bias=None, act=ACT_NONE, slope=LEA
 
 
 def lstm_step_ok(B, H, x=None, wx=None):
-    ok = B <= 64 and H % 8 == 0
+    ok = B <= 256 and H % 8 == 0
     if x is not None:
         ok = ok and x.size(1) % 8 == 0 and x.stride(0) % 4 == 0 and wx.stride(0) % 4 == 0
     return ok
