@@ -306,7 +306,7 @@ def test_error_convention(K):
         K.act_fwd(torch.zeros(4), torch.zeros(4), K.ACT_LEAKY)   # CPU tensor: no fallback
 
 
-@pytest.mark.parametrize('shape', [(64, 2048, 512), (64, 512, 2048), (64, 256, 1024), (64, 1024, 4096),
+@pytest.mark.parametrize('shape', [(64, 2048, 512), (64, 512, 2048), (64, 256, 1024), (64, 1024, 4096), (128, 512, 2048),
                                    (3, 40, 24), (33, 7, 8), (64, 4096, 256)])
 @pytest.mark.parametrize('tb', [True, False])
 def test_skinny_gemm(K, shape, tb):
@@ -331,7 +331,7 @@ def test_skinny_rejects_unaligned(K):
     with pytest.raises(ValueError):
         K.skinny_gemm(torch.zeros(4, 12).cuda(), torch.zeros(5, 12).cuda(), torch.zeros(4, 5).cuda(), tb=True)
     assert not K.skinny_ok(torch.zeros(4, 12).cuda(), torch.zeros(5, 12).cuda(), True)
-    assert not K.skinny_ok(torch.zeros(70, 16).cuda(), torch.zeros(5, 16).cuda(), True)
+    assert not K.skinny_ok(torch.zeros(300, 16).cuda(), torch.zeros(5, 16).cuda(), True)
 
 
 @pytest.mark.parametrize('B,H,Kx', [(64, 1024, 256), (64, 512, 0), (5, 24, 16), (33, 64, 32)])
@@ -353,7 +353,7 @@ def test_lstm_step_fwd(K, B, H, Kx):
         close(g_d, rg, rtol=1e-4); close(c_d, rc, rtol=1e-4); close(h_d, rh, rtol=1e-4)
 
 
-@pytest.mark.parametrize('T,B,H,ndir,ragged', [(128, 64, 512, 2, True), (5, 3, 8, 2, True), (7, 33, 24, 1, False),
+@pytest.mark.parametrize('T,B,H,ndir,ragged', [(128, 64, 512, 2, True), (16, 128, 64, 2, True), (5, 3, 8, 2, True), (7, 33, 24, 1, False),
                                                (1, 4, 16, 2, True)])
 def test_lstm_seq_fwd_bwd(K, T, B, H, ndir, ragged):
     gen = torch.Generator().manual_seed(15)
