@@ -61,6 +61,8 @@ SIGNATURES = {
     'ag_lstm_cell_bwd': (C.c_int, [vp, C.c_int, vp, C.c_int, vp, C.c_int, vp, C.c_int, vp, C.c_int,
                                    vp, C.c_int, vp, C.c_int, vp, C.c_int, vp, C.c_int, vp, C.c_int,
                                    C.c_int, C.c_int, vp]),
+    'ag_gru_cell_fwd': (C.c_int, [vp, vp, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp]),
+    'ag_gru_cell_bwd': (C.c_int, [vp, vp, vp, C.c_int, vp, C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
     'ag_skinny_gemm': (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int,
                                  f32, vp, C.c_int, f32, C.c_int, vp]),
     'ag_lstm_step_fwd': (C.c_int, [vp, vp, C.c_int, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_int,

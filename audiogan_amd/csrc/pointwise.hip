@@ -400,3 +400,69 @@ extern "C" int ag_opt_step(const ag_opt_desc* descs_dev, int n, const float* nor
   AG_CHECK_LAUNCH("ag_opt_step");
   return AG_OK;
 }
+
+// ------------------------------------------------------------------------------------------
+// GRU cell pointwise (BASELINE config C4; torch.nn.GRUCell semantics, gate order r|z|n):
+//   r = s(gi_r + gh_r), z = s(gi_z + gh_z), n = tanh(gi_n + r * gh_n), h' = (1-z) n + z h
+// gi = x W_ih^T + b_ih, gh = h W_hh^T + b_hh are complete on entry.  fwd overwrites gi with the
+// activated (r, z, n); gh keeps gh_n for backward.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gru_cell_fwd_kernel(float* __restrict__ gi, const float* __restrict__ gh,
+                                                           const float* __restrict__ h_prev, int ldhp,
+                                                           float* __restrict__ h_out, int ldh, int B, int H) {
+  const int j = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+  if (j >= H) return;
+  float* a = gi + (int64_t)b * 3 * H;
+  const float* c = gh + (int64_t)b * 3 * H;
+  const float r = ag_sigmoid(a[j] + c[j]);
+  const float z = ag_sigmoid(a[H + j] + c[H + j]);
+  const float n = tanhf(a[2 * H + j] + r * c[2 * H + j]);
+  const float hp = h_prev[(int64_t)b * ldhp + j];
+  a[j] = r;
+  a[H + j] = z;
+  a[2 * H + j] = n;
+  h_out[(int64_t)b * ldh + j] = (1.f - z) * n + z * hp;
+}
+
+extern "C" int ag_gru_cell_fwd(float* gi, const float* gh, const float* h_prev, int ldhp, float* h_out,
+                               int ldh, int B, int H, void* stream) {
+  AG_REQUIRE(gi && gh && h_prev && h_out && B > 0 && H > 0 && B <= 65535, "ag_gru_cell_fwd: bad args");
+  hipLaunchKernelGGL(gru_cell_fwd_kernel, dim3(ag_cdiv(H, 256), B), dim3(256), 0, (hipStream_t)stream, gi, gh,
+                     h_prev, ldhp, h_out, ldh, B, H);
+  AG_CHECK_LAUNCH("ag_gru_cell_fwd");
+  return AG_OK;
+}
+
+// dgi = (dr_pre, dz_pre, dn_pre), dgh = (dr_pre, dz_pre, dn_pre * r), dh_prev = dh * z (direct path)
+__global__ __launch_bounds__(256) void gru_cell_bwd_kernel(const float* __restrict__ ga, const float* __restrict__ gh,
+                                                           const float* __restrict__ h_prev, int ldhp,
+                                                           const float* __restrict__ dh, int lddh,
+                                                           float* __restrict__ dgi, float* __restrict__ dgh,
+                                                           float* __restrict__ dh_prev, int lddhp, int B, int H) {
+  const int j = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+  if (j >= H) return;
+  const float* a = ga + (int64_t)b * 3 * H;
+  const float r = a[j], z = a[H + j], n = a[2 * H + j];
+  const float hn = gh[(int64_t)b * 3 * H + 2 * H + j];
+  const float hp = h_prev[(int64_t)b * ldhp + j];
+  const float g = dh[(int64_t)b * lddh + j];
+  const float dn_pre = g * (1.f - z) * (1.f - n * n);
+  const float dz_pre = g * (hp - n) * z * (1.f - z);
+  const float dr_pre = dn_pre * hn * r * (1.f - r);
+  float* di = dgi + (int64_t)b * 3 * H;
+  float* dhh = dgh + (int64_t)b * 3 * H;
+  di[j] = dr_pre; di[H + j] = dz_pre; di[2 * H + j] = dn_pre;
+  dhh[j] = dr_pre; dhh[H + j] = dz_pre; dhh[2 * H + j] = dn_pre * r;
+  dh_prev[(int64_t)b * lddhp + j] = g * z;
+}
+
+extern "C" int ag_gru_cell_bwd(const float* gates_act, const float* gh, const float* h_prev, int ldhp,
+                               const float* dh, int lddh, float* dgi, float* dgh, float* dh_prev, int lddhp,
+                               int B, int H, void* stream) {
+  AG_REQUIRE(gates_act && gh && h_prev && dh && dgi && dgh && dh_prev && B > 0 && H > 0 && B <= 65535,
+             "ag_gru_cell_bwd: bad args");
+  hipLaunchKernelGGL(gru_cell_bwd_kernel, dim3(ag_cdiv(H, 256), B), dim3(256), 0, (hipStream_t)stream, gates_act,
+                     gh, h_prev, ldhp, dh, lddh, dgi, dgh, dh_prev, lddhp, B, H);
+  AG_CHECK_LAUNCH("ag_gru_cell_bwd");
+  return AG_OK;
+}

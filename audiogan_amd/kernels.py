@@ -605,3 +605,33 @@ def _work_seq_bwd(gates, whh, *a_, **kw):
 for _n, _w in (('skinny_gemm', _work_skinny), ('lstm_step_fwd', _work_step),
                ('_lstm_seq_fwd_range', _work_seq_fwd), ('_lstm_seq_bwd_range', _work_seq_bwd)):
     _instrument(_n, _w)
+
+
+# ------------------------------------------------------------------------------------
+# GRU cell pointwise (config C4)
+# ------------------------------------------------------------------------------------
+def gru_cell_fwd(gi, gh, h_prev, h_out):
+    """gi, gh: [B,3H] contiguous (complete products incl. biases); gi <- (r,z,n); h_out <- h'"""
+    for t_, n in ((gi, 'gi'), (gh, 'gh')):
+        _chk(t_, n)
+        assert t_.is_contiguous()
+    B, H3 = gi.shape
+    H = H3 // 3
+    assert tuple(gh.shape) == (B, H3) and tuple(h_prev.shape) == (B, H) and tuple(h_out.shape) == (B, H)
+    check(lib.ag_gru_cell_fwd(_p(gi), _p(gh), _p(h_prev), _mat(h_prev, 'h_prev'), _p(h_out), _mat(h_out, 'h_out'),
+                              B, H, _stream()), 'ag_gru_cell_fwd')
+
+
+def gru_cell_bwd(gates_act, gh, h_prev, dh, dgi, dgh, dh_prev):
+    for t_, n in ((gates_act, 'gates_act'), (gh, 'gh'), (dgi, 'dgi'), (dgh, 'dgh')):
+        _chk(t_, n)
+        assert t_.is_contiguous()
+    B, H3 = gates_act.shape
+    H = H3 // 3
+    check(lib.ag_gru_cell_bwd(_p(gates_act), _p(gh), _p(h_prev), _mat(h_prev, 'h_prev'), _p(dh), _mat(dh, 'dh'),
+                              _p(dgi), _p(dgh), _p(dh_prev), _mat(dh_prev, 'dh_prev'), B, H, _stream()),
+          'ag_gru_cell_bwd')
+
+
+for _n in ('gru_cell_fwd', 'gru_cell_bwd'):
+    _instrument(_n, None)

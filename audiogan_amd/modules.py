@@ -81,6 +81,11 @@ class WNLSTMCell(_WNModule):
         super().__init__(nn.LSTMCell(fin, hidden), ['weight_ih', 'weight_hh', 'bias_hh', 'bias_ih'])
 
 
+class WNGRUCell(_WNModule):
+    def __init__(self, fin, hidden):
+        super().__init__(nn.GRUCell(fin, hidden), ['weight_ih', 'weight_hh', 'bias_hh', 'bias_ih'])
+
+
 class Residual(nn.Module):
     """audiogan.py:256-264 (parameters only; computed inside ops.DHeadFn)."""
 
@@ -151,6 +156,9 @@ class Generator(nn.Module):
         _add(self._trunk.group, fin, 'weight', stride=1, engine=True)
         _add(self._trunk.group, fin, 'bias')
 
+    def _front_apply(self, zc):
+        return ops.GFrontFn.apply(zc, self._front, *self._front.group.params())
+
     def forward(self, batch_size=None, length=None, z=None, c=None, stop=None):
         fs, ns, es = self._frame_size, self._noise_size, self._embed_size
         dev = c.device
@@ -160,7 +168,7 @@ class Generator(nn.Module):
         else:
             batch_size, nframes, _ = z.size()
         zc = torch.cat([z, c.unsqueeze(1).expand(batch_size, nframes, es)], 2).transpose(0, 1).contiguous()
-        x, s = ops.GFrontFn.apply(zc, self._front, *self._front.group.params())
+        x, s = self._front_apply(zc)
 
         if isinstance(stop, str):
             assert stop == 'never'
@@ -275,3 +283,23 @@ class Embedder(nn.Module):
         fwd = seq[idx, torch.arange(b, device=dev), :h]
         bwd = seq[0, :, h:]
         return torch.cat([fwd, bwd], 1)
+
+
+class GRUGenerator(Generator):
+    """BASELINE config C4: the Generator of audiogan.py:361-468 with the LSTMCell of its frame loop
+    (:377-386, :437-443) replaced by a GRU cell (one layer).  The reference contains no GRU
+    (SURVEY.md F5): parity is against torch.nn.GRUCell via oracle.GRUGenerator, not the reference."""
+
+    def __init__(self, frame_size=200, embed_size=200, noise_size=100, state_size=1024,
+                 struct=((17, 8, 128, 16), (9, 4, 64, 32), (9, 4, 64, 32), (9, 4, 32, 32))):
+        super().__init__(frame_size, embed_size, noise_size, state_size, 1, struct)
+        self.rnn = nn.ModuleList([Replicated(WNGRUCell(frame_size + embed_size + noise_size, state_size))])
+        self._front = ops.GRUFront(frame_size, state_size)
+        for n in ('weight_ih', 'weight_hh', 'bias_ih', 'bias_hh'):
+            _add(self._front.group, self.rnn[0].module, n)
+        for lin in (self.proj.module, self.stopper.module):
+            _add(self._front.group, lin, 'weight')
+            _add(self._front.group, lin, 'bias')
+
+    def _front_apply(self, zc):
+        return ops.GRUFrontFn.apply(zc, self._front, *self._front.group.params())

@@ -20,15 +20,16 @@ from .common import PARAM_EPOCH, Prepared, WNGroup, _zeros_like_list  # noqa: F4
 
 class ConvSpec(object):
     """kind 'conv': weight [Cout,Cin,K] (NN.Conv1d); 'convT': weight [Cin,Cout,K] (NN.ConvTranspose1d)."""
-    __slots__ = ('kind', 'cin', 'cout', 'K', 'stride', 'pad')
+    __slots__ = ('kind', 'cin', 'cout', 'K', 'stride', 'pad', 'out_pad')
 
-    def __init__(self, kind, cin, cout, K_, stride, pad):
+    def __init__(self, kind, cin, cout, K_, stride, pad, out_pad=0):
         self.kind, self.cin, self.cout, self.K, self.stride, self.pad = kind, cin, cout, K_, stride, pad
+        self.out_pad = out_pad      # ConvTranspose1d output_padding (extra positions on the right)
 
     def out_len(self, lin):
         if self.kind == 'conv':
             return (lin + 2 * self.pad - self.K) // self.stride + 1
-        return (lin - 1) * self.stride - 2 * self.pad + self.K
+        return (lin - 1) * self.stride - 2 * self.pad + self.K + self.out_pad
 
 
 # --------------------------------------------------------------------------------------
@@ -273,7 +274,7 @@ class DHeadFn(torch.autograd.Function):
         return (da if ctx.needs_input_grad[0] else None, None) + tuple(grads)
 
 
-from .recurrent import LSTMSeqFn, GFront, GFrontFn  # noqa: E402,F401
+from .recurrent import LSTMSeqFn, GFront, GFrontFn, GRUFront, GRUFrontFn  # noqa: E402,F401
 
 
 # --------------------------------------------------------------------------------------

@@ -270,3 +270,98 @@ class GFrontFn(torch.autograd.Function):
             dzc = dzc.view(T, B, Fz)
         grads = front.group.backward(dws)
         return (dzc, None) + tuple(grads)
+
+
+# --------------------------------------------------------------------------------------
+# GRU variant of the generator front (BASELINE config C4; oracle = torch.nn.GRUCell because the
+# reference has no GRU).  One layer; same frame feedback as GFrontFn.
+# --------------------------------------------------------------------------------------
+class GRUFront(object):
+    """WN items: [w_ih, w_hh, b_ih, b_hh, proj.w, proj.b, stop.w, stop.b]"""
+
+    def __init__(self, frame_size, state_size):
+        self.fs, self.ss = frame_size, state_size
+        self.group = WNGroup()
+
+
+class GRUFrontFn(torch.autograd.Function):
+    """zc [T,B,Fz] -> x [B,T*fs], s [B,T];  frame t: h_t = GRUCell([x_{t-1}, zc_t], h_{t-1}),
+    x_t = tanh(proj(h_t)), s_t = stopper(h_t)."""
+
+    @staticmethod
+    def forward(ctx, zc, front, *params):
+        T, B, Fz = zc.shape
+        fs, S = front.fs, front.ss
+        dev = zc.device
+        ctx.set_materialize_grads(False)
+        w_ih, w_hh, b_ih, b_hh, pw, pb, sw, sb = [p.w for p in front.group.prepare()]
+        wx, wz = w_ih[:, :fs], w_ih[:, fs:]
+        x = torch.empty(B, T * fs, device=dev)
+        gi = torch.empty(T, B, 3 * S, device=dev)      # -> activated (r, z, n)
+        gh = torch.empty(T, B, 3 * S, device=dev)      # h-part incl. b_hh (n slot needed for backward)
+        hs = torch.empty(T + 1, B, S, device=dev)      # hs[t+1] = h_t, hs[0] = 0
+        hs[0].zero_()
+        K.gemm(zc.contiguous().view(T * B, Fz), wz, gi.view(T * B, 3 * S), tb=True, bias=b_ih)
+        for t in range(T):
+            if t > 0:
+                _small_acc(x[:, (t - 1) * fs:t * fs], wx, gi[t], tb=True)
+            _small(hs[t], w_hh, gh[t], tb=True, bias=b_hh)
+            K.gru_cell_fwd(gi[t], gh[t], hs[t], hs[t + 1])
+            _small(hs[t + 1], pw, x[:, t * fs:(t + 1) * fs], tb=True, bias=pb, act=ACT_TANH)
+        s = torch.empty(T * B, 1, device=dev)
+        K.gemm(hs[1:].view(T * B, S), sw, s, tb=True, bias=sb)
+        ctx.front, ctx.key, ctx.dims = front, front.group._key, (T, B, Fz)
+        ctx.save_for_backward(zc, x, gi, gh, hs)
+        return x, s.view(T, B).t()
+
+    @staticmethod
+    def backward(ctx, dx, ds):
+        front = ctx.front
+        fs, S = front.fs, front.ss
+        T, B, Fz = ctx.dims
+        prep = front.group.prepare()
+        assert front.group._key == ctx.key, 'parameters changed between forward and backward'
+        w_ih, w_hh, _, _, pw, _, sw, _ = [p.w for p in prep]
+        wx = w_ih[:, :fs]
+        zc, x, gi, gh, hs = ctx.saved_tensors
+        dev = zc.device
+        dws = _zeros_like_list([it['v'] for it in front.group.items])
+        dxa = dx.contiguous().clone() if dx is not None else torch.zeros(B, T * fs, device=dev)
+        dha = torch.zeros(T + 1, B, S, device=dev)     # dha[t+1] accumulates dL/dh_t
+        if ds is not None:
+            ds_tb = ds.t().contiguous().view(T * B, 1)
+            K.gemm(ds_tb, hs[1:].view(T * B, S), dws[6], ta=True)
+            K.col_sum(ds_tb, dws[7])
+            K.gemm(ds_tb, sw, dha[1:].view(T * B, S))
+        dgi = torch.empty(T, B, 3 * S, device=dev)
+        dgh = torch.empty(T, B, 3 * S, device=dev)
+        dxt = torch.empty(T, B, fs, device=dev)
+        xt_c = torch.empty(B, fs, device=dev)
+        dh_dir = torch.empty(B, S, device=dev)
+        for t in reversed(range(T)):
+            gx = dxt[t]
+            gx.copy_(dxa[:, t * fs:(t + 1) * fs])
+            xt_c.copy_(x[:, t * fs:(t + 1) * fs])
+            K.act_bwd(gx, xt_c, gx, ACT_TANH)
+            _small_acc(gx, pw, dha[t + 1])
+            K.gru_cell_bwd(gi[t], gh[t], hs[t], dha[t + 1], dgi[t], dgh[t], dh_dir)
+            K.axpby(dh_dir, dha[t], 1.0, 1.0)                     # direct path  dh * z
+            _small_acc(dgh[t], w_hh, dha[t])                      # through the hidden product
+            if t > 0:
+                _small_acc(dgi[t], wx, dxa[:, (t - 1) * fs:t * fs])
+        dxt2, dgi2, dgh2 = dxt.view(T * B, fs), dgi.view(T * B, 3 * S), dgh.view(T * B, 3 * S)
+        K.gemm(dxt2, hs[1:].view(T * B, S), dws[4], ta=True)
+        K.col_sum(dxt2, dws[5])
+        K.gemm(dgi2, zc.contiguous().view(T * B, Fz), dws[0][:, fs:], ta=True)
+        if T > 1:
+            xprev = x.view(B, T, fs)[:, :T - 1].transpose(0, 1).contiguous().view((T - 1) * B, fs)
+            K.gemm(dgi[1:].view((T - 1) * B, 3 * S), xprev, dws[0][:, :fs], ta=True)
+        K.gemm(dgh2, hs[:T].view(T * B, S), dws[1], ta=True)
+        K.col_sum(dgi2, dws[2])
+        K.col_sum(dgh2, dws[3])
+        dzc = None
+        if ctx.needs_input_grad[0]:
+            dzc = torch.empty(T * B, Fz, device=dev)
+            K.gemm(dgi2, w_ih[:, fs:], dzc)
+            dzc = dzc.view(T, B, Fz)
+        return (dzc, None) + tuple(front.group.backward(dws))

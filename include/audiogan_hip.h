@@ -174,6 +174,16 @@ int ag_lstm_cell_bwd(const float* gates_act, int ldg, const float* c_prev, int l
                      float* dc_prev, int lddcp, float* dh_pass, int lddhp, const int64_t* valid_i64,
                      int t, int B, int H, void* stream);
 
+/* GRU cell pointwise step (BASELINE config C4; the reference has no GRU -- SURVEY.md F5 -- so the
+ * contract is torch.nn.GRUCell's: gate order r|z|n, n = tanh(gi_n + r * gh_n)).  gi [B,3H] and
+ * gh [B,3H] (contiguous) hold the complete input / hidden products incl. biases; fwd overwrites gi
+ * with the activated (r,z,n), gh keeps gh_n.  bwd writes dgi, dgh and dh_prev = dh * z. */
+int ag_gru_cell_fwd(float* gi, const float* gh, const float* h_prev, int ldhp, float* h_out, int ldh,
+                    int B, int H, void* stream);
+int ag_gru_cell_bwd(const float* gates_act, const float* gh, const float* h_prev, int ldhp,
+                    const float* dh, int lddh, float* dgi, float* dgh, float* dh_prev, int lddhp, int B,
+                    int H, void* stream);
+
 /* Skinny product for the sequential part of the recurrent layers (M = clips per call <= 256):
  *   C[M,N] = act(A[M,K] * op(B) + beta*C + bias)         (accumulate_atomic == 0)
  *   C[M,N] += A[M,K] * op(B) (+ bias)   K split over workgroups, fp32 atomics  (== 1)

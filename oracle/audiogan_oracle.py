@@ -331,6 +331,37 @@ class Discriminator(nn.Module):
         return logits, acts, act_lens, nframes
 
 
+class GRUGenerator(Generator):
+    """Config C4: Generator (audiogan.py:361-468) with the LSTMCell of the frame loop replaced by
+    torch.nn.GRUCell.  UNPINNED: the reference has no GRU anywhere."""
+
+    def __init__(self, frame_size=200, embed_size=200, noise_size=100, state_size=1024,
+                 struct=((17, 8, 128, 16), (9, 4, 64, 32), (9, 4, 64, 32), (9, 4, 32, 32))):
+        super().__init__(frame_size, embed_size, noise_size, state_size, 1, struct)
+        self.rnn = nn.ModuleList([Replicated(weight_norm(
+            nn.GRUCell(frame_size + embed_size + noise_size, state_size),
+            ['weight_ih', 'weight_hh', 'bias_hh', 'bias_ih']))])
+
+    def forward(self, batch_size=None, length=None, z=None, c=None, stop=None):
+        fs, ns, ss, es = self._frame_size, self._noise_size, self._state_size, self._embed_size
+        batch_size, nframes, _ = z.size()
+        zc = torch.cat([z, c.unsqueeze(1).expand(batch_size, nframes, es)], 2)
+        h = torch.zeros(batch_size, ss)
+        x_t = torch.zeros(batch_size, fs)
+        xs, logits = [], []
+        for t in range(nframes):
+            h = self.rnn[0](torch.cat([x_t, zc[:, t]], 1), h)
+            x_t = torch.tanh(self.proj(h))
+            xs.append(x_t)
+            logits.append(self.stopper(h).squeeze(1))
+        x = torch.cat(xs, 1).unsqueeze(1)
+        for layer in self.dense_res_gen:
+            x_next = layer(x)
+            x = torch.cat([x, x_next], 1)
+        return (x_next.squeeze(1), torch.stack(logits, 1), None,
+                torch.full((batch_size,), nframes * fs, dtype=torch.long))
+
+
 # --------------------------------------------------------------------------
 # C1 "tiny conv" G/D.  Spec: modeltf.py:256-286 and :578-595 restated in PyTorch
 # conventions (SURVEY.md section 8, C1 row).  UNPINNED: TensorFlow-only in the

@@ -355,5 +355,29 @@ def lstm_seq_bwd(gates, whh, c_all, dy, dgates, dhbuf, dcbuf, valid):
                 dpass.add_(dgates[d][t] @ whh[d])
 
 
+def gru_cell_fwd(gi, gh, h_prev, h_out):
+    B, H3 = gi.shape
+    H = H3 // 3
+    r = torch.sigmoid(gi[:, :H] + gh[:, :H])
+    z = torch.sigmoid(gi[:, H:2 * H] + gh[:, H:2 * H])
+    n = torch.tanh(gi[:, 2 * H:] + r * gh[:, 2 * H:])
+    hn = (1 - z) * n + z * h_prev
+    gi.copy_(torch.cat([r, z, n], 1))
+    h_out.copy_(hn)
+
+
+def gru_cell_bwd(gates_act, gh, h_prev, dh, dgi, dgh, dh_prev):
+    B, H3 = gates_act.shape
+    H = H3 // 3
+    r, z, n = gates_act[:, :H], gates_act[:, H:2 * H], gates_act[:, 2 * H:]
+    hn = gh[:, 2 * H:]
+    dn_pre = dh * (1 - z) * (1 - n * n)
+    dz_pre = dh * (h_prev - n) * z * (1 - z)
+    dr_pre = dn_pre * hn * r * (1 - r)
+    dgi.copy_(torch.cat([dr_pre, dz_pre, dn_pre], 1))
+    dgh.copy_(torch.cat([dr_pre, dz_pre, dn_pre * r], 1))
+    dh_prev.copy_(dh * z)
+
+
 ALL = [n for n, v in list(globals().items()) if callable(v) and not n.startswith('_')
        and n not in ('F', 'install')]

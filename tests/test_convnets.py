@@ -1,0 +1,92 @@
+"""C1 tiny conv G/D and the WGAN-GP critic (hand-written double backward) vs the oracle.
+Runs on CPU with the kernel model (host logic) and, marked gpu, on the real kernels."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import audiogan_oracle as O
+from tests import kernel_model
+
+
+def _run(dev, A):
+    torch.manual_seed(31)
+    # ---- C1: tiny conv generator / discriminator, B=4, L=1024 sine clips
+    go, do = O.Conv1DGenerator(), O.Conv1DDiscriminator()
+    g, d = A.Conv1DGenerator(), A.Conv1DDiscriminator()
+    g.load_state_dict(go.state_dict()); d.load_state_dict(do.state_dict())
+    g.to(dev); d.to(dev)
+    z = torch.randn(4, 1024 // go.multiplier)
+    real = torch.from_numpy(O.synthetic_clips(4, 1024, 'sine')).float()
+    xo = go(z=z)
+    x = g(z=z.to(dev))
+    assert x.shape == (4, 1024)
+    np.testing.assert_allclose(x.detach().cpu().numpy(), xo.detach().numpy(), rtol=1e-3, atol=1e-5)
+    so, s = do(torch.cat([xo, real])), d(torch.cat([x, real.to(dev)]))
+    np.testing.assert_allclose(s.detach().cpu().numpy(), so.detach().numpy(), rtol=1e-3, atol=1e-5)
+    w = torch.randn(8)
+    (so * w).sum().backward(); (s * w.to(dev)).sum().backward()
+    for a, b in ((g, go), (d, do)):
+        for (k, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):
+            np.testing.assert_allclose(p.grad.cpu().numpy(), q.grad.numpy(), rtol=1e-3,
+                                       atol=1e-5 * max(1.0, float(q.grad.abs().max())), err_msg=k)
+    # ---- WGAN-GP on the conv critic (C5), small stack
+    struct = [[7, 2, 4], [7, 2, 8], [5, 2, 8]]
+    co = O.Conv1DDiscriminator(config=[(c, k, s) for k, s, c in struct])
+    cr = A.ConvPoolCritic(cnn_struct=struct)
+    cr.load_state_dict(co.state_dict()); cr.to(dev)
+    xr, xf, eps = torch.randn(5, 256), torch.randn(5, 256), torch.rand(5, 1)
+    lo = O.wgan_gp_d_loss(lambda t: co(t), xr, xf, eps, lam=10.0)
+    l = A.wgan_gp_d_loss(cr, xr.to(dev), xf.to(dev), eps.to(dev), lam=10.0)
+    np.testing.assert_allclose(float(l), float(lo), rtol=1e-3)
+    lo.backward(); l.backward()
+    for (k, p), (_, q) in zip(cr.named_parameters(), co.named_parameters()):
+        np.testing.assert_allclose(p.grad.cpu().numpy(), q.grad.numpy(), rtol=2e-3,
+                                   atol=2e-5 * max(1.0, float(q.grad.abs().max())), err_msg=k)
+    np.testing.assert_allclose(float(A.wgan_g_loss(cr, xf.to(dev))), float(O.wgan_g_loss(lambda t: co(t), xf)),
+                               rtol=1e-3, atol=1e-6)
+
+
+def test_convnets_host_logic(monkeypatch):
+    kernel_model.install(monkeypatch)
+    import audiogan_amd as A
+    _run(torch.device('cpu'), A)
+
+
+@pytest.mark.gpu
+def test_convnets_gpu():
+    import audiogan_amd as A
+    _run(torch.device('cuda'), A)
+
+
+def _run_gru(dev, A):
+    """config C4: GRU generator (vs torch.nn.GRUCell via the oracle) + conv critic"""
+    torch.manual_seed(41)
+    cfg = dict(frame_size=32, embed_size=8, noise_size=8, state_size=64, struct=[[17, 8, 16, 8], [9, 4, 16, 8]])
+    go, g = O.GRUGenerator(**cfg), A.GRUGenerator(**cfg)
+    assert list(g.state_dict().keys()) == list(go.state_dict().keys())
+    g.load_state_dict(go.state_dict()); g.to(dev)
+    z, c = torch.randn(5, 4, 8), torch.randn(5, 8)
+    xo, so, _, _ = go(z=z, c=c)
+    x, s, _, ln = g(z=z.to(dev), c=c.to(dev), stop='never')
+    np.testing.assert_allclose(x.detach().cpu().numpy(), xo.detach().numpy(), rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(s.detach().cpu().numpy(), so.detach().numpy(), rtol=1e-3, atol=1e-5)
+    w, w2 = torch.randn(xo.shape), torch.randn(so.shape)
+    ((xo * w).sum() + (so * w2).sum()).backward()
+    ((x * w.to(dev)).sum() + (s * w2.to(dev)).sum()).backward()
+    for (k, p), (_, q) in zip(g.named_parameters(), go.named_parameters()):
+        if k.split('.')[-1].startswith('bias') and k.endswith('_v'):
+            continue
+        np.testing.assert_allclose(p.grad.cpu().numpy(), q.grad.numpy(), rtol=2e-3,
+                                   atol=2e-5 * max(1.0, float(q.grad.abs().max())), err_msg=k)
+
+
+def test_gru_generator_host_logic(monkeypatch):
+    kernel_model.install(monkeypatch)
+    import audiogan_amd as A
+    _run_gru(torch.device('cpu'), A)
+
+
+@pytest.mark.gpu
+def test_gru_generator_gpu():
+    import audiogan_amd as A
+    _run_gru(torch.device('cuda'), A)

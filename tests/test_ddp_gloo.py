@@ -1,0 +1,96 @@
+"""N>1 path on CPU: 2 processes, gloo backend, kernels replaced by the torch model.  Two ranks that
+each see half of the batch must end up with the same parameters as one process that sees all of it
+(flat gradient bucket -> one sum all-reduce per network -> 1/world folded into the optimiser)."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _setup_models():
+    from oracle import audiogan_oracle as O  # noqa: F401
+    import audiogan_amd as A
+    torch.manual_seed(5)
+    g = A.Generator(16, 6, 5, 24, 1, struct=[[9, 4, 8, 4], [9, 4, 8, 4]])
+    d = A.Discriminator(16, 6, 1, cnn_struct=[[7, 2, 4], [7, 2, 8]])
+    return A, g, d
+
+
+def _batch(B):
+    gen = torch.Generator().manual_seed(9)
+    T, fs = 4, 16
+    return dict(real=torch.randn(B, T * fs, generator=gen), real_len=torch.full((B,), T * fs, dtype=torch.long),
+                c=torch.randn(B, 6, generator=gen), z=torch.randn(B, T, 5, generator=gen),
+                nr=torch.randn(B, T * fs, generator=gen) * 0.01, nf=torch.randn(B, T * fs, generator=gen) * 0.01)
+
+
+def _install_model():
+    import audiogan_amd.kernels as K
+    from tests import kernel_model as KM
+    for n in KM.ALL:
+        setattr(K, n, getattr(KM, n))
+
+
+def _steps(A, g, d, b, buckets=False):
+    from audiogan_amd import optim, train, ddp
+    og, od = optim.RMSprop(list(g.parameters()), lr=1e-3), optim.RMSprop(list(d.parameters()), lr=1e-3)
+    hd = hg = None
+    if buckets:
+        ddp.broadcast_parameters(g); ddp.broadcast_parameters(d)
+        bd, bg = ddp.GradBucket(list(d.parameters())), ddp.GradBucket(list(g.parameters()))
+        od.bucket, og.bucket = bd, bg
+        hd, hg = bd.all_reduce, bg.all_reduce
+    for _ in range(2):
+        train.d_step(g, d, od, b['real'], b['real_len'], b['c'], b['z'], b['nr'], b['nf'], 1.0, grad_hook=hd)
+        train.g_step(g, d, og, b['c'], b['z'], b['nf'], 0.1, grad_hook=hg)
+        if buckets:
+            assert bd.check_views() and bg.check_views(), 'autograd must accumulate into the flat bucket'
+    return {k: v.clone() for k, v in list(g.state_dict().items()) + list(d.state_dict().items())}
+
+
+def _worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    import warnings
+    warnings.filterwarnings('ignore')
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    _install_model()
+    A, g, d = _setup_models()
+    if rank == 1:      # rank 1 starts from different weights: broadcast must fix that
+        with torch.no_grad():
+            for p in list(g.parameters()) + list(d.parameters()):
+                p.add_(0.1)
+    full = _batch(4)
+    half = {k: v[rank * 2:(rank + 1) * 2] for k, v in full.items()}
+    sd = _steps(A, g, d, half, buckets=True)
+    torch.save(sd, os.path.join(out, 'rank%d.pt' % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_equal_one_process(tmp_path):
+    port = 29500 + (os.getpid() % 2000)
+    mp.start_processes(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True, start_method='spawn')
+    r0, r1 = torch.load(os.path.join(tmp_path, 'rank0.pt')), torch.load(os.path.join(tmp_path, 'rank1.pt'))
+    for k in r0:
+        np.testing.assert_array_equal(r0[k].numpy(), r1[k].numpy(), err_msg='ranks diverged: ' + k)
+    sys.path.insert(0, ROOT)
+    _install_model_local = _install_model
+    import audiogan_amd.kernels as K
+    saved = {n: getattr(K, n) for n in dir(K)}
+    try:
+        _install_model_local()
+        A, g, d = _setup_models()
+        ref = _steps(A, g, d, _batch(4), buckets=False)
+    finally:
+        for n, v in saved.items():
+            setattr(K, n, v)
+    for k in ref:
+        if k.split('.')[-1].startswith('bias') and k.endswith('_v'):
+            continue   # rounding-noise gradients, see DESIGN.md section 2
+        np.testing.assert_allclose(r0[k].numpy(), ref[k].numpy(), rtol=2e-3, atol=2e-5, err_msg=k)
