@@ -17,30 +17,104 @@ struct WgP {
   int64_t sh_bs, sh_cs, lg_bs, lg_cs;
   int B, A, Lsh, C, Llg, K, s, p;
   int CK;       // C*K
-  int TC;       // time chunk (even)
+  int TC;       // time chunk (multiple of 4)
   int nchunk;   // chunks per clip
-  int shp;      // LDS pitch of the sh tile (odd)
   int lgp;      // LDS pitch of one lg channel row (odd)
   int maxch;    // channel rows staged per tile
+  int vec;      // sh rows may be read with 16-byte loads
 };
 
+// 8 waves: waves 0-3 multiply chunk i out of LDS buffer i&1 while waves 4-7 stage chunk i+1.
+// LDS: sh tile TRANSPOSED [TC][AT+1] (MFMA A operand = unit-stride read), lg rows [maxch][lgp].
 template <int TA, int TN, int WA, int WN>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgP p) {
-  static_assert(WA * WN == 4, "4 waves");
+__global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgP p) {
+  static_assert(WA * WN == 4, "4 compute waves");
   constexpr int AT = 32 * TA * WA, NT = 32 * TN * WN;
+  constexpr int SP = AT + 1;
   extern __shared__ float smem[];
-  float* shs = smem;                          // [AT][shp]
-  float* lgs = smem + (size_t)AT * p.shp;     // [maxch][lgp]
+  const size_t bufsz = (size_t)p.TC * SP + (size_t)p.maxch * p.lgp;
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l31 = lane & 31, h = lane >> 5;
-  const int wa = wid / WN, wn = wid % WN;
+  const int cw = wid & 3;
+  const int wa = cw / WN, wn = cw % WN;
   const int a0 = blockIdx.y * AT, ck0 = blockIdx.x * NT;
   const int c_lo = ck0 / p.K;
   int c_hi = (ck0 + NT - 1) / p.K;
   if (c_hi >= p.C) c_hi = p.C - 1;
   const int nch = c_hi - c_lo + 1;
   const int span = p.s * (p.TC - 1) + p.K;
+  const int total = p.B * p.nchunk;
+  const int nmine = (total - (int)blockIdx.z + (int)gridDim.z - 1) / (int)gridDim.z;   // chunks of this block
+
+  auto stage = [&](int ch, int buf, int sw, int nsw) {
+    float* shs = smem + buf * bufsz;
+    float* lgs = shs + (size_t)p.TC * SP;
+    const int b = ch / p.nchunk;
+    const int t0 = (ch - b * p.nchunk) * p.TC;
+    const float* sb = p.sh + (int64_t)b * p.sh_bs;
+    const float* lb = p.lg + (int64_t)b * p.lg_bs;
+    const int g0 = p.s * t0 - p.p;
+    const int q4 = p.TC >> 2;                 // float4 per sh row
+    const int stot = AT * q4, ltot = nch * span, step = nsw * 64;
+    constexpr int US = 4, UL = 4;
+    int se = sw * 64 + lane, le = se;
+    while (se < stot || le < ltot) {
+      f32x4 sv[US];
+      float lv[UL];
+#pragma unroll
+      for (int u = 0; u < US; ++u) {
+        const int e = se + u * step;
+        sv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (e < stot) {
+          const int r = e / q4, q = e - r * q4;
+          const int a = a0 + r, tg = t0 + 4 * q;
+          if (a < p.A) {
+            const float* src = sb + (int64_t)a * p.sh_cs + tg;
+            if (p.vec && tg + 3 < p.Lsh) {
+              sv[u] = *reinterpret_cast<const f32x4*>(src);
+            } else {
+#pragma unroll
+              for (int x = 0; x < 4; ++x)
+                if (tg + x < p.Lsh) sv[u][x] = src[x];
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < UL; ++u) {
+        const int e = le + u * step;
+        lv[u] = 0.f;
+        if (e < ltot) {
+          const int r = e / span, i = e - r * span;
+          const int g = g0 + i;
+          if (g >= 0 && g < p.Llg) lv[u] = lb[(int64_t)(c_lo + r) * p.lg_cs + g];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < US; ++u) {
+        const int e = se + u * step;
+        if (e < stot) {
+          const int r = e / q4, q = e - r * q4;
+#pragma unroll
+          for (int x = 0; x < 4; ++x) shs[(4 * q + x) * SP + r] = sv[u][x];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < UL; ++u) {
+        const int e = le + u * step;
+        if (e < ltot) {
+          const int r = e / span, i = e - r * span;
+          lgs[r * p.lgp + i] = lv[u];
+        }
+      }
+      se += US * step;
+      le += UL * step;
+    }
+  };
+
+  if (nmine > 0) stage(blockIdx.z, 0, wid, 8);
+  __syncthreads();
 
   // per-lane column constants
   int joff[TN];
@@ -53,7 +127,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgP p) {
     const int k = jok[j] ? ck - c * p.K : 0;
     joff[j] = (c - c_lo) * p.lgp + k + p.s * h;
   }
-
   f32x16 acc[TA][TN];
 #pragma unroll
   for (int i = 0; i < TA; ++i)
@@ -62,42 +135,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgP p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  const int total = p.B * p.nchunk;
-  for (int ch = blockIdx.z; ch < total; ch += gridDim.z) {
-    const int b = ch / p.nchunk;
-    const int t0 = (ch - b * p.nchunk) * p.TC;
-    __syncthreads();
-    // stage sh tile: rows a0..a0+AT, cols t0..t0+TC (zero outside)
-    {
-      const float* sb = p.sh + (int64_t)b * p.sh_bs;
-      for (int r = wid; r < AT; r += 4) {
-        const int a = a0 + r;
-        const bool aok = a < p.A;
-        const float* sr = sb + (int64_t)a * p.sh_cs;
-        for (int t = lane; t < p.TC; t += 64) {
-          const int tg = t0 + t;
-          shs[r * p.shp + t] = (aok && tg < p.Lsh) ? sr[tg] : 0.f;
-        }
-      }
+  for (int ci = 0; ci < nmine; ++ci) {
+    if (wid >= 4) {
+      if (ci + 1 < nmine) stage(blockIdx.z + (ci + 1) * gridDim.z, (ci + 1) & 1, cw, 4);
+      __syncthreads();
+      continue;
     }
-    // stage lg rows: channels c_lo..c_hi, positions s*t0-p .. +span
-    {
-      const float* lb = p.lg + (int64_t)b * p.lg_bs;
-      const int g0 = p.s * t0 - p.p;
-      for (int r = wid; r < nch; r += 4) {
-        const float* lr = lb + (int64_t)(c_lo + r) * p.lg_cs;
-        for (int i = lane; i < span; i += 64) {
-          const int g = g0 + i;
-          lgs[r * p.lgp + i] = (g >= 0 && g < p.Llg) ? lr[g] : 0.f;
-        }
-      }
-    }
-    __syncthreads();
-    const float* arow = shs + (wa * 32 * TA + l31) * p.shp + h;
+    const float* shs = smem + (ci & 1) * bufsz;
+    const float* lgs = shs + (size_t)p.TC * SP;
+    const float* arow = shs + h * SP + wa * 32 * TA + l31;
     for (int t = 0; t < p.TC; t += 2) {
       float av[TA], bv[TN];
 #pragma unroll
-      for (int i = 0; i < TA; ++i) av[i] = arow[32 * i * p.shp + t];
+      for (int i = 0; i < TA; ++i) av[i] = arow[t * SP + 32 * i];
 #pragma unroll
       for (int j = 0; j < TN; ++j) bv[j] = jok[j] ? lgs[joff[j] + p.s * t] : 0.f;
 #pragma unroll
@@ -106,7 +156,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgP p) {
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
     }
+    __syncthreads();
   }
+  if (wid >= 4) return;
 
 #pragma unroll
   for (int i = 0; i < TA; ++i)
@@ -125,29 +177,28 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgP p) {
 template <int TA, int TN, int WA, int WN>
 static int launch_wgrad(WgP& p, hipStream_t st) {
   constexpr int AT = 32 * TA * WA, NT = 32 * TN * WN;
-  p.TC = 64;
-  if (p.Lsh < 64) p.TC = ag_roundup(p.Lsh, 2);
+  p.TC = AT >= 128 ? 32 : 64;   // keeps two LDS buffers of the 128x128 tile under 48 KiB (>= 2 workgroups per CU)
+  if (p.Lsh < p.TC) p.TC = ag_roundup(p.Lsh, 4);
   p.nchunk = ag_cdiv(p.Lsh, p.TC);
-  p.shp = p.TC + 1;
   const int span = p.s * (p.TC - 1) + p.K;
   p.lgp = span | 1;
   p.maxch = (NT - 1) / p.K + 2;
   if (p.maxch > p.C) p.maxch = p.C;
-  const size_t lds = ((size_t)AT * p.shp + (size_t)p.maxch * p.lgp) * sizeof(float);
+  const size_t lds = 2 * ((size_t)p.TC * (AT + 1) + (size_t)p.maxch * p.lgp) * sizeof(float);
   if (lds > 160 * 1024) {
     ag_set_error("conv wgrad: tile needs %zu B of LDS", lds);
     return AG_ERR_UNSUPPORTED;
   }
   const int gx = ag_cdiv(p.CK, NT), gy = ag_cdiv(p.A, AT);
   const int total = p.B * p.nchunk;
-  int gz = ag_cdiv(2048, gx * gy);  // ~8 workgroups per CU over the whole grid
+  int gz = ag_cdiv(1024, gx * gy);  // ~4 workgroups of 8 waves per CU over the whole grid
   if (gz > total) gz = total;
   if (gz < 1) gz = 1;
   auto kern = conv_wgrad_kernel<TA, TN, WA, WN>;
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds);
-  hipLaunchKernelGGL(kern, dim3(gx, gy, gz), dim3(256), lds, st, p);
+  hipLaunchKernelGGL(kern, dim3(gx, gy, gz), dim3(512), lds, st, p);
   AG_CHECK_LAUNCH("ag_conv1d_wgrad");
   return AG_OK;
 }
@@ -163,6 +214,7 @@ extern "C" int ag_conv1d_wgrad(const float* sh, int64_t sh_bs, int64_t sh_cs, co
   p.sh_bs = sh_bs; p.sh_cs = sh_cs; p.lg_bs = lg_bs; p.lg_cs = lg_cs;
   p.B = B; p.A = A; p.Lsh = Lsh; p.C = C; p.Llg = Llg; p.K = K; p.s = stride; p.p = pad;
   p.CK = C * K;
+  p.vec = (((uintptr_t)sh & 15) == 0) && (sh_bs % 4 == 0) && (sh_cs % 4 == 0);
   hipStream_t st = (hipStream_t)stream;
   if (A <= 32) return launch_wgrad<1, 1, 1, 4>(p, st);             // 32 x 128
   if (A <= 64 || p.CK <= 64) return launch_wgrad<1, 1, 2, 2>(p, st);  // 64 x 64

@@ -403,8 +403,9 @@ __global__ __launch_bounds__(256) void lstm_cell_bwd2_kernel(const CellBwd2P p) 
 extern "C" int ag_lstm_seq_bwd(const float* const* gates, const float* const* whh,
                                const float* const* c_all, const float* dy, float* const* dgates,
                                float* const* dhbuf, float* const* dcbuf, const int64_t* valid_i64, int T,
-                               int B, int H, int ndir, int k_begin, int k_end, void* stream) {
+                               int B, int H, int ndir, int k_begin, int k_end, int phases, void* stream) {
   AG_REQUIRE(gates && whh && c_all && dy && dgates && dhbuf && dcbuf, "ag_lstm_seq_bwd: null table");
+  AG_REQUIRE(phases >= 1 && phases <= 3, "ag_lstm_seq_bwd: phases is a bit mask (1 cell, 2 product)");
   AG_REQUIRE(ndir == 1 || ndir == 2, "ag_lstm_seq_bwd: ndir must be 1 or 2");
   AG_REQUIRE(T > 0 && B > 0 && B <= 256 && (4 * H) % 8 == 0, "ag_lstm_seq_bwd: bad shape");
   AG_REQUIRE(0 <= k_begin && k_begin <= k_end && k_end <= T, "ag_lstm_seq_bwd: bad step range");
@@ -433,9 +434,11 @@ extern "C" int ag_lstm_seq_bwd(const float* const* gates, const float* const* wh
       s.q[d].A = D.dgates; s.q[d].B = whh[d]; s.q[d].C = D.dh_pass; s.q[d].bias = nullptr;
     }
     if (ndir == 1) { c.d[1] = c.d[0]; s.q[1] = s.q[0]; }
-    hipLaunchKernelGGL(lstm_cell_bwd2_kernel, dim3(ag_cdiv(H, 256), B, ndir), dim3(256), 0, st, c);
-    AG_CHECK_LAUNCH("ag_lstm_seq_bwd(cell)");
-    if (k > 0) {
+    if (phases & 1) {
+      hipLaunchKernelGGL(lstm_cell_bwd2_kernel, dim3(ag_cdiv(H, 256), B, ndir), dim3(256), 0, st, c);
+      AG_CHECK_LAUNCH("ag_lstm_seq_bwd(cell)");
+    }
+    if (k > 0 && (phases & 2)) {
       int rc = launch_skinny(s, ndir, 1, st);
       if (rc != AG_OK) return rc;
     }

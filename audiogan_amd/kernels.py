@@ -556,12 +556,22 @@ def lstm_seq_bwd(gates, whh, c_all, dy, dgates, dhbuf, dcbuf, valid):
     T = gates[0].size(0)
     if Profiler.enabled:
         for k_ in reversed(range(T)):
-            _lstm_seq_bwd_range(gates, whh, c_all, dy, dgates, dhbuf, dcbuf, valid, k_, k_ + 1)
+            _lstm_seq_bwd_cell(gates, whh, c_all, dy, dgates, dhbuf, dcbuf, valid, k_, k_ + 1, 1)
+            if k_ > 0:
+                _lstm_seq_bwd_prod(gates, whh, c_all, dy, dgates, dhbuf, dcbuf, valid, k_, k_ + 1, 2)
     else:
         _lstm_seq_bwd_range(gates, whh, c_all, dy, dgates, dhbuf, dcbuf, valid, 0, T)
 
 
-def _lstm_seq_bwd_range(gates, whh, c_all, dy, dgates, dhbuf, dcbuf, valid, k0, k1):
+def _lstm_seq_bwd_cell(*a):
+    _lstm_seq_bwd_range(*a)
+
+
+def _lstm_seq_bwd_prod(*a):
+    _lstm_seq_bwd_range(*a)
+
+
+def _lstm_seq_bwd_range(gates, whh, c_all, dy, dgates, dhbuf, dcbuf, valid, k0, k1, phases=3):
     ndir = len(gates)
     T, B, H4 = gates[0].shape
     H = H4 // 4
@@ -574,7 +584,7 @@ def _lstm_seq_bwd_range(gates, whh, c_all, dy, dgates, dhbuf, dcbuf, valid, k0, 
     assert dy.is_contiguous() and tuple(dy.shape) == (T, B, ndir * H)
     check(lib.ag_lstm_seq_bwd(_ptr_table(gates), _ptr_table(whh), _ptr_table(c_all), _p(dy),
                               _ptr_table(dgates), _ptr_table(dhbuf), _ptr_table(dcbuf), _p(valid), T, B, H,
-                              ndir, k0, k1, _stream()), 'ag_lstm_seq_bwd')
+                              ndir, k0, k1, phases, _stream()), 'ag_lstm_seq_bwd')
 
 
 def _work_skinny(A, B, Cm, tb=False, *a_, **kw):
@@ -595,15 +605,20 @@ def _work_seq_fwd(pre, whh, *a_, **kw):
     return 'lstm_step_fwd_kernel', 2.0 * nd * B * H4 * (H4 // 4), 4.0 * nd * (H4 * (H4 // 4) + 3 * B * H4)
 
 
-def _work_seq_bwd(gates, whh, *a_, **kw):
+def _work_seq_bwd_prod(gates, whh, *a_, **kw):
     T, B, H4 = gates[0].shape
     nd = len(gates)
-    return 'lstm_cell_bwd2_kernel + skinny_gemm_kernel (one step)', 2.0 * nd * B * H4 * (H4 // 4), \
-        4.0 * nd * (H4 * (H4 // 4) + 4 * B * H4)
+    return 'skinny_gemm_kernel', 2.0 * nd * B * H4 * (H4 // 4), 4.0 * nd * (H4 * (H4 // 4) + 2 * B * H4)
+
+
+def _work_seq_bwd_cell(gates, whh, *a_, **kw):
+    T, B, H4 = gates[0].shape
+    return 'lstm_cell_bwd2_kernel', 0.0, 4.0 * len(gates) * B * H4 * 3.5
 
 
 for _n, _w in (('skinny_gemm', _work_skinny), ('lstm_step_fwd', _work_step),
-               ('_lstm_seq_fwd_range', _work_seq_fwd), ('_lstm_seq_bwd_range', _work_seq_bwd)):
+               ('_lstm_seq_fwd_range', _work_seq_fwd), ('_lstm_seq_bwd_prod', _work_seq_bwd_prod),
+               ('_lstm_seq_bwd_cell', _work_seq_bwd_cell)):
     _instrument(_n, _w)
 
 
