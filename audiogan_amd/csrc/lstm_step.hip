@@ -38,37 +38,67 @@ struct SkinnyP {
   int mtiles;    // grid.z = nprob * mtiles
 };
 
-// A rows m0..m0+31 (k contiguous) x B rows (k contiguous), K range [k0,k1) (multiples of 8)
+// A rows m0..m0+31 (k contiguous) x B rows (k contiguous), K range [k0,k1) (multiples of 8).
+// Loads are UNCONDITIONAL (callers clamp out-of-range rows to a valid row; the garbage only
+// reaches output rows/columns that the epilogue drops) and issued in batches of UNR k-steps
+// before the first MFMA: with a predicated load hipcc branches around every load and waits
+// vmcnt(0) per k-step, i.e. one dependent L2 round trip per 8 k instead of one per batch.
+template <int UNR>
+__device__ __forceinline__ void nt_batch(f32x16& acc, const float* __restrict__ ar,
+                                         const float* __restrict__ br, int k) {
+  f32x4 a[UNR], b[UNR];
+#pragma unroll
+  for (int u = 0; u < UNR; ++u) {
+    b[u] = *reinterpret_cast<const f32x4*>(br + k + 8 * u);
+    a[u] = *reinterpret_cast<const f32x4*>(ar + k + 8 * u);
+  }
+#pragma unroll
+  for (int u = 0; u < UNR; ++u)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][e], b[u][e], acc, 0, 0, 0);
+}
+
 __device__ __forceinline__ void skinny_core_nt(f32x16& acc, const float* __restrict__ arow, bool aok,
                                                const float* __restrict__ brow, bool bok, int k0, int k1,
                                                int h) {
+  (void)aok; (void)bok;
   const float* ar = arow + 4 * h;
   const float* br = brow + 4 * h;
-  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 8
-  for (int k = k0; k < k1; k += 8) {
-    const f32x4 b = bok ? *reinterpret_cast<const f32x4*>(br + k) : z;
-    const f32x4 a = aok ? *reinterpret_cast<const f32x4*>(ar + k) : z;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e], acc, 0, 0, 0);
-  }
+  int k = k0;
+  for (; k + 64 <= k1; k += 64) nt_batch<8>(acc, ar, br, k);
+  if (k + 32 <= k1) { nt_batch<4>(acc, ar, br, k); k += 32; }
+  if (k + 16 <= k1) { nt_batch<2>(acc, ar, br, k); k += 16; }
+  if (k + 8 <= k1) nt_batch<1>(acc, ar, br, k);
 }
 
 // B stored [K][N]: lane j reads B[k][n0+j] (coalesced along n)
+template <int UNR>
+__device__ __forceinline__ void nn_batch(f32x16& acc, const float* __restrict__ ar,
+                                         const float* __restrict__ bc, int ldb, int k) {
+  f32x4 a[UNR];
+  float b[UNR][4];
+#pragma unroll
+  for (int u = 0; u < UNR; ++u) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) b[u][e] = bc[(int64_t)(k + 8 * u + e) * ldb];
+    a[u] = *reinterpret_cast<const f32x4*>(ar + k + 8 * u);
+  }
+#pragma unroll
+  for (int u = 0; u < UNR; ++u)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][e], b[u][e], acc, 0, 0, 0);
+}
+
 __device__ __forceinline__ void skinny_core_nn(f32x16& acc, const float* __restrict__ arow, bool aok,
                                                const float* __restrict__ bcol, int ldb, bool bok, int k0,
                                                int k1, int h) {
+  (void)aok; (void)bok;
   const float* ar = arow + 4 * h;
-  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-  for (int k = k0; k < k1; k += 8) {
-    float b[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) b[e] = bok ? bcol[(int64_t)(k + 4 * h + e) * ldb] : 0.f;
-    const f32x4 a = aok ? *reinterpret_cast<const f32x4*>(ar + k) : z;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e], acc, 0, 0, 0);
-  }
+  const float* bc = bcol + (int64_t)4 * h * ldb;
+  int k = k0;
+  for (; k + 32 <= k1; k += 32) nn_batch<4>(acc, ar, bc, ldb, k);
+  if (k + 16 <= k1) { nn_batch<2>(acc, ar, bc, ldb, k); k += 16; }
+  if (k + 8 <= k1) nn_batch<1>(acc, ar, bc, ldb, k);
 }
 
 // sum the per-wave 32x32 accumulators through LDS; afterwards red[0..1023] holds the block total,
