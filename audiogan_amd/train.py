@@ -53,3 +53,47 @@ def g_step(g, d, opt_g, c, z, noise_fake, ggradclip=0.1, g_optim='boundary_seeki
     scale = grad_hook() if grad_hook is not None else 1.0
     opt_g.step(clip_norm=ggradclip, grad_scale=scale, check=check)
     return loss.detach(), fake.detach(), cls_g.detach()
+
+
+# --------------------------------------------------------------------------------------
+# The same two iterations cut at the gradient all-reduce, so that each phase can be captured
+# into its own hipGraph while the RCCL collective between them stays an ordinary stream op:
+#   d_backward -> [all-reduce D grads] -> opt_d.step -> g_backward -> [all-reduce G grads] -> opt_g.step
+# --------------------------------------------------------------------------------------
+def d_backward(g, d, opt_d, real, real_len, c, z, noise_real, noise_fake, stop='never',
+               batch_real_fake=True):
+    """forward + backward of the critic iteration; gradients are left in ``.grad``"""
+    with torch.no_grad():
+        fake, _, _, fake_len = g(z=z, c=c, stop=stop)
+        fake = fake + noise_fake
+    B = real.size(0)
+    if batch_real_fake and fake.size(1) == real.size(1):
+        cls, _, _, nf = d(torch.cat([real + noise_real, fake], 0),
+                          torch.cat([real_len.to(fake_len.device), fake_len], 0), torch.cat([c, c], 0))
+        cls_d, cls_g, nf_d, nf_g = cls[:B], cls[B:], nf[:B], nf[B:]
+    else:
+        cls_d, _, _, nf_d = d(real + noise_real, real_len, c)
+        cls_g, _, _, nf_g = d(fake, fake_len, c)
+    loss_d, _ = masked_bce_mean(cls_d, 0.9, nf_d.contiguous())
+    loss_g, _ = masked_bce_mean(cls_g, 0.0, nf_g.contiguous())
+    loss = loss_d + loss_g
+    opt_d.zero_grad()
+    loss.backward()
+    return loss.detach()
+
+
+def g_backward(g, d, opt_g, c, z, noise_fake, g_optim='boundary_seeking', stop='never'):
+    """forward + backward of the generator iteration (through D, whose weights get no gradient)"""
+    flags = [p.requires_grad for p in d.parameters()]
+    for p in d.parameters():
+        p.requires_grad_(False)
+    try:
+        fake, _, _, fake_len = g(z=z, c=c, stop=stop)
+        cls_g, _, _, nf_g = d(fake + noise_fake, fake_len, c)
+        loss, _ = masked_bce_mean(cls_g, 0.5 if g_optim == 'boundary_seeking' else 0.0, nf_g)
+        opt_g.zero_grad()
+        loss.backward()
+    finally:
+        for p, r in zip(d.parameters(), flags):
+            p.requires_grad_(r)
+    return loss.detach()

@@ -109,6 +109,8 @@ def main():
     ap.add_argument('--cpu-steps', type=int, default=2)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--force-phases', action='store_true',
+                    help='use the multi-GPU code path (gradient buckets + 4 graphs per step) on one GPU')
     ap.add_argument('--no-graph', action='store_true',
                     help='enqueue every kernel from Python each step instead of replaying a hipGraph')
     args = ap.parse_args()
@@ -126,14 +128,15 @@ def main():
     dev = torch.device('cuda', local_rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=dev)
+        dist.init_process_group('nccl')
 
     import audiogan_amd as A
     from audiogan_amd import train, ddp, kernels as K
 
     g, d, opt_g, opt_d = build_models(A, dev, args.opt)
     hook_d = hook_g = None
-    if world > 1:
+    multi = world > 1 or args.force_phases
+    if multi:
         ddp.broadcast_parameters(g)
         ddp.broadcast_parameters(d)
         bd, bg = ddp.GradBucket(list(d.parameters())), ddp.GradBucket(list(g.parameters()))
@@ -158,46 +161,78 @@ def main():
         if prof:
             disc = K.Profiler.stop()
             dominant = max(disc.items(), key=lambda kv: kv[1]['ms'])[0]
-    # ---- capture the whole G+D step into ONE hipGraph (single GPU): ~3000 launches per step
-    # would otherwise be paced by the Python interpreter, not by the GPU
+    # ---- hipGraph capture: ~3000 launches per step would otherwise be paced by the Python
+    # interpreter, not by the GPU.  One GPU: the whole G+D step is ONE graph.  N GPUs: four graphs
+    # (critic fwd+bwd | opt_d | generator fwd+bwd | opt_g) with the two RCCL gradient all-reduces
+    # as ordinary stream operations between them.
     graph = None
-    if world == 1 and not args.no_graph:
+    phases = None
+
+    def capture(fn):
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            fn()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr):
+            fn()
+        return gr
+
+    b_ = batch
+    if not args.no_graph:
         try:
             K.reserve_table_arena()
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                one_step(train, g, d, opt_g, opt_d, batch)
-            torch.cuda.current_stream().wait_stream(side)
-            torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                one_step(train, g, d, opt_g, opt_d, batch)
-            graph.replay()
+            if not multi:
+                graph = capture(lambda: one_step(train, g, d, opt_g, opt_d, batch))
+                graph.replay()
+            else:
+                scale = 1.0 / world
+                g1 = capture(lambda: train.d_backward(g, d, opt_d, b_['real'], b_['real_len'], b_['c'], b_['z'],
+                                                      b_['noise_real'], b_['noise_fake']))
+                bd.all_reduce()
+                g2 = capture(lambda: opt_d.step(clip_norm=1.0, grad_scale=scale))
+                g3 = capture(lambda: train.g_backward(g, d, opt_g, b_['c'], b_['z'], b_['noise_fake']))
+                bg.all_reduce()
+                g4 = capture(lambda: opt_g.step(clip_norm=0.1, grad_scale=scale))
+                phases = (g1, g2, g3, g4)
             torch.cuda.synchronize()
         except Exception as e:  # noqa: BLE001
             sys.stderr.write('hipGraph capture failed (%s: %s); running eagerly\n' % (type(e).__name__, e))
-            graph = None
+            graph = phases = None
             torch.cuda.synchronize()
+
+    def run_step():
+        if graph is not None:
+            graph.replay()
+        elif phases is not None:
+            phases[0].replay()
+            bd.all_reduce()
+            phases[1].replay()
+            phases[2].replay()
+            bg.all_reduce()
+            phases[3].replay()
+        else:
+            one_step(train, g, d, opt_g, opt_d, batch, hook_d, hook_g)
+
+    graphed = graph is not None or phases is not None
     # ---- timed region: exactly K steps between barrier+synchronize on both sides
-    if dominant is not None and graph is None:
+    if dominant is not None and not graphed:
         K.Profiler.start(only=dominant)
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        if graph is not None:
-            graph.replay()
-        else:
-            one_step(train, g, d, opt_g, opt_d, batch, hook_d, hook_g)
+        run_step()
     sync()
     dt = time.perf_counter() - t0
-    rec = K.Profiler.stop() if (dominant is not None and graph is None) else {}
-    if graph is not None and dominant is not None:
+    rec = K.Profiler.stop() if (dominant is not None and not graphed) else {}
+    if graphed and dominant is not None:
         # per-kernel HIP-event timing is impossible inside a graph replay: time the dominant
         # kernel class in eager steps right after the timed region (same kernels, same shapes)
         K.Profiler.start(only=dominant)
         for _ in range(2):
-            one_step(train, g, d, opt_g, opt_d, batch)
+            one_step(train, g, d, opt_g, opt_d, batch, hook_d, hook_g)
         rec = K.Profiler.stop()
         for r_ in rec.values():
             r_['per_step_div'] = 2
@@ -219,7 +254,9 @@ def main():
                                    'per-parameter clip d=1 g=0.1' % (args.batch, args.opt),
                        'global_batch': world * args.batch, 'clip_len': L,
                        'parallelism': 'dp%d' % world,
-                       'launch': 'hipGraph replay' if graph is not None else 'eager'},
+                       'launch': ('hipGraph replay (1 graph per step)' if graph is not None else
+                                  'hipGraph replay (4 graphs per step, RCCL all-reduce between)' if phases is not None
+                                  else 'eager')},
         }
         if dominant is not None and dominant in rec:
             r = rec[dominant]
