@@ -10,7 +10,10 @@
 
 #include "common.h"
 
+#ifndef GBK
 #define GBK 16
+#endif
+#define GKQ (GBK / 4)
 
 struct GemmP {
   const float* A;
@@ -40,7 +43,7 @@ struct KContig {
 #pragma unroll
     for (int it = 0; it < ITER; ++it) {
       const int idx = tid + it * 256;
-      const int r = idx >> 2, kq = idx & 3;
+      const int r = idx / GKQ, kq = idx % GKQ;
       const int gr = r0 + r, gk = k0 + kq * 4;
       f32x4 q = {0.f, 0.f, 0.f, 0.f};
       if (gr < nrows) {
@@ -61,7 +64,7 @@ struct KContig {
 #pragma unroll
     for (int it = 0; it < ITER; ++it) {
       const int idx = tid + it * 256;
-      const int r = idx >> 2, kq = idx & 3;
+      const int r = idx / GKQ, kq = idx % GKQ;
 #pragma unroll
       for (int e = 0; e < 4; ++e) S[(kq * 4 + e) * PITCH + r] = v[it][e];
     }

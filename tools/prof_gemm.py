@@ -1,0 +1,18 @@
+"""micro-driver: GEMM shapes of the C2 step through the C ABI"""
+import sys, torch
+sys.path.insert(0, '.')
+import audiogan_amd.kernels as K
+shapes = [(16384, 2048, 612, 0, 1), (16384, 1024, 1024, 0, 1), (16384, 612, 2048, 0, 0), (16384, 1024, 1024, 0, 0),
+          (2048, 612, 16384, 1, 0), (1024, 1024, 16384, 1, 0), (8192, 2048, 612, 0, 1), (2048, 512, 16256, 1, 0)]
+for M, N, Kd, ta, tb in shapes:
+    A = torch.randn((Kd, M) if ta else (M, Kd), device='cuda')
+    B = torch.randn((N, Kd) if tb else (Kd, N), device='cuda')
+    C = torch.empty(M, N, device='cuda')
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    for it in range(2):
+        ev[0].record()
+        for _ in range(10):
+            K.gemm(A, B, C, ta=bool(ta), tb=bool(tb))
+        ev[1].record(); torch.cuda.synchronize()
+    us = ev[0].elapsed_time(ev[1]) * 100
+    print('M=%d N=%d K=%d ta=%d tb=%d: %.1f us  %.1f TF' % (M, N, Kd, ta, tb, us, 2.0 * M * N * Kd / us / 1e6))
