@@ -72,6 +72,18 @@ def one_step(train, g, d, opt_g, opt_d, b, hook_d=None, hook_g=None):
     train.g_step(g, d, opt_g, b['c'], b['z'], b['noise_fake'], 0.1, grad_hook=hook_g)
 
 
+def pmc_traffic(kernel):
+    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes
+    (profiles/r01_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE in separate passes, gfx950 x2 read
+    correction applied); None when that kernel was not profiled."""
+    path = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
+    if not os.path.exists(path):
+        return None
+    tab = json.load(open(path))
+    ent = tab.get(kernel.replace(' ', ''))
+    return ent['bytes_per_launch'] if ent else None
+
+
 def cpu_baseline(batch, steps, opt_kind, threads=0):
     """the oracle's canonical step on `batch` clips of the same workload, all host cores"""
     from oracle import audiogan_oracle as O
@@ -271,7 +283,7 @@ def main():
                 'peak': PEAK_F32_MFMA_TFLOPS if mfma_bound else PEAK_HBM_GBS,
                 'unit': 'TFLOP/s' if mfma_bound else 'GB/s',
                 'frac': (tf / PEAK_F32_MFMA_TFLOPS) if mfma_bound else (gbs / PEAK_HBM_GBS),
-                'traffic': None, 'launches_per_step': r['n'] / r.get('per_step_div', args.steps),
+                'traffic': pmc_traffic(dominant), 'launches_per_step': r['n'] / r.get('per_step_div', args.steps),
                 'avg_launch_us': avg_ms * 1e3,
                 'share_of_gpu_time': share,
                 'algorithmic_per_launch': {'flops': r['flops'] / r['n'], 'bytes': r['bytes'] / r['n']},
