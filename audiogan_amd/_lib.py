@@ -50,6 +50,11 @@ SIGNATURES = {
     'ag_wpa_numel': (i64, [C.c_int, C.c_int, C.c_int]),
     'ag_wpb_numel': (i64, [C.c_int, C.c_int, C.c_int, C.c_int]),
     'ag_conv1d_wgrad': (C.c_int, [vp, i64, i64, vp, i64, i64, vp] + [C.c_int] * 8 + [vp]),
+    'ag_conv1d_o1_fwd': (C.c_int, [vp, i64, i64, vp, vp, vp, i64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                   C.c_int, f32, vp]),
+    'ag_conv1d_o1_bwd_data': (C.c_int, [vp, i64, vp, vp, i64, i64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                        C.c_int, vp]),
+    'ag_conv1d_o1_wgrad': (C.c_int, [vp, i64, vp, i64, i64, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     'ag_channel_sum': (C.c_int, [vp, i64, i64, vp, C.c_int, C.c_int, C.c_int, vp]),
     'ag_leaky_bwd': (C.c_int, [vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, C.c_int,
                                C.c_int, C.c_int, f32, vp]),
@@ -73,6 +78,7 @@ SIGNATURES = {
     'ag_bce_logits_bwd': (C.c_int, [vp, C.c_int, f32, vp, vp, f32, vp, C.c_int, C.c_int, C.c_int, vp]),
     'ag_act_fwd': (C.c_int, [vp, vp, i64, C.c_int, f32, vp]),
     'ag_act_bwd': (C.c_int, [vp, vp, vp, i64, C.c_int, f32, vp]),
+    'ag_act_bwd2d': (C.c_int, [vp, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, f32, vp]),
     'ag_axpby': (C.c_int, [vp, vp, i64, f32, f32, vp]),
     'ag_grad_norms': (C.c_int, [vp, C.c_int, vp, vp, vp, f32, vp, vp]),
     'ag_opt_step': (C.c_int, [vp, C.c_int, vp, C.c_int, f32, f32, f32, f32, f32, f32, C.c_int, vp, vp]),

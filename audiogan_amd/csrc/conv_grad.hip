@@ -292,3 +292,137 @@ extern "C" int ag_leaky_bwd(const float* dy, int64_t dy_bs, int64_t dy_cs, const
   AG_CHECK_LAUNCH("ag_leaky_bwd");
   return AG_OK;
 }
+
+// ------------------------------------------------------------------------------------------
+// Single-output-channel convolution, stride 1 (the Generator's final Conv1d 113 -> 1, k3,
+// audiogan.py:404-407).  One output channel would waste 31/32 of an MFMA tile and the layer is
+// HBM-bound anyway (reads C*L, writes L per clip), so it gets plain VALU kernels:
+//   fwd   y[b,t]     = bias + sum_{c,k} w[c,k] x[b,c,t+k-p]         (+ activation)
+//   bwdx  dx[b,c,t] (+)= sum_k w[c,k] dy[b,t-k+p]
+//   wgrad dw[c,k]   += sum_{b,t} dy[b,t] x[b,c,t+k-p]
+// ------------------------------------------------------------------------------------------
+#define O1_MAXK 9
+
+__global__ __launch_bounds__(256) void conv_o1_fwd_kernel(const float* __restrict__ x, int64_t x_bs, int64_t x_cs,
+                                                          const float* __restrict__ w, const float* __restrict__ bias,
+                                                          float* __restrict__ y, int64_t y_bs, int C, int L, int K,
+                                                          int p, int act, float slope) {
+  const int b = blockIdx.y;
+  const int t0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (t0 >= L) return;
+  const float* xb = x + (int64_t)b * x_bs;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int c = 0; c < C; ++c) {
+    const float* xc = xb + (int64_t)c * x_cs;
+    float win[4 + O1_MAXK - 1];
+#pragma unroll
+    for (int i = 0; i < 4 + O1_MAXK - 1; ++i) {
+      const int g = t0 + i - p;
+      win[i] = (i < 4 + K - 1 && g >= 0 && g < L) ? xc[g] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < O1_MAXK; ++k) {
+      if (k >= K) break;
+      const float wk = w[c * K + k];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] += wk * win[j + k];
+    }
+  }
+  const float bo = bias ? bias[0] : 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (t0 + j < L) y[(int64_t)b * y_bs + t0 + j] = ag_apply_act(acc[j] + bo, act, slope);
+}
+
+__global__ __launch_bounds__(256) void conv_o1_bwdx_kernel(const float* __restrict__ dy, int64_t dy_bs,
+                                                           const float* __restrict__ w, float* __restrict__ dx,
+                                                           int64_t dx_bs, int64_t dx_cs, int C, int L, int K, int p,
+                                                           int accumulate) {
+  const int b = blockIdx.z, c = blockIdx.y;
+  const int t0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (t0 >= L) return;
+  const float* dyb = dy + (int64_t)b * dy_bs;
+  // dx[t] = sum_k w[c,k] dy[t - k + p]  -> window dy[t0 + p - (K-1) .. t0 + p + 3]
+  float win[4 + O1_MAXK - 1];
+#pragma unroll
+  for (int i = 0; i < 4 + O1_MAXK - 1; ++i) {
+    const int g = t0 + p - (K - 1) + i;
+    win[i] = (i < 4 + K - 1 && g >= 0 && g < L) ? dyb[g] : 0.f;
+  }
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < O1_MAXK; ++k) {
+    if (k >= K) break;
+    const float wk = w[c * K + k];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] += wk * win[j + (K - 1) - k];
+  }
+  float* d = dx + (int64_t)b * dx_bs + (int64_t)c * dx_cs;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (t0 + j < L) d[t0 + j] = accumulate ? d[t0 + j] + acc[j] : acc[j];
+}
+
+__global__ __launch_bounds__(256) void conv_o1_wgrad_kernel(const float* __restrict__ dy, int64_t dy_bs,
+                                                            const float* __restrict__ x, int64_t x_bs, int64_t x_cs,
+                                                            float* __restrict__ dw, int B, int C, int L, int K, int p,
+                                                            int nsplit) {
+  __shared__ float red[17];
+  const int c = blockIdx.x;
+  float acc[O1_MAXK];
+#pragma unroll
+  for (int k = 0; k < O1_MAXK; ++k) acc[k] = 0.f;
+  const int64_t total = (int64_t)B * L;
+  for (int64_t i = (int64_t)blockIdx.y * 256 + threadIdx.x; i < total; i += (int64_t)nsplit * 256) {
+    const int b = (int)(i / L), t = (int)(i - (int64_t)b * L);
+    const float g = dy[(int64_t)b * dy_bs + t];
+    const float* xc = x + (int64_t)b * x_bs + (int64_t)c * x_cs;
+#pragma unroll
+    for (int k = 0; k < O1_MAXK; ++k) {
+      const int q = t + k - p;
+      if (k < K && q >= 0 && q < L) acc[k] += g * xc[q];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < O1_MAXK; ++k) {
+    if (k >= K) break;
+    const float s = ag_block_sum(acc[k], red);
+    if (threadIdx.x == 0) atomicAdd(dw + c * K + k, s);
+  }
+}
+
+extern "C" int ag_conv1d_o1_fwd(const float* x, int64_t x_bs, int64_t x_cs, const float* w, const float* bias,
+                                float* y, int64_t y_bs, int B, int C, int L, int K, int pad, int act, float slope,
+                                void* stream) {
+  AG_REQUIRE(x && w && y && B > 0 && C > 0 && L > 0 && K > 0 && K <= O1_MAXK && pad >= 0 && B <= 65535,
+             "ag_conv1d_o1_fwd: bad args (needs stride 1, K <= 9)");
+  AG_REQUIRE(L + 2 * pad - K + 1 == L, "ag_conv1d_o1_fwd: needs a length-preserving ('same') conv");
+  hipLaunchKernelGGL(conv_o1_fwd_kernel, dim3(ag_cdiv(L, 1024), B), dim3(256), 0, (hipStream_t)stream, x, x_bs, x_cs,
+                     w, bias, y, y_bs, C, L, K, pad, act, slope);
+  AG_CHECK_LAUNCH("ag_conv1d_o1_fwd");
+  return AG_OK;
+}
+
+extern "C" int ag_conv1d_o1_bwd_data(const float* dy, int64_t dy_bs, const float* w, float* dx, int64_t dx_bs,
+                                     int64_t dx_cs, int B, int C, int L, int K, int pad, int accumulate,
+                                     void* stream) {
+  AG_REQUIRE(dy && w && dx && B > 0 && C > 0 && L > 0 && K > 0 && K <= O1_MAXK && B <= 65535 && C <= 65535,
+             "ag_conv1d_o1_bwd_data: bad args");
+  hipLaunchKernelGGL(conv_o1_bwdx_kernel, dim3(ag_cdiv(L, 1024), C, B), dim3(256), 0, (hipStream_t)stream, dy, dy_bs,
+                     w, dx, dx_bs, dx_cs, C, L, K, pad, accumulate);
+  AG_CHECK_LAUNCH("ag_conv1d_o1_bwd_data");
+  return AG_OK;
+}
+
+extern "C" int ag_conv1d_o1_wgrad(const float* dy, int64_t dy_bs, const float* x, int64_t x_bs, int64_t x_cs,
+                                  float* dw, int B, int C, int L, int K, int pad, void* stream) {
+  AG_REQUIRE(dy && x && dw && B > 0 && C > 0 && L > 0 && K > 0 && K <= O1_MAXK, "ag_conv1d_o1_wgrad: bad args");
+  int nsplit = ag_cdiv(2048, C);
+  const int64_t cap = ag_cdiv64((int64_t)B * L, 256 * 8);
+  if (nsplit > cap) nsplit = (int)cap;
+  if (nsplit < 1) nsplit = 1;
+  hipLaunchKernelGGL(conv_o1_wgrad_kernel, dim3(C, nsplit), dim3(256), 0, (hipStream_t)stream, dy, dy_bs, x, x_bs,
+                     x_cs, dw, B, C, L, K, pad, nsplit);
+  AG_CHECK_LAUNCH("ag_conv1d_o1_wgrad");
+  return AG_OK;
+}

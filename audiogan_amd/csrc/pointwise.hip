@@ -466,3 +466,26 @@ extern "C" int ag_gru_cell_bwd(const float* gates_act, const float* gh, const fl
   AG_CHECK_LAUNCH("ag_gru_cell_bwd");
   return AG_OK;
 }
+
+// dx[r, c] = dy[r, c] * act'(.) from the saved output y, all three row-strided 2-D views
+__global__ __launch_bounds__(256) void act_bwd2d_kernel(const float* __restrict__ dy, int lddy,
+                                                        const float* __restrict__ y, int ldy,
+                                                        float* __restrict__ dx, int lddx, int rows, int cols,
+                                                        int act, float slope) {
+  const int c = blockIdx.x * 256 + threadIdx.x, r = blockIdx.y;
+  if (c >= cols) return;
+  const float o = y[(int64_t)r * ldy + c];
+  float g = dy[(int64_t)r * lddy + c];
+  if (act == AG_ACT_LEAKY) g = o > 0.f ? g : g * slope;
+  else if (act == AG_ACT_TANH) g = g * (1.f - o * o);
+  dx[(int64_t)r * lddx + c] = g;
+}
+
+extern "C" int ag_act_bwd2d(const float* dy, int lddy, const float* y, int ldy, float* dx, int lddx, int rows,
+                            int cols, int act, float slope, void* stream) {
+  AG_REQUIRE(dy && y && dx && rows > 0 && cols > 0 && rows <= 65535, "ag_act_bwd2d: bad args");
+  hipLaunchKernelGGL(act_bwd2d_kernel, dim3(ag_cdiv(cols, 256), rows), dim3(256), 0, (hipStream_t)stream, dy, lddy,
+                     y, ldy, dx, lddx, rows, cols, act, slope);
+  AG_CHECK_LAUNCH("ag_act_bwd2d");
+  return AG_OK;
+}

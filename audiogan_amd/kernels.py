@@ -650,3 +650,54 @@ def gru_cell_bwd(gates_act, gh, h_prev, dh, dgi, dgh, dh_prev):
 
 for _n in ('gru_cell_fwd', 'gru_cell_bwd'):
     _instrument(_n, None)
+
+
+def act_bwd2d(dy, y, dx, act, slope=LEAKY_SLOPE):
+    """dx = dy * act'(.) on 2-D row-strided views (unit stride along dim 1)"""
+    a, b, c = _mat(dy, 'dy'), _mat(y, 'y'), _mat(dx, 'dx')
+    assert tuple(dy.shape) == tuple(y.shape) == tuple(dx.shape)
+    check(lib.ag_act_bwd2d(_p(dy), a, _p(y), b, _p(dx), c, dy.size(0), dy.size(1), act, slope, _stream()),
+          'ag_act_bwd2d')
+
+
+_instrument('act_bwd2d', None)
+
+
+# ------------------------------------------------------------------------------------
+# single-output-channel stride-1 conv (Generator's final conv)
+# ------------------------------------------------------------------------------------
+def conv_o1_ok(spec_kind, cout, K_, stride, pad):
+    return spec_kind == 'conv' and cout == 1 and stride == 1 and K_ <= 9 and 2 * pad == K_ - 1
+
+
+def conv_o1_fwd(x, w, bias, y, K_, pad, act=ACT_NONE, slope=LEAKY_SLOPE):
+    """x [B,C,L] view, w [1,C,K] contiguous, y [B,1,L] view"""
+    x_bs, x_cs = _bcl(x, 'x')
+    y_bs, _ = _bcl(y, 'y')
+    _chk(w, 'w'); _chk(bias, 'bias')
+    B, Cc, L = x.shape
+    assert w.is_contiguous() and w.numel() == Cc * K_ and tuple(y.shape) == (B, 1, L)
+    check(lib.ag_conv1d_o1_fwd(_p(x), x_bs, x_cs, _p(w), _p(bias), _p(y), y_bs, B, Cc, L, K_, pad, act, slope,
+                               _stream()), 'ag_conv1d_o1_fwd')
+
+
+def conv_o1_bwd_data(dy, w, dx, K_, pad, accumulate=False):
+    dy_bs, _ = _bcl(dy, 'dy')
+    dx_bs, dx_cs = _bcl(dx, 'dx')
+    B, Cc, L = dx.shape
+    assert w.is_contiguous() and w.numel() == Cc * K_ and tuple(dy.shape) == (B, 1, L)
+    check(lib.ag_conv1d_o1_bwd_data(_p(dy), dy_bs, _p(w), _p(dx), dx_bs, dx_cs, B, Cc, L, K_, pad,
+                                    int(accumulate), _stream()), 'ag_conv1d_o1_bwd_data')
+
+
+def conv_o1_wgrad(dy, x, dw, K_, pad):
+    dy_bs, _ = _bcl(dy, 'dy')
+    x_bs, x_cs = _bcl(x, 'x')
+    B, Cc, L = x.shape
+    assert dw.is_contiguous() and dw.numel() == Cc * K_ and tuple(dy.shape) == (B, 1, L)
+    check(lib.ag_conv1d_o1_wgrad(_p(dy), dy_bs, _p(x), x_bs, x_cs, _p(dw), B, Cc, L, K_, pad, _stream()),
+          'ag_conv1d_o1_wgrad')
+
+
+for _n in ('conv_o1_fwd', 'conv_o1_bwd_data', 'conv_o1_wgrad'):
+    _instrument(_n, None)

@@ -106,6 +106,13 @@ class dense_res_bottleneck(nn.Module):
         self.deconv = WNConvTranspose1d(hidden_filters, outfilters, kernel - 1, stride, stride // 2)
 
 
+def _cumprod(xs):
+    p = 1
+    for v in xs:
+        p *= v
+        yield p
+
+
 def _add(group, mod, name, **kw):
     v, g = mod.wn(name)
     group.add(v, g, **kw)
@@ -240,19 +247,21 @@ class Discriminator(nn.Module):
         ss, es = self._state_size, self._embed_size
         b = x.size(0)
         length = length.to(x.device).long()
-        lens_list, n = [], length
-        for _, stride, _ in self.cnn_struct:
-            n = (n + stride - 1) // stride
-            lens_list.append(n.contiguous())
+        # nframes after layer i = ceil(... ceil(length / s_1) ... / s_i) = ceil(length / (s_1 ... s_i)):
+        # all layers in one broadcast op instead of one tiny kernel pair per layer (:533)
+        prods = torch.tensor(list(_cumprod([s for _, s, _ in self.cnn_struct])), device=x.device).view(-1, 1)
+        lens_all = (length.view(1, -1) + prods - 1) // prods
+        lens_list = [lens_all[i] for i in range(lens_all.size(0))]
+        n = lens_list[-1]
         acts = ops.DConvStackFn.apply(x, self._stack, lens_list, *self._stack.group.params())
         a = acts[-1]
         tq = a.size(2)
         seq = torch.cat([a.permute(2, 0, 1), c.unsqueeze(0).expand(tq, b, es)], 2)
         for layer in range(self._num_layers):
             seq = ops.LSTMSeqFn.apply(seq.contiguous(), n, 2, *self._rnn_weights(layer))
-        rows = seq.permute(1, 0, 2).reshape(b * tq, ss)
-        logits = ops.DHeadFn.apply(rows, self._head, *self._head.group.params()).view(b, tq)
-        return logits, list(acts), lens_list, n
+        # the heads are per-row: keep the LSTM's (time, clip) row order and transpose only the logits
+        logits = ops.DHeadFn.apply(seq.reshape(tq * b, ss), self._head, *self._head.group.params())
+        return logits.view(tq, b).t(), list(acts), lens_list, n
 
 
 class Embedder(nn.Module):

@@ -35,15 +35,23 @@ class ConvSpec(object):
 # --------------------------------------------------------------------------------------
 # conv helpers (layout bookkeeping between NN.Conv1d / NN.ConvTranspose1d and the engine)
 # --------------------------------------------------------------------------------------
+def _o1(spec):
+    return K.conv_o1_ok(spec.kind, spec.cout, spec.K, spec.stride, spec.pad)
+
+
 def conv_fwd(spec, prep, x, y, bias=None, res=None, lens=None, act=ACT_NONE):
-    if spec.kind == 'conv':
+    if prep.w is not None and res is None and lens is None and _o1(spec):
+        K.conv_o1_fwd(x, prep.w, bias, y, spec.K, spec.pad, act)
+    elif spec.kind == 'conv':
         K.conv_engine(x, prep.wpa, y, spec.K, spec.stride, spec.pad, 0, bias, res, lens, act)
     else:
         K.conv_engine(x, prep.wpb, y, spec.K, spec.stride, spec.pad, 1, bias, res, lens, act)
 
 
 def conv_bwd_data(spec, prep, dy, dx, accumulate=False):
-    if spec.kind == 'conv':
+    if prep.w is not None and _o1(spec):
+        K.conv_o1_bwd_data(dy, prep.w, dx, spec.K, spec.pad, accumulate)
+    elif spec.kind == 'conv':
         K.conv_engine(dy, prep.wpb, dx, spec.K, spec.stride, spec.pad, 1, accumulate=accumulate)
     else:
         K.conv_engine(dy, prep.wpa, dx, spec.K, spec.stride, spec.pad, 0, accumulate=accumulate)
@@ -51,7 +59,9 @@ def conv_bwd_data(spec, prep, dy, dx, accumulate=False):
 
 def conv_wgrad(spec, x, dy, dw, db):
     """dw, db must be zero-filled."""
-    if spec.kind == 'conv':
+    if _o1(spec):
+        K.conv_o1_wgrad(dy, x, dw, spec.K, spec.pad)
+    elif spec.kind == 'conv':
         K.conv_wgrad(dy, x, dw, spec.K, spec.stride, spec.pad)
     else:
         K.conv_wgrad(x, dy, dw, spec.K, spec.stride, spec.pad)
@@ -184,10 +194,12 @@ class DConvStackFn(torch.autograd.Function):
             if d is None:
                 if g is None:
                     continue
-                d = g.contiguous().clone()
-            elif g is not None:
-                K.axpby(g.contiguous(), d, 1.0, 1.0)
-            K.leaky_bwd(d, acts[i], d, lens=ctx.lens_list[i])
+                d = torch.empty_like(acts[i])
+                K.leaky_bwd(g.contiguous(), acts[i], d, lens=ctx.lens_list[i])     # out of place: no clone
+            else:
+                if g is not None:
+                    K.axpby(g.contiguous(), d, 1.0, 1.0)
+                K.leaky_bwd(d, acts[i], d, lens=ctx.lens_list[i])
             xin = acts[i - 1] if i > 0 else x.contiguous().view(B, 1, L)
             if wg:
                 conv_wgrad(sp, xin, d, dws[2 * i], dws[2 * i + 1])

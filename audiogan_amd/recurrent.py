@@ -228,12 +228,9 @@ class GFrontFn(torch.autograd.Function):
         dgs = [torch.empty(T, B, 4 * S, device=dev) for _ in range(nl)]
         dxt = torch.empty(T, B, fs, device=dev)      # d(pre-tanh) of the projection, per frame
         dcs = [[torch.zeros(B, S, device=dev), torch.empty(B, S, device=dev)] for _ in range(nl)]
-        xt_c = torch.empty(B, fs, device=dev)
         for t in reversed(range(T)):
             gx = dxt[t]
-            gx.copy_(dxa[:, t * fs:(t + 1) * fs])
-            xt_c.copy_(x[:, t * fs:(t + 1) * fs])
-            K.act_bwd(gx, xt_c, gx, ACT_TANH)
+            K.act_bwd2d(dxa[:, t * fs:(t + 1) * fs], x[:, t * fs:(t + 1) * fs], gx, ACT_TANH)
             _small_acc(gx, pw, dha[-1][t])                                   # through the projection
             for l in reversed(range(nl)):
                 K.lstm_cell_bwd(gates[l][t], cs[l][t], cs[l][t + 1], dha[l][t], None,
@@ -336,13 +333,10 @@ class GRUFrontFn(torch.autograd.Function):
         dgi = torch.empty(T, B, 3 * S, device=dev)
         dgh = torch.empty(T, B, 3 * S, device=dev)
         dxt = torch.empty(T, B, fs, device=dev)
-        xt_c = torch.empty(B, fs, device=dev)
         dh_dir = torch.empty(B, S, device=dev)
         for t in reversed(range(T)):
             gx = dxt[t]
-            gx.copy_(dxa[:, t * fs:(t + 1) * fs])
-            xt_c.copy_(x[:, t * fs:(t + 1) * fs])
-            K.act_bwd(gx, xt_c, gx, ACT_TANH)
+            K.act_bwd2d(dxa[:, t * fs:(t + 1) * fs], x[:, t * fs:(t + 1) * fs], gx, ACT_TANH)
             _small_acc(gx, pw, dha[t + 1])
             K.gru_cell_bwd(gi[t], gh[t], hs[t], dha[t + 1], dgi[t], dgh[t], dh_dir)
             K.axpby(dh_dir, dha[t], 1.0, 1.0)                     # direct path  dh * z

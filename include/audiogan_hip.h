@@ -126,6 +126,19 @@ int ag_conv1d_wgrad(const float* sh, int64_t sh_bs, int64_t sh_cs, const float* 
                     int64_t lg_cs, float* dw, int B, int A, int Lsh, int C, int Llg, int K,
                     int stride, int pad, void* stream);
 
+/* Single-output-channel stride-1 'same' convolution (the Generator's final Conv1d 113 -> 1, k3,
+ * audiogan.py:404-407): one output channel cannot fill an MFMA tile and the layer is HBM-bound, so it
+ * has plain vector kernels.  w is the standard [1, C, K] weight (= [C, K]); K <= 9.
+ *   fwd      y[b,t]      = act(bias + sum_{c,k} w[c,k] x[b,c,t+k-pad])
+ *   bwd_data dx[b,c,t] (+)= sum_k w[c,k] dy[b,t-k+pad]
+ *   wgrad    dw[c,k]    += sum_{b,t} dy[b,t] x[b,c,t+k-pad]        (atomics; dw pre-zeroed) */
+int ag_conv1d_o1_fwd(const float* x, int64_t x_bs, int64_t x_cs, const float* w, const float* bias, float* y,
+                     int64_t y_bs, int B, int C, int L, int K, int pad, int act, float slope, void* stream);
+int ag_conv1d_o1_bwd_data(const float* dy, int64_t dy_bs, const float* w, float* dx, int64_t dx_bs,
+                          int64_t dx_cs, int B, int C, int L, int K, int pad, int accumulate, void* stream);
+int ag_conv1d_o1_wgrad(const float* dy, int64_t dy_bs, const float* x, int64_t x_bs, int64_t x_cs, float* dw,
+                       int B, int C, int L, int K, int pad, void* stream);
+
 /* db[c] (+)= sum_{b,t} dy[b,c,t]   (bias gradient; atomics, db pre-zeroed) */
 int ag_channel_sum(const float* dy, int64_t bs, int64_t cs, float* db, int B, int C, int L,
                    void* stream);
@@ -242,6 +255,9 @@ int ag_act_fwd(const float* x, float* y, int64_t n, int act, float slope, void* 
 /* dx = dy * act'(.) using the saved OUTPUT y */
 int ag_act_bwd(const float* dy, const float* y, float* dx, int64_t n, int act, float slope,
                void* stream);
+/* same on row-strided 2-D views [rows, cols] (frame slices of the generator's [B, T*frame] output) */
+int ag_act_bwd2d(const float* dy, int lddy, const float* y, int ldy, float* dx, int lddx, int rows,
+                 int cols, int act, float slope, void* stream);
 /* y = a*x + b*y  on n contiguous floats */
 int ag_axpby(const float* x, float* y, int64_t n, float a, float b, void* stream);
 

@@ -379,5 +379,30 @@ def gru_cell_bwd(gates_act, gh, h_prev, dh, dgi, dgh, dh_prev):
     dh_prev.copy_(dh * z)
 
 
+def act_bwd2d(dy, y, dx, act, slope=LEAKY_SLOPE):
+    act_bwd(dy, y, dx, act, slope)
+
+
+def conv_o1_ok(spec_kind, cout, K_, stride, pad):
+    return spec_kind == 'conv' and cout == 1 and stride == 1 and K_ <= 9 and 2 * pad == K_ - 1
+
+
+def conv_o1_fwd(x, w, bias, y, K_, pad, act=ACT_NONE, slope=LEAKY_SLOPE):
+    out = F.conv1d(x, w.view(1, x.size(1), K_), bias, 1, pad)
+    y.copy_(_act(out, act, slope))
+
+
+def conv_o1_bwd_data(dy, w, dx, K_, pad, accumulate=False):
+    out = F.conv_transpose1d(dy, w.view(1, dx.size(1), K_), None, 1, pad)
+    dx.copy_(out + dx if accumulate else out)
+
+
+def conv_o1_wgrad(dy, x, dw, K_, pad):
+    xp = F.pad(x, (pad, pad))
+    L = x.size(2)
+    for k in range(K_):
+        dw.view(x.size(1), K_)[:, k] += torch.einsum('bt,bct->c', dy[:, 0], xp[:, :, k:k + L])
+
+
 ALL = [n for n, v in list(globals().items()) if callable(v) and not n.startswith('_')
        and n not in ('F', 'install')]

@@ -382,3 +382,37 @@ def test_lstm_seq_fwd_bwd(K, T, B, H, ndir, ragged):
     for d in range(ndir):
         close(c[d], cr[d], rtol=1e-3, atol=1e-5)
         close(dg[d], dgr[d], rtol=2e-3, atol=2e-5)
+
+
+@pytest.mark.parametrize('C,L,Kk', [(113, 8192, 3), (5, 100, 1), (7, 1030, 9), (1, 4, 3)])
+def test_conv_single_output_channel(K, C, L, Kk):
+    B, p = 3, (Kk - 1) // 2
+    gen = torch.Generator().manual_seed(17)
+    x, w, b = torch.randn(B, C + 2, L, generator=gen)[:, 1:C + 1], torch.randn(1, C, Kk, generator=gen) / (C * Kk) ** 0.5, torch.randn(1, generator=gen)
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    yref = torch.tanh(F.conv1d(xr, wr, b, 1, p))
+    xd = dev(torch.randn(B, C + 2, L))
+    xd[:, 1:C + 1] = dev(x)
+    y = torch.empty(B, 1, L).cuda()
+    K.conv_o1_fwd(xd[:, 1:C + 1], dev(w), dev(b), y, Kk, p, act=K.ACT_TANH)
+    close(y, yref, msg='fwd')
+    gy = torch.randn(B, 1, L, generator=gen)
+    lin = F.conv1d(xr, wr, None, 1, p)
+    lin.backward(gy)
+    dx0 = torch.randn(B, C, L, generator=gen)
+    dx = dev(dx0.clone())
+    K.conv_o1_bwd_data(dev(gy), dev(w), dx, Kk, p, accumulate=True)
+    close(dx, dx0 + xr.grad, msg='bwd-data')
+    dw = torch.zeros(1, C, Kk).cuda()
+    K.conv_o1_wgrad(dev(gy), xd[:, 1:C + 1], dw, Kk, p)
+    close(dw, wr.grad, msg='wgrad')
+    assert K.conv_o1_ok('conv', 1, Kk, 1, p) and not K.conv_o1_ok('conv', 2, Kk, 1, p)
+
+
+def test_act_bwd2d(K):
+    gen = torch.Generator().manual_seed(18)
+    dy, y = torch.randn(64, 8192, generator=gen), torch.tanh(torch.randn(64, 8192, generator=gen))
+    out = torch.empty(64, 256).cuda()
+    K.act_bwd2d(dev(dy)[:, 512:768], dev(y)[:, 512:768], out, K.ACT_TANH)
+    close(out, dy[:, 512:768] * (1 - y[:, 512:768] ** 2), rtol=1e-5)
