@@ -236,6 +236,14 @@ class Discriminator(nn.Module):
             _add(self._head.group, self.classifier.module[i], 'weight')
             _add(self._head.group, self.classifier.module[i], 'bias')
 
+    def _stride_prods(self, dev):
+        # built once per device (a host->device copy inside forward would break hipGraph capture)
+        t = getattr(self, '_prods', None)
+        if t is None or t.device != dev:
+            t = torch.tensor(list(_cumprod([s for _, s, _ in self.cnn_struct])), device=dev).view(-1, 1)
+            self._prods = t
+        return t
+
     def _rnn_weights(self, layer):
         out = []
         for suffix in ('', '_reverse'):
@@ -249,7 +257,7 @@ class Discriminator(nn.Module):
         length = length.to(x.device).long()
         # nframes after layer i = ceil(... ceil(length / s_1) ... / s_i) = ceil(length / (s_1 ... s_i)):
         # all layers in one broadcast op instead of one tiny kernel pair per layer (:533)
-        prods = torch.tensor(list(_cumprod([s for _, s, _ in self.cnn_struct])), device=x.device).view(-1, 1)
+        prods = self._stride_prods(x.device)
         lens_all = (length.view(1, -1) + prods - 1) // prods
         lens_list = [lens_all[i] for i in range(lens_all.size(0))]
         n = lens_list[-1]

@@ -179,6 +179,7 @@ def main():
     # as ordinary stream operations between them.
     graph = None
     phases = None
+    capture_error = None
 
     def capture(fn):
         side = torch.cuda.Stream()
@@ -213,6 +214,7 @@ def main():
         except Exception as e:  # noqa: BLE001
             sys.stderr.write('hipGraph capture failed (%s: %s); running eagerly\n' % (type(e).__name__, e))
             graph = phases = None
+            capture_error = '%s: %s' % (type(e).__name__, str(e)[:200])
             torch.cuda.synchronize()
 
     def run_step():
@@ -268,7 +270,7 @@ def main():
                        'parallelism': 'dp%d' % world,
                        'launch': ('hipGraph replay (1 graph per step)' if graph is not None else
                                   'hipGraph replay (4 graphs per step, RCCL all-reduce between)' if phases is not None
-                                  else 'eager')},
+                                  else 'eager' + (' (capture failed: %s)' % capture_error if capture_error else ''))},
         }
         if dominant is not None and dominant in rec:
             r = rec[dominant]
