@@ -189,7 +189,8 @@ def main():
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         gr = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(gr):
+        # thread_local: other threads (e.g. the RCCL watchdog) may keep calling HIP while we capture
+        with torch.cuda.graph(gr, capture_error_mode='thread_local'):
             fn()
         return gr
 
