@@ -35,6 +35,7 @@ struct ConvP {
   int Mpad;       // row pitch of the prepared weight (multiple of 32)
   int n_lo;       // first column index (0 for mode 0, pad/s for mode 1)
   int n_cnt;      // number of columns
+  int xvec;       // input rows may be read with aligned 16-byte loads
   int tapoff[MAX_TAPS];
 };
 
@@ -82,21 +83,34 @@ __global__ __launch_bounds__(512) void conv_engine_kernel(const ConvP p) {
     // Staging is latency-bound: ALL global loads of a round (UX input samples + UW weight
     // float4 per lane) are issued before the first LDS write, so a chunk costs one or two
     // dependent memory round trips instead of one per loop iteration.
-    constexpr int UX = 4, UW = 4;
+    // Input samples are fetched as 16-byte pieces aligned to a multiple of 4 samples (window start
+    // rounded down), then scattered into the polyphase rows.
+    constexpr int UX = 2, UW = 4;
     const int step = nsw * 64;
-    const int xtot = p.CC * span, wtot = p.CC * taps * (OT / 4);
+    const int base4 = base - (((base % 4) + 4) % 4);       // floor to a multiple of 4 (base may be < 0)
+    const int nq = (base - base4 + span + 3) / 4;          // float4 pieces per channel
+    const int xtot = p.CC * nq, wtot = p.CC * taps * (OT / 4);
     int xe = sw * 64 + lane, we = xe;
     while (xe < xtot || we < wtot) {
-      float xv[UX];
+      f32x4 xv[UX];
       f32x4 wv[UW];
 #pragma unroll
       for (int u = 0; u < UX; ++u) {
         const int e = xe + u * step;
-        xv[u] = 0.f;
+        xv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (e < xtot) {
-          const int cc = e / span, rem = e - cc * span;
-          const int g = base + rem, c = c0 + cc;
-          if (c < a.C && g >= 0 && g < a.Lin) xv[u] = xb[(int64_t)c * a.x_cs + g];
+          const int cc = e / nq, i4 = e - cc * nq;
+          const int g = base4 + 4 * i4, c = c0 + cc;
+          if (c < a.C) {
+            const float* src = xb + (int64_t)c * a.x_cs + g;
+            if (p.xvec && g >= 0 && g + 3 < a.Lin) {
+              xv[u] = *reinterpret_cast<const f32x4*>(src);
+            } else {
+#pragma unroll
+              for (int q = 0; q < 4; ++q)
+                if (g + q >= 0 && g + q < a.Lin) xv[u][q] = src[q];
+            }
+          }
         }
       }
 #pragma unroll
@@ -114,22 +128,27 @@ __global__ __launch_bounds__(512) void conv_engine_kernel(const ConvP p) {
       for (int u = 0; u < UX; ++u) {
         const int e = xe + u * step;
         if (e < xtot) {
-          const int cc = e / span, rem = e - cc * span;
-          int r, qq;
-          if (S0 > 0) {
-            r = rem % SD;
-            qq = rem / SD;
-          } else if (TAPS > 0) {
-            r = 0;
-            qq = rem;
-          } else if (p.sp_shift >= 0) {
-            r = rem & (p.sp - 1);
-            qq = rem >> p.sp_shift;
-          } else {
-            qq = rem / p.sp;
-            r = rem - qq * p.sp;
+          const int cc = e / nq, i4 = e - cc * nq;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int rem = base4 + 4 * i4 + q - base;
+            if (rem < 0 || rem >= span) continue;
+            int r, qq;
+            if (S0 > 0) {
+              r = rem % SD;
+              qq = rem / SD;
+            } else if (TAPS > 0) {
+              r = 0;
+              qq = rem;
+            } else if (p.sp_shift >= 0) {
+              r = rem & (p.sp - 1);
+              qq = rem >> p.sp_shift;
+            } else {
+              qq = rem / p.sp;
+              r = rem - qq * p.sp;
+            }
+            xs[cc * chs + r * rowlen + qq] = xv[u][q];
           }
-          xs[cc * chs + r * rowlen + qq] = xv[u];
         }
       }
 #pragma unroll
@@ -389,6 +408,7 @@ extern "C" int ag_conv1d_engine(const ag_conv_args* args, void* stream) {
   }
   AG_REQUIRE(p.taps <= MAX_TAPS, "ag_conv1d_engine: more than %d taps", MAX_TAPS);
   p.sp_shift = ilog2_exact(p.sp);
+  p.xvec = (((uintptr_t)a.x & 15) == 0) && (a.x_bs % 4 == 0) && (a.x_cs % 4 == 0);
   p.Cpad = ag_roundup(a.C, 2);
   p.Mpad = ag_roundup(p.Mrows, 32);
   hipStream_t st = (hipStream_t)stream;
