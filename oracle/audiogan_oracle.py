@@ -414,6 +414,38 @@ class Conv1DDiscriminator(nn.Module):
 
 
 # --------------------------------------------------------------------------
+# feature statistics of the reference's current G step (audiogan.py:336-359, :850-855)
+# --------------------------------------------------------------------------
+def fourth_moment(v):
+    """audiogan.py:336-339; Python-2 ``(1/4)`` is 0, so this is x**0."""
+    return (((v - v.mean(0).unsqueeze(0)) ** 4).sum(0)) ** 0
+
+
+def calc_dists(hidden_states, hidden_state_lengths):
+    """audiogan.py:341-359."""
+    means_d, stds_d, fourth_d = [], [], []
+    for h, l in zip(hidden_states, hidden_state_lengths):
+        mask = length_mask((h.size(0), h.size(2)), l)
+        lf = l.unsqueeze(1).float()
+        m = h.sum(2) / lf
+        cen = h - m.unsqueeze(2) * mask.unsqueeze(1)
+        s = (cen ** 2).sum(2) ** 0.5 / lf
+        f = (cen ** 4).sum(2) ** 0.25 / lf
+        means_d += [(m.mean(0), m.std(0)), (s.mean(0), s.std(0)), (f.mean(0), f.std(0))]
+        stds_d += [(m.std(0), m.std(0)), (s.std(0), s.std(0)), (f.std(0), f.std(0))]
+        fourth_d += [(fourth_moment(m), m.std(0)), (fourth_moment(s), s.std(0)), (fourth_moment(f), f.std(0))]
+    return means_d + stds_d + fourth_d
+
+
+def feature_penalty(dists_d, dists_g, batch_size):
+    """audiogan.py:850-855."""
+    pen = 0
+    for r, f in zip(dists_d, dists_g):
+        pen = pen + torch.pow(r[0] - f[0], 2).mean() / batch_size
+    return pen
+
+
+# --------------------------------------------------------------------------
 # canonical G+D step (SURVEY.md section 8(d)): audiogan.py:706-788 and :816-921
 # minus the out-of-scope extras (FGSM passes, feature matching, REINFORCE,
 # logging).  All stochastic inputs are passed in.

@@ -42,8 +42,8 @@ OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tests', 'g
 WANTED = ['weight_norm', 'div_roundup', 'roundup', 'log_sigmoid', 'log_one_minus_sigmoid',
           'binary_cross_entropy_with_logits_per_sample', 'advanced_index', 'length_mask',
           'dynamic_rnn', 'check_grad', 'clip_grad', 'Residual', 'dense_res_bottleneck',
-          'Embedder', 'Generator', 'Discriminator']
-FLOORDIV_IN = {'div_roundup', 'roundup', 'Discriminator'}
+          'Embedder', 'Generator', 'Discriminator', 'fourth_moment', 'calc_dists']
+FLOORDIV_IN = {'div_roundup', 'roundup', 'Discriminator', 'fourth_moment'}   # integer '/' only
 
 
 def _blocks(text):
@@ -232,6 +232,12 @@ def main():
              **{'act%d' % i: a.detach().numpy() for i, a in enumerate(acts)},
              **{'actlen%d' % i: a.numpy() for i, a in enumerate(act_lens)},
              **_pack('sd.', _sd(d)), **_grads(d))
+
+    # ---- feature statistics (calc_dists / fourth_moment) on D's activations ---------------
+    dists = R.calc_dists([a.detach() for a in acts], act_lens)
+    np.savez(os.path.join(OUT, 'ref_calc_dists.npz'), n=len(dists),
+             **{'s%d' % i: t[0].numpy() for i, t in enumerate(dists)},
+             **{'d%d' % i: t[1].numpy() for i, t in enumerate(dists)})
 
     # ---- Embedder -------------------------------------------------------------
     torch.manual_seed(5)

@@ -125,3 +125,17 @@ def test_embedder(golden_dir):
     e.load_state_dict(_sd(v), strict=True)
     emb = e(torch.from_numpy(v['chars']), torch.from_numpy(v['clen']))
     np.testing.assert_allclose(emb.detach().numpy(), v['emb'], rtol=RTOL, atol=ATOL)
+
+
+def test_calc_dists_and_fourth_moment(golden_dir):
+    """audiogan.py:336-359 incl. the Python-2 ``(1/4) == 0`` exponent of fourth_moment"""
+    v = _load(golden_dir, 'ref_calc_dists.npz')
+    dv = _load(golden_dir, 'ref_discriminator.npz')
+    acts = [torch.from_numpy(dv['act%d' % i]) for i in range(3)]
+    lens = [torch.from_numpy(dv['actlen%d' % i]) for i in range(3)]
+    dists = O.calc_dists(acts, lens)
+    assert len(dists) == int(v['n']) == 27
+    for i, (s, d) in enumerate(dists):
+        np.testing.assert_allclose(s.numpy(), v['s%d' % i], rtol=1e-5, atol=1e-6, err_msg='stat %d' % i)
+        np.testing.assert_allclose(d.numpy(), v['d%d' % i], rtol=1e-5, atol=1e-6, err_msg='std %d' % i)
+    assert float(O.fourth_moment(torch.randn(5, 3)).min()) == 1.0
