@@ -50,7 +50,7 @@ def _run(dev, A):
     assert strong.float().mean() > 0.5
     np.testing.assert_array_equal(torch.sign(adv)[strong].numpy(), torch.sign(go_)[strong].numpy())
     assert float(adv.abs().max()) == pytest.approx(1e-3)
-XX
+    assert not adv[1, 112:].any()         # past the clip's length (+ receptive field) the input is masked out
     # ---- adversarial z (audiogan.py:99-137)
     z2 = X.adversarially_sample_z(g, d, B, T, 8, 128, c.to(dev), 0.01, c.to(dev), z=z.to(dev),
                                   noise=torch.zeros(B, 128).to(dev), stop='never')
