@@ -1,0 +1,56 @@
+"""Checkpoints with the reference's file naming (audiogan.py:936-939: ``%s-{dis,gen,eg,ed}-%05d``)
+but as ``state_dict``s instead of whole-module pickles, so they load into this package's modules AND
+into the reference's (the parameter names are identical, see tests/test_host_logic.py).  Optimiser
+state, step counters and RNG state -- which the reference never saved -- go
+into a fifth file ``%s-opt-%05d``."""
+import os
+
+import torch
+
+_ROLES = (('dis', 'd'), ('gen', 'g'), ('eg', 'e_g'), ('ed', 'e_d'))
+
+
+def _path(prefix, role, iteration):
+    return '%s-%s-%05d' % (prefix, role, iteration)
+
+
+def save(prefix, iteration, d=None, g=None, e_g=None, e_d=None, opt_d=None, opt_g=None, extra=None):
+    mods = dict(d=d, g=g, e_g=e_g, e_d=e_d)
+    written = []
+    for role, key in _ROLES:
+        m = mods[key]
+        if m is not None:
+            torch.save({k: v.detach().cpu() for k, v in m.state_dict().items()}, _path(prefix, role, iteration))
+            written.append(_path(prefix, role, iteration))
+    if opt_d is not None or opt_g is not None or extra is not None:
+        blob = dict(opt_d=_cpu(opt_d.state_dict()) if opt_d is not None else None,
+                    opt_g=_cpu(opt_g.state_dict()) if opt_g is not None else None,
+                    extra=extra, torch_rng=torch.get_rng_state())
+        torch.save(blob, _path(prefix, 'opt', iteration))
+        written.append(_path(prefix, 'opt', iteration))
+    return written
+
+
+def load(prefix, iteration, d=None, g=None, e_g=None, e_d=None, opt_d=None, opt_g=None, strict=True):
+    mods = dict(d=d, g=g, e_g=e_g, e_d=e_d)
+    for role, key in _ROLES:
+        m = mods[key]
+        if m is not None:
+            m.load_state_dict(torch.load(_path(prefix, role, iteration), map_location='cpu'), strict=strict)
+    extra = None
+    p = _path(prefix, 'opt', iteration)
+    if os.path.exists(p) and (opt_d is not None or opt_g is not None):
+        blob = torch.load(p, map_location='cpu', weights_only=False)
+        for o, key in ((opt_d, 'opt_d'), (opt_g, 'opt_g')):
+            if o is not None and blob.get(key) is not None:
+                o.load_state_dict(_to(blob[key], o.params[0].device))
+        extra = blob.get('extra')
+    return extra
+
+
+def _cpu(sd):
+    return {k: ([t.detach().cpu() for t in v] if isinstance(v, list) else v) for k, v in sd.items()}
+
+
+def _to(sd, dev):
+    return {k: ([t.to(dev) for t in v] if isinstance(v, list) else v) for k, v in sd.items()}
