@@ -125,8 +125,8 @@ def main():
     ap.add_argument('--batch', type=int, default=64, help='clips per GPU')
     ap.add_argument('--opt', default='adam', choices=['adam', 'rmsprop'],
                     help='adam = north_star; rmsprop = audiogan.py:693-694')
-    ap.add_argument('--cpu-batch', type=int, default=8)
-    ap.add_argument('--cpu-steps', type=int, default=2)
+    ap.add_argument('--cpu-batch', type=int, default=32)
+    ap.add_argument('--cpu-steps', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--force-phases', action='store_true',
