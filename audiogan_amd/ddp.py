@@ -10,8 +10,14 @@ import torch.distributed as dist
 class GradBucket(object):
     """Owns the flat gradient buffer of one network."""
 
-    def __init__(self, params, group=None):
-        self.params = [p for p in params]
+    def __init__(self, params, group=None, early=None):
+        """``early``: parameters whose gradients are final before the rest of backward has run (they
+        are laid out first, so their all-reduce can be issued while backward continues)."""
+        params = [p for p in params]
+        early = [p for p in (early or [])]
+        eid = set(id(p) for p in early)
+        self.params = early + [p for p in params if id(p) not in eid]
+        self.n_early = sum(p.numel() for p in early)
         self.group = group
         n = sum(p.numel() for p in self.params)
         dev = self.params[0].device
@@ -36,12 +42,16 @@ class GradBucket(object):
             o += p.numel()
         return True
 
-    def all_reduce(self, async_op=False):
-        """sum over ranks; returns the scale the optimiser must apply (1/world)"""
+    def all_reduce(self, async_op=False, part='all'):
+        """sum over ranks; returns the scale the optimiser must apply (1/world).  part: 'all', 'early'
+        (the leading n_early elements) or 'late' (the rest).  async_op=True: the collective runs on
+        RCCL's own stream (after everything already enqueued on the current stream); call wait()."""
         if self.world > 1:
-            self._work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
-            if not async_op:
-                self._work = None
+            buf = {'all': self.flat, 'early': self.flat[:self.n_early], 'late': self.flat[self.n_early:]}[part]
+            if buf.numel():
+                self._work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+                if not async_op:
+                    self._work = None
         return 1.0 / self.world
 
     def wait(self):

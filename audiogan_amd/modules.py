@@ -251,25 +251,38 @@ class Discriminator(nn.Module):
                 out.append(getattr(self.rnn, '%s_l%d%s' % (n, layer, suffix)))
         return out
 
-    def forward(self, x, length, c, percent_used=0.1):
-        ss, es = self._state_size, self._embed_size
-        b = x.size(0)
+    def features(self, x, length):
+        """the conv stack of forward() (audiogan.py:529-536): (activations, their lengths)"""
         length = length.to(x.device).long()
         # nframes after layer i = ceil(... ceil(length / s_1) ... / s_i) = ceil(length / (s_1 ... s_i)):
         # all layers in one broadcast op instead of one tiny kernel pair per layer (:533)
         prods = self._stride_prods(x.device)
         lens_all = (length.view(1, -1) + prods - 1) // prods
         lens_list = [lens_all[i] for i in range(lens_all.size(0))]
-        n = lens_list[-1]
         acts = ops.DConvStackFn.apply(x, self._stack, lens_list, *self._stack.group.params())
-        a = acts[-1]
-        tq = a.size(2)
+        return acts, lens_list
+
+    def classify(self, a, n, c):
+        """the rest of forward() (audiogan.py:537-549): biLSTM over [conv features, c] + heads -> logits"""
+        ss, es = self._state_size, self._embed_size
+        b, tq = a.size(0), a.size(2)
         seq = torch.cat([a.permute(2, 0, 1), c.unsqueeze(0).expand(tq, b, es)], 2)
         for layer in range(self._num_layers):
             seq = ops.LSTMSeqFn.apply(seq.contiguous(), n, 2, *self._rnn_weights(layer))
         # the heads are per-row: keep the LSTM's (time, clip) row order and transpose only the logits
         logits = ops.DHeadFn.apply(seq.reshape(tq * b, ss), self._head, *self._head.group.params())
-        return logits.view(tq, b).t(), list(acts), lens_list, n
+        return logits.view(tq, b).t()
+
+    def early_params(self):
+        """parameters whose gradients are complete BEFORE the conv stack's backward runs (heads + biLSTM):
+        their all-reduce can overlap that backward"""
+        conv = set(id(p) for p in self.cnn.parameters())
+        return [p for p in self.parameters() if id(p) not in conv]
+
+    def forward(self, x, length, c, percent_used=0.1):
+        acts, lens_list = self.features(x, length)
+        n = lens_list[-1]
+        return self.classify(acts[-1], n, c), list(acts), lens_list, n
 
 
 class Embedder(nn.Module):

@@ -97,3 +97,31 @@ def g_backward(g, d, opt_g, c, z, noise_fake, g_optim='boundary_seeking', stop='
         for p, r in zip(d.parameters(), flags):
             p.requires_grad_(r)
     return loss.detach()
+
+
+def d_backward_early(g, d, opt_d, real, real_len, c, z, noise_real, noise_fake, keep, stop='never'):
+    """critic forward + backward DOWN TO the conv features: afterwards the gradients of the heads and the
+    biLSTM (93 % of D's parameters, ``d.early_params()``) are final, so their all-reduce can run while
+    ``d_backward_late`` pushes the gradient through the conv stack.  ``keep`` carries the cut tensors."""
+    with torch.no_grad():
+        fake, _, _, fake_len = g(z=z, c=c, stop=stop)
+        fake = fake + noise_fake
+    B = real.size(0)
+    x = torch.cat([real + noise_real, fake], 0)
+    lens = torch.cat([real_len.to(fake_len.device), fake_len], 0)
+    acts, lens_list = d.features(x, lens)
+    a_cut = acts[-1].detach().requires_grad_(True)
+    nf = lens_list[-1]
+    cls = d.classify(a_cut, nf, torch.cat([c, c], 0))
+    loss_d, _ = masked_bce_mean(cls[:B], 0.9, nf[:B].contiguous())
+    loss_g, _ = masked_bce_mean(cls[B:], 0.0, nf[B:].contiguous())
+    loss = loss_d + loss_g
+    opt_d.zero_grad()
+    loss.backward()
+    keep['acts'], keep['a_cut'] = acts, a_cut
+    return loss.detach()
+
+
+def d_backward_late(keep):
+    """the conv stack's backward (weight gradients of D's cnn) from the cut gradient"""
+    keep['acts'][-1].backward(keep['a_cut'].grad)

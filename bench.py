@@ -159,7 +159,8 @@ def main():
     if multi:
         ddp.broadcast_parameters(g)
         ddp.broadcast_parameters(d)
-        bd, bg = ddp.GradBucket(list(d.parameters())), ddp.GradBucket(list(g.parameters()))
+        bd = ddp.GradBucket(list(d.parameters()), early=d.early_params())
+        bg = ddp.GradBucket(list(g.parameters()))
         opt_d.bucket, opt_g.bucket = bd, bg
         hook_d, hook_g = bd.all_reduce, bg.all_reduce
     batch = synthetic_batch(args.batch, dev, seed=1000 + rank)
@@ -188,13 +189,15 @@ def main():
     graph = None
     phases = None
     capture_error = None
+    keep = {}
 
-    def capture(fn):
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            fn()
-        torch.cuda.current_stream().wait_stream(side)
+    def capture(fn, warm=True):
+        if warm:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                fn()
+            torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         gr = torch.cuda.CUDAGraph()
         # thread_local: other threads (e.g. the RCCL watchdog) may keep calling HIP while we capture
@@ -211,14 +214,17 @@ def main():
                 graph.replay()
             else:
                 scale = 1.0 / world
-                g1 = capture(lambda: train.d_backward(g, d, opt_d, b_['real'], b_['real_len'], b_['c'], b_['z'],
-                                                      b_['noise_real'], b_['noise_fake']))
+                # critic: graph 1a ends where the gradients of heads + biLSTM are final; their all-reduce
+                # (93 % of D's bytes) then runs on RCCL's stream WHILE graph 1b does the conv-stack backward
+                g1a = capture(lambda: train.d_backward_early(g, d, opt_d, b_['real'], b_['real_len'], b_['c'],
+                                                             b_['z'], b_['noise_real'], b_['noise_fake'], keep))
+                g1b = capture(lambda: train.d_backward_late(keep), warm=False)
                 bd.all_reduce()
                 g2 = capture(lambda: opt_d.step(clip_norm=1.0, grad_scale=scale))
                 g3 = capture(lambda: train.g_backward(g, d, opt_g, b_['c'], b_['z'], b_['noise_fake']))
                 bg.all_reduce()
                 g4 = capture(lambda: opt_g.step(clip_norm=0.1, grad_scale=scale))
-                phases = (g1, g2, g3, g4)
+                phases = (g1a, g1b, g2, g3, g4)
             torch.cuda.synchronize()
         except Exception as e:  # noqa: BLE001
             sys.stderr.write('hipGraph capture failed (%s: %s); running eagerly\n' % (type(e).__name__, e))
@@ -230,12 +236,15 @@ def main():
         if graph is not None:
             graph.replay()
         elif phases is not None:
-            phases[0].replay()
-            bd.all_reduce()
-            phases[1].replay()
-            phases[2].replay()
+            phases[0].replay()                         # critic fwd + bwd of heads / biLSTM
+            bd.all_reduce(async_op=True, part='early') # overlaps ...
+            phases[1].replay()                         # ... the conv-stack backward
+            bd.wait()
+            bd.all_reduce(part='late')
+            phases[2].replay()                         # opt_d
+            phases[3].replay()                         # generator fwd + bwd
             bg.all_reduce()
-            phases[3].replay()
+            phases[4].replay()                         # opt_g
         else:
             one_step(train, g, d, opt_g, opt_d, batch, hook_d, hook_g)
 
@@ -278,7 +287,8 @@ def main():
                        'global_batch': world * args.batch, 'clip_len': L,
                        'parallelism': 'dp%d' % world,
                        'launch': ('hipGraph replay (1 graph per step)' if graph is not None else
-                                  'hipGraph replay (4 graphs per step, RCCL all-reduce between)' if phases is not None
+                                  'hipGraph replay (5 graphs per step; D all-reduce overlaps the conv-stack backward)'
+                                  if phases is not None
                                   else 'eager' + (' (capture failed: %s)' % capture_error if capture_error else ''))},
         }
         if dominant is not None and dominant in rec:

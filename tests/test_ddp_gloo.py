@@ -42,12 +42,27 @@ def _steps(A, g, d, b, buckets=False):
     hd = hg = None
     if buckets:
         ddp.broadcast_parameters(g); ddp.broadcast_parameters(d)
-        bd, bg = ddp.GradBucket(list(d.parameters())), ddp.GradBucket(list(g.parameters()))
+        bd = ddp.GradBucket(list(d.parameters()), early=d.early_params())
+        bg = ddp.GradBucket(list(g.parameters()))
+        assert 0 < bd.n_early < bd.flat.numel()
         od.bucket, og.bucket = bd, bg
         hd, hg = bd.all_reduce, bg.all_reduce
-    for _ in range(2):
-        train.d_step(g, d, od, b['real'], b['real_len'], b['c'], b['z'], b['nr'], b['nf'], 1.0, grad_hook=hd)
-        train.g_step(g, d, og, b['c'], b['z'], b['nf'], 0.1, grad_hook=hg)
+    for it in range(2):
+        if buckets and it == 1:
+            # the phase-split critic iteration of bench.py's multi-GPU path: all-reduce of the heads /
+            # biLSTM gradients issued asynchronously before the conv-stack backward runs
+            keep = {}
+            train.d_backward_early(g, d, od, b['real'], b['real_len'], b['c'], b['z'], b['nr'], b['nf'], keep)
+            bd.all_reduce(async_op=True, part='early')
+            train.d_backward_late(keep)
+            bd.wait()
+            scale = bd.all_reduce(part='late')
+            od.step(clip_norm=1.0, grad_scale=scale)
+            train.g_backward(g, d, og, b['c'], b['z'], b['nf'])
+            og.step(clip_norm=0.1, grad_scale=bg.all_reduce())
+        else:
+            train.d_step(g, d, od, b['real'], b['real_len'], b['c'], b['z'], b['nr'], b['nf'], 1.0, grad_hook=hd)
+            train.g_step(g, d, og, b['c'], b['z'], b['nf'], 0.1, grad_hook=hg)
         if buckets:
             assert bd.check_views() and bg.check_views(), 'autograd must accumulate into the flat bucket'
     return {k: v.clone() for k, v in list(g.state_dict().items()) + list(d.state_dict().items())}
