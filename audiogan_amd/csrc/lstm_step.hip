@@ -425,6 +425,131 @@ __global__ __launch_bounds__(256) void lstm_cell_bwd2_kernel(const CellBwd2P p) 
   D.dh_pass[(int64_t)b * H + j] = 0.f;
 }
 
+// ------------------------------------------------------------------------------------------
+// fused backward step: product of the NEXT processed step + cell backward of THIS step.
+//   dh[m,u] = dh_pass_in[m,u] + sum_kk dgates_{k+1}[m,kk] * W_hh[kk,u]        (k < T-1)
+//   (dgates_k, dc_prev, dh_pass_out) = cell_bwd(dh + dy_k, dc_next, saved gates / cells of step k)
+// One workgroup = 16 clips x 16 hidden units; its 16 waves split K = 4H and are summed through LDS,
+// so the result is complete inside the workgroup (no atomics) and the cell backward runs in the
+// epilogue: ONE launch per time step instead of a pointwise launch plus an atomic product launch.
+// ------------------------------------------------------------------------------------------
+struct BwdStepDir {
+  const float* dg_next;  // [B,4H] dgates of the previously processed step (k+1), or NULL when k == T-1
+  const float* whh;      // [4H,H]
+  const float* ga;       // activated gates of step k [B,4H]
+  const float* c_prev;   // [B,H]
+  const float* c_new;    // [B,H]
+  const float* dy;       // [B,ldy] slice
+  const float* dc_next;  // [B,H] or NULL
+  const float* dh_pass_in;  // [B,H] or NULL
+  float* dgates;         // [B,4H] (out)
+  float* dc_prev;        // [B,H] (out)
+  float* dh_pass_out;    // [B,H] (out)
+  int ldy, t;
+};
+struct BwdStepP {
+  BwdStepDir d[2];
+  const int64_t* valid;
+  int B, H;
+};
+
+// 16 clips x 16 units per workgroup (v_mfma_f32_16x16x4_f32: lane (i = l&15, g = l>>4) supplies
+// A[i][k-slot g] and B[k-slot g][i]).  A lane loads one float4 of its dgates row per 16-k unit and the
+// four MFMAs of the unit take elements 0..3 as k = 16u + 4g + e, so the row is read 16 bytes at a time.
+// The step is latency bound (W_hh comes from the fabric every step: L2 is not coherent across
+// launches), so every load of a wave's K range is requested before the first MFMA.
+#define BWD_UB 8      // 16-k units requested per round (8 float4 + 32 dwords in flight per lane)
+template <int MT>      // 16-clip row tiles per workgroup (they share the W_hh registers)
+__global__ __launch_bounds__(1024) void lstm_step_bwd_kernel(const BwdStepP p) {
+  __shared__ float red[16 * 256 * MT];
+  // (an XCD-aware workgroup order - one direction and a fixed quarter of the unit tiles per XCD, to cut
+  // the per-step L2 fills - was measured: no change, the step is bound by launch + fp32 MFMA time)
+  const int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  const BwdStepDir& D = p.d[by];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  const int H = p.H, B = p.B;
+  const int n0 = bx * 16, m0 = bz * 16 * MT;
+  // epilogue (clip, unit) of threads 0..256*MT-1; operands requested up front
+  const int eu = n0 + (threadIdx.x & 15), em = m0 + ((threadIdx.x >> 4) & (16 * MT - 1));
+  const bool epi = threadIdx.x < 256 * MT && em < B;
+  float ig = 0.f, fg = 0.f, gg = 0.f, og = 0.f, cp = 0.f, cn = 0.f, dyv = 0.f, dcn = 0.f, dpi = 0.f;
+  bool padded = false;
+  if (epi) {
+    const float* gr = D.ga + (int64_t)em * 4 * H + eu;
+    ig = gr[0]; fg = gr[H]; gg = gr[2 * H]; og = gr[3 * H];
+    const int64_t o = (int64_t)em * H + eu;
+    cp = D.c_prev[o];
+    cn = D.c_new[o];
+    dyv = D.dy[(int64_t)em * D.ldy + eu];
+    if (D.dc_next) dcn = D.dc_next[o];
+    if (D.dh_pass_in) dpi = D.dh_pass_in[o];
+    padded = p.valid && D.t >= p.valid[em];
+  }
+  f32x4 acc[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (D.dg_next) {
+    const int KU = (4 * H) >> 4;                        // 16-k units
+    const int u0 = KU * wid / 16, u1 = KU * (wid + 1) / 16;
+    // rows past B are clamped: they only feed their own (unwritten) output rows
+    const float* ar[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) ar[t] = D.dg_next + (int64_t)min(m0 + 16 * t + li, B - 1) * 4 * H + 4 * g;
+    const float* br = D.whh + (int64_t)(4 * g) * H + n0 + li;
+    for (int ub = u0; ub < u1; ub += BWD_UB) {
+      f32x4 a[MT][BWD_UB];
+      float b[BWD_UB][4];
+#pragma unroll
+      for (int i = 0; i < BWD_UB; ++i) {
+        const int u = min(ub + i, u1 - 1);
+#pragma unroll
+        for (int t = 0; t < MT; ++t) a[t][i] = *reinterpret_cast<const f32x4*>(ar[t] + 16 * u);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) b[i][e] = br[(int64_t)(16 * u + e) * H];
+      }
+#pragma unroll
+      for (int i = 0; i < BWD_UB; ++i) {
+        if (ub + i < u1) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+              acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][i][e], b[i][e], acc[t], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // C layout: col = lane & 15, row = 4 * (lane >> 4) + e
+#pragma unroll
+  for (int t = 0; t < MT; ++t)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[wid * 256 * MT + (16 * t + 4 * g + e) * 16 + li] = acc[t][e];
+  __syncthreads();
+  if (!epi) return;
+  const int o256 = threadIdx.x;        // = (row em - m0) * 16 + (col eu - n0)
+  float dhf = dpi;                     // gradient reaching h_k from later steps
+#pragma unroll
+  for (int w = 0; w < 16; ++w) dhf += red[w * 256 * MT + o256];
+  float* dg = D.dgates + (int64_t)em * 4 * H + eu;
+  const int64_t o = (int64_t)em * H + eu;
+  if (padded) {
+    dg[0] = 0.f; dg[H] = 0.f; dg[2 * H] = 0.f; dg[3 * H] = 0.f;
+    D.dc_prev[o] = dcn;
+    D.dh_pass_out[o] = dhf;
+    return;
+  }
+  const float dhv = dhf + dyv;
+  const float tc = tanhf(cn);
+  const float dc = dcn + dhv * og * (1.f - tc * tc);
+  dg[0] = dc * gg * ig * (1.f - ig);
+  dg[H] = dc * cp * fg * (1.f - fg);
+  dg[2 * H] = dc * ig * (1.f - gg * gg);
+  dg[3 * H] = dhv * tc * og * (1.f - og);
+  D.dc_prev[o] = dc * fg;
+  D.dh_pass_out[o] = 0.f;
+}
+
 // Whole layer backward through time: per step ONE pointwise launch and ONE K-split skinny
 // product  dh_{k-1} += dgates_k * W_hh  (atomics into the buffer that already holds the
 // pass-through term of padded rows); both directions share each launch.
@@ -441,6 +566,39 @@ extern "C" int ag_lstm_seq_bwd(const float* const* gates, const float* const* wh
   AG_REQUIRE(0 <= k_begin && k_begin <= k_end && k_end <= T, "ag_lstm_seq_bwd: bad step range");
   hipStream_t st = (hipStream_t)stream;
   const int64_t BH = (int64_t)B * H, BG = (int64_t)B * 4 * H;
+  if (phases == 3 && H % 16 == 0) {
+    // fused path: launch k = product of step k+1 + cell backward of step k
+    for (int k = k_end - 1; k >= k_begin; --k) {
+      BwdStepP q;
+      q.valid = valid_i64; q.B = B; q.H = H;
+      for (int d = 0; d < ndir; ++d) {
+        const int t = d == 0 ? k : T - 1 - k;
+        const int tn = d == 0 ? k + 1 : T - 2 - k;     // time index of processing step k+1
+        BwdStepDir& D = q.d[d];
+        D.dg_next = (k == T - 1) ? nullptr : dgates[d] + (int64_t)tn * BG;
+        D.whh = whh[d];
+        D.ga = gates[d] + (int64_t)t * BG;
+        D.c_prev = c_all[d] + (int64_t)k * BH;
+        D.c_new = c_all[d] + (int64_t)(k + 1) * BH;
+        D.dy = dy + (int64_t)t * B * ndir * H + (int64_t)d * H;
+        D.ldy = ndir * H;
+        D.dc_next = (k == T - 1) ? nullptr : dcbuf[d] + ((k + 1) & 1) * BH;
+        D.dh_pass_in = (k == T - 1) ? nullptr : dhbuf[d] + ((k + 1) & 1) * BH;
+        D.dgates = dgates[d] + (int64_t)t * BG;
+        D.dc_prev = dcbuf[d] + (k & 1) * BH;
+        D.dh_pass_out = dhbuf[d] + (k & 1) * BH;
+        D.t = t;
+      }
+      if (ndir == 1) q.d[1] = q.d[0];
+      // one wave of workgroups fills the 256 CUs: two row tiles per workgroup once a single one would not
+      if ((int64_t)(H / 16) * ndir * ag_cdiv(B, 16) > 256)
+        hipLaunchKernelGGL(lstm_step_bwd_kernel<2>, dim3(H / 16, ndir, ag_cdiv(B, 32)), dim3(1024), 0, st, q);
+      else
+        hipLaunchKernelGGL(lstm_step_bwd_kernel<1>, dim3(H / 16, ndir, ag_cdiv(B, 16)), dim3(1024), 0, st, q);
+      AG_CHECK_LAUNCH("ag_lstm_seq_bwd(step)");
+    }
+    return AG_OK;
+  }
   for (int k = k_end - 1; k >= k_begin; --k) {
     CellBwd2P c;
     c.valid = valid_i64; c.B = B; c.H = H;

@@ -555,7 +555,11 @@ def _lstm_seq_fwd_range(pre, whh, c_all, hbuf, y, valid, k0, k1):
 def lstm_seq_bwd(gates, whh, c_all, dy, dgates, dhbuf, dcbuf, valid):
     T = gates[0].size(0)
     if Profiler.enabled:
+        H = gates[0].size(2) // 4
         for k_ in reversed(range(T)):
+            if H % 16 == 0:     # the fused step kernel (product of step k+1 + cell backward of step k)
+                _lstm_seq_bwd_step(gates, whh, c_all, dy, dgates, dhbuf, dcbuf, valid, k_, k_ + 1, 3)
+                continue
             _lstm_seq_bwd_cell(gates, whh, c_all, dy, dgates, dhbuf, dcbuf, valid, k_, k_ + 1, 1)
             if k_ > 0:
                 _lstm_seq_bwd_prod(gates, whh, c_all, dy, dgates, dhbuf, dcbuf, valid, k_, k_ + 1, 2)
@@ -568,6 +572,10 @@ def _lstm_seq_bwd_cell(*a):
 
 
 def _lstm_seq_bwd_prod(*a):
+    _lstm_seq_bwd_range(*a)
+
+
+def _lstm_seq_bwd_step(*a):
     _lstm_seq_bwd_range(*a)
 
 
@@ -611,6 +619,12 @@ def _work_seq_bwd_prod(gates, whh, *a_, **kw):
     return 'skinny_gemm_kernel', 2.0 * nd * B * H4 * (H4 // 4), 4.0 * nd * (H4 * (H4 // 4) + 2 * B * H4)
 
 
+def _work_seq_bwd_step(gates, whh, *a_, **kw):
+    T, B, H4 = gates[0].shape
+    nd = len(gates)
+    return 'lstm_step_bwd_kernel', 2.0 * nd * B * H4 * (H4 // 4), 4.0 * nd * (H4 * (H4 // 4) + 5.5 * B * H4)
+
+
 def _work_seq_bwd_cell(gates, whh, *a_, **kw):
     T, B, H4 = gates[0].shape
     return 'lstm_cell_bwd2_kernel', 0.0, 4.0 * len(gates) * B * H4 * 3.5
@@ -618,7 +632,7 @@ def _work_seq_bwd_cell(gates, whh, *a_, **kw):
 
 for _n, _w in (('skinny_gemm', _work_skinny), ('lstm_step_fwd', _work_step),
                ('_lstm_seq_fwd_range', _work_seq_fwd), ('_lstm_seq_bwd_prod', _work_seq_bwd_prod),
-               ('_lstm_seq_bwd_cell', _work_seq_bwd_cell)):
+               ('_lstm_seq_bwd_cell', _work_seq_bwd_cell), ('_lstm_seq_bwd_step', _work_seq_bwd_step)):
     _instrument(_n, _w)
 
 

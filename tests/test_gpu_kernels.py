@@ -354,7 +354,7 @@ def test_lstm_step_fwd(K, B, H, Kx):
 
 
 @pytest.mark.parametrize('T,B,H,ndir,ragged', [(128, 64, 512, 2, True), (16, 128, 64, 2, True), (5, 3, 8, 2, True), (7, 33, 24, 1, False),
-                                               (1, 4, 16, 2, True)])
+                                               (1, 4, 16, 2, True), (6, 40, 96, 1, True), (9, 70, 32, 2, True), (3, 150, 512, 2, True)])
 def test_lstm_seq_fwd_bwd(K, T, B, H, ndir, ragged):
     gen = torch.Generator().manual_seed(15)
     pre = [torch.randn(T, B, 4 * H, generator=gen) for _ in range(ndir)]
