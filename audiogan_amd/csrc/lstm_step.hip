@@ -71,6 +71,38 @@ __device__ __forceinline__ void skinny_core_nt(f32x16& acc, const float* __restr
   if (k + 8 <= k1) nt_batch<1>(acc, ar, br, k);
 }
 
+// the same for MT 32-row tiles that share the B registers (acc[t], ar[t])
+template <int UNR, int MT>
+__device__ __forceinline__ void nt_batch_mt(f32x16* acc, const float* const* ar, const float* __restrict__ br, int k) {
+  f32x4 a[MT][UNR], b[UNR];
+#pragma unroll
+  for (int u = 0; u < UNR; ++u) {
+    b[u] = *reinterpret_cast<const f32x4*>(br + k + 8 * u);
+#pragma unroll
+    for (int t = 0; t < MT; ++t) a[t][u] = *reinterpret_cast<const f32x4*>(ar[t] + k + 8 * u);
+  }
+#pragma unroll
+  for (int u = 0; u < UNR; ++u)
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t][u][e], b[u][e], acc[t], 0, 0, 0);
+}
+
+template <int MT>
+__device__ __forceinline__ void skinny_core_nt_mt(f32x16* acc, const float* const* arow, const float* __restrict__ brow,
+                                                  int k0, int k1, int h) {
+  const float* ar[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) ar[t] = arow[t] + 4 * h;
+  const float* br = brow + 4 * h;
+  int k = k0;
+  for (; k + 64 <= k1; k += 64) nt_batch_mt<8, MT>(acc, ar, br, k);
+  if (k + 32 <= k1) { nt_batch_mt<4, MT>(acc, ar, br, k); k += 32; }
+  if (k + 16 <= k1) { nt_batch_mt<2, MT>(acc, ar, br, k); k += 16; }
+  if (k + 8 <= k1) nt_batch_mt<1, MT>(acc, ar, br, k);
+}
+
 // B stored [K][N]: lane j reads B[k][n0+j] (coalesced along n)
 template <int UNR>
 __device__ __forceinline__ void nn_batch(f32x16& acc, const float* __restrict__ ar,
@@ -221,6 +253,7 @@ struct LstmStepP {
   int skip_h;          // 1: h_prev is known to be zero (first step) -> skip that product
 };
 
+template <int MT>      // 32-clip row tiles per workgroup (they share the weight registers)
 __global__ __launch_bounds__(512) void lstm_step_fwd_kernel(const LstmStepP p) {
   extern __shared__ float red[];
   const LstmDir& D = p.d[blockIdx.y];
@@ -228,64 +261,89 @@ __global__ __launch_bounds__(512) void lstm_step_fwd_kernel(const LstmStepP p) {
   const int l31 = lane & 31, h = lane >> 5;
   const int H = p.H, B = p.B;
   const int u0 = blockIdx.x * 8;
-  const int m0 = blockIdx.z * 32;
+  const int m0 = blockIdx.z * 32 * MT;
   // column j of this workgroup's 32-wide tile = gate (j>>3), hidden unit u0 + (j&7)
   const int unit = u0 + (l31 & 7);
-  const bool bok = unit < H, aok = (m0 + l31) < B;
+  const bool bok = unit < H;
   const int row = (l31 >> 3) * H + (bok ? unit : 0);
-  const int arow_i = aok ? m0 + l31 : 0;
-  // epilogue operands of this thread's (clip, unit) pair are requested FIRST so that their
+  // epilogue operands of this thread's (clip, unit) pairs are requested FIRST so that their
   // latency overlaps the product (one dependent memory round trip less per time step)
   const int euu = threadIdx.x & 7, emm = (threadIdx.x >> 3) & 31;
-  const int eu = u0 + euu, em = m0 + emm;
-  const bool epi = threadIdx.x < 256 && em < B && eu < H;
-  float pre4[4] = {0.f, 0.f, 0.f, 0.f}, cp = 0.f, hp = 0.f;
-  bool padded = false;
-  if (epi) {
-    const float* pre = D.pre + (int64_t)em * 4 * H + eu;
-    pre4[0] = pre[0]; pre4[1] = pre[H]; pre4[2] = pre[2 * H]; pre4[3] = pre[3 * H];
-    cp = D.c_prev[(int64_t)em * H + eu];
-    padded = p.valid && D.t >= p.valid[em];
-    if (padded) hp = D.h_prev[(int64_t)em * H + eu];
-  }
-  f32x16 acc;
+  const int eu = u0 + euu;
+  const bool ethread = threadIdx.x < 256 && eu < H;
+  float pre4[MT][4], cp[MT], hp[MT];
+  bool padded[MT], epi[MT];
 #pragma unroll
-  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  for (int t = 0; t < MT; ++t) {
+    const int em = m0 + 32 * t + emm;
+    epi[t] = ethread && em < B;
+    pre4[t][0] = pre4[t][1] = pre4[t][2] = pre4[t][3] = 0.f;
+    cp[t] = hp[t] = 0.f;
+    padded[t] = false;
+    if (epi[t]) {
+      const float* pre = D.pre + (int64_t)em * 4 * H + eu;
+      pre4[t][0] = pre[0]; pre4[t][1] = pre[H]; pre4[t][2] = pre[2 * H]; pre4[t][3] = pre[3 * H];
+      cp[t] = D.c_prev[(int64_t)em * H + eu];
+      padded[t] = p.valid && D.t >= p.valid[em];
+      if (padded[t]) hp[t] = D.h_prev[(int64_t)em * H + eu];
+    }
+  }
+  f32x16 acc[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
   // split the concatenated K axis [x | h] over the waves in units of 8
   const int KxU = D.x ? (D.Kx >> 3) : 0;
   const int KhU = p.skip_h ? 0 : (H >> 3);
   const int KU = KxU + KhU;
   const int s0 = (int)((int64_t)KU * wid / nw), s1 = (int)((int64_t)KU * (wid + 1) / nw);
+  const float* arow[MT];
   if (s0 < KxU) {
     const int e1 = s1 < KxU ? s1 : KxU;
-    skinny_core_nt(acc, D.x + (int64_t)arow_i * D.ldx, aok, D.wx + (int64_t)row * D.ldwx, bok, s0 * 8,
-                   e1 * 8, h);
+#pragma unroll
+    for (int t = 0; t < MT; ++t) arow[t] = D.x + (int64_t)min(m0 + 32 * t + l31, B - 1) * D.ldx;
+    skinny_core_nt_mt<MT>(acc, arow, D.wx + (int64_t)row * D.ldwx, s0 * 8, e1 * 8, h);
   }
   if (s1 > KxU) {
     const int b0 = (s0 > KxU ? s0 : KxU) - KxU;
-    skinny_core_nt(acc, D.h_prev + (int64_t)arow_i * H, aok, D.whh + (int64_t)row * H, bok, b0 * 8,
-                   (s1 - KxU) * 8, h);
+#pragma unroll
+    for (int t = 0; t < MT; ++t) arow[t] = D.h_prev + (int64_t)min(m0 + 32 * t + l31, B - 1) * H;
+    skinny_core_nt_mt<MT>(acc, arow, D.whh + (int64_t)row * H, b0 * 8, (s1 - KxU) * 8, h);
   }
-  block_reduce_acc(acc, red, nw, wid, lane);
+  // per-wave accumulators -> LDS, element (t, e, lane) of wave w at red[(w*MT + t)*1024 + e*64 + lane]
+#pragma unroll
+  for (int t = 0; t < MT; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) red[(size_t)(wid * MT + t) * 1024 + e * 64 + lane] = acc[t][e];
+  __syncthreads();
   // epilogue: (m, unit) pairs; the 4 gates of a pair sit at columns uu, 8+uu, 16+uu, 24+uu
-  if (!epi) return;
-  {
-    // inverse of row = (e&3) + 8*(e>>2) + 4*(lane>>5)
-    const int hh = (emm >> 2) & 1, e = (emm & 3) + 4 * (emm >> 3);
-    const float* rr = red + (size_t)e * 64 + 32 * hh;
+  if (!ethread) return;
+  // inverse of row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+  const int hh = (emm >> 2) & 1, e = (emm & 3) + 4 * (emm >> 3);
+#pragma unroll
+  for (int t = 0; t < MT; ++t) {
+    if (!epi[t]) continue;
+    const int em = m0 + 32 * t + emm;
+    float pr[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int w = 0; w < nw; ++w) {
+      const float* rr = red + (size_t)(w * MT + t) * 1024 + e * 64 + 32 * hh + euu;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) pr[q] += rr[8 * q];
+    }
     float* pre = D.pre + (int64_t)em * 4 * H + eu;
     const int64_t o = (int64_t)em * H + eu;
-    if (padded) {
-      D.h_out[o] = hp;
-      D.c_out[o] = cp;
+    if (padded[t]) {
+      D.h_out[o] = hp[t];
+      D.c_out[o] = cp[t];
       if (D.y_out) D.y_out[(int64_t)em * D.ldy + eu] = 0.f;
-      return;
+      continue;
     }
-    const float ig = ag_sigmoid(pre4[0] + rr[euu]);
-    const float fg = ag_sigmoid(pre4[1] + rr[8 + euu]);
-    const float gg = tanhf(pre4[2] + rr[16 + euu]);
-    const float og = ag_sigmoid(pre4[3] + rr[24 + euu]);
-    const float cn = fg * cp + ig * gg;
+    const float ig = ag_sigmoid(pre4[t][0] + pr[0]);
+    const float fg = ag_sigmoid(pre4[t][1] + pr[1]);
+    const float gg = tanhf(pre4[t][2] + pr[2]);
+    const float og = ag_sigmoid(pre4[t][3] + pr[3]);
+    const float cn = fg * cp[t] + ig * gg;
     const float hn = og * tanhf(cn);
     pre[0] = ig;
     pre[H] = fg;
@@ -299,9 +357,14 @@ __global__ __launch_bounds__(512) void lstm_step_fwd_kernel(const LstmStepP p) {
 
 static int launch_lstm_step(const LstmStepP& p, int ndir, hipStream_t st) {
   const int nw = 8;
-  const size_t lds = (size_t)nw * 1024 * sizeof(float);
-  dim3 grid(ag_cdiv(p.H, 8), ndir, ag_cdiv(p.B, 32));
-  hipLaunchKernelGGL(lstm_step_fwd_kernel, grid, dim3(64 * nw), lds, st, p);
+  // one wave of workgroups on the 256 CUs: two 32-clip tiles per workgroup once single tiles would not fit
+  if ((int64_t)ag_cdiv(p.H, 8) * ndir * ag_cdiv(p.B, 32) > 256) {
+    dim3 grid(ag_cdiv(p.H, 8), ndir, ag_cdiv(p.B, 64));
+    hipLaunchKernelGGL(lstm_step_fwd_kernel<2>, grid, dim3(64 * nw), (size_t)nw * 2048 * sizeof(float), st, p);
+  } else {
+    dim3 grid(ag_cdiv(p.H, 8), ndir, ag_cdiv(p.B, 32));
+    hipLaunchKernelGGL(lstm_step_fwd_kernel<1>, grid, dim3(64 * nw), (size_t)nw * 1024 * sizeof(float), st, p);
+  }
   AG_CHECK_LAUNCH("ag_lstm_step_fwd");
   return AG_OK;
 }
@@ -459,20 +522,24 @@ struct BwdStepP {
 // The step is latency bound (W_hh comes from the fabric every step: L2 is not coherent across
 // launches), so every load of a wave's K range is requested before the first MFMA.
 #define BWD_UB 8      // 16-k units requested per round (8 float4 + 32 dwords in flight per lane)
-template <int MT>      // 16-clip row tiles per workgroup (they share the W_hh registers)
+template <int MT, int NT>      // 16-clip row tiles x 16-unit column tiles per workgroup (register reuse)
 __global__ __launch_bounds__(1024) void lstm_step_bwd_kernel(const BwdStepP p) {
-  __shared__ float red[16 * 256 * MT];
+  constexpr int TM = 16 * MT, TN = 16 * NT;
+  __shared__ float red[16 * TM * TN];
   // (an XCD-aware workgroup order - one direction and a fixed quarter of the unit tiles per XCD, to cut
-  // the per-step L2 fills - was measured: no change, the step is bound by launch + fp32 MFMA time)
-  const int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
-  const BwdStepDir& D = p.d[by];
+  // the per-step L2 fills - was measured: no change)
+  const BwdStepDir& D = p.d[blockIdx.y];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int li = lane & 15, g = lane >> 4;
   const int H = p.H, B = p.B;
-  const int n0 = bx * 16, m0 = bz * 16 * MT;
-  // epilogue (clip, unit) of threads 0..256*MT-1; operands requested up front
-  const int eu = n0 + (threadIdx.x & 15), em = m0 + ((threadIdx.x >> 4) & (16 * MT - 1));
-  const bool epi = threadIdx.x < 256 * MT && em < B;
+  // 16-unit tiles split a 128-byte W_hh line between two workgroups: put both on the same XCD (same L2);
+  // workgroup ids go round-robin over the 8 XCDs and blockIdx.x is the fastest index
+  int bx = blockIdx.x;
+  if (NT == 1 && (gridDim.x & 15) == 0) bx = (bx & ~15) | ((bx & 7) << 1) | ((bx >> 3) & 1);
+  const int n0 = bx * TN, m0 = blockIdx.z * TM;
+  // epilogue (clip, unit) of threads 0..TM*TN-1; operands requested up front
+  const int eu = n0 + (threadIdx.x % TN), em = m0 + (threadIdx.x / TN) % TM;
+  const bool epi = threadIdx.x < TM * TN && em < B && eu < H;
   float ig = 0.f, fg = 0.f, gg = 0.f, og = 0.f, cp = 0.f, cn = 0.f, dyv = 0.f, dcn = 0.f, dpi = 0.f;
   bool padded = false;
   if (epi) {
@@ -486,27 +553,33 @@ __global__ __launch_bounds__(1024) void lstm_step_bwd_kernel(const BwdStepP p) {
     if (D.dh_pass_in) dpi = D.dh_pass_in[o];
     padded = p.valid && D.t >= p.valid[em];
   }
-  f32x4 acc[MT];
+  f32x4 acc[MT][NT];
 #pragma unroll
-  for (int t = 0; t < MT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < MT; ++t)
+#pragma unroll
+    for (int c = 0; c < NT; ++c) acc[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
   if (D.dg_next) {
     const int KU = (4 * H) >> 4;                        // 16-k units
     const int u0 = KU * wid / 16, u1 = KU * (wid + 1) / 16;
-    // rows past B are clamped: they only feed their own (unwritten) output rows
+    // rows / units past the end are clamped: they only feed their own (unwritten) outputs
     const float* ar[MT];
+    const float* br[NT];
 #pragma unroll
     for (int t = 0; t < MT; ++t) ar[t] = D.dg_next + (int64_t)min(m0 + 16 * t + li, B - 1) * 4 * H + 4 * g;
-    const float* br = D.whh + (int64_t)(4 * g) * H + n0 + li;
+#pragma unroll
+    for (int c = 0; c < NT; ++c) br[c] = D.whh + (int64_t)(4 * g) * H + min(n0 + 16 * c + li, H - 1);
     for (int ub = u0; ub < u1; ub += BWD_UB) {
       f32x4 a[MT][BWD_UB];
-      float b[BWD_UB][4];
+      float b[NT][BWD_UB][4];
 #pragma unroll
       for (int i = 0; i < BWD_UB; ++i) {
         const int u = min(ub + i, u1 - 1);
 #pragma unroll
         for (int t = 0; t < MT; ++t) a[t][i] = *reinterpret_cast<const f32x4*>(ar[t] + 16 * u);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) b[i][e] = br[(int64_t)(16 * u + e) * H];
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int c = 0; c < NT; ++c) b[c][i][e] = br[c][(int64_t)(16 * u + e) * H];
       }
 #pragma unroll
       for (int i = 0; i < BWD_UB; ++i) {
@@ -515,22 +588,26 @@ __global__ __launch_bounds__(1024) void lstm_step_bwd_kernel(const BwdStepP p) {
           for (int e = 0; e < 4; ++e)
 #pragma unroll
             for (int t = 0; t < MT; ++t)
-              acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][i][e], b[i][e], acc[t], 0, 0, 0);
+#pragma unroll
+              for (int c = 0; c < NT; ++c)
+                acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][i][e], b[c][i][e], acc[t][c], 0, 0, 0);
         }
       }
     }
   }
-  // C layout: col = lane & 15, row = 4 * (lane >> 4) + e
+  // C layout of a 16x16 tile: col = lane & 15, row = 4 * (lane >> 4) + e
 #pragma unroll
   for (int t = 0; t < MT; ++t)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) red[wid * 256 * MT + (16 * t + 4 * g + e) * 16 + li] = acc[t][e];
+    for (int c = 0; c < NT; ++c)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) red[wid * TM * TN + (16 * t + 4 * g + e) * TN + 16 * c + li] = acc[t][c][e];
   __syncthreads();
   if (!epi) return;
-  const int o256 = threadIdx.x;        // = (row em - m0) * 16 + (col eu - n0)
+  const int ot = threadIdx.x;          // = (row em - m0) * TN + (col eu - n0)
   float dhf = dpi;                     // gradient reaching h_k from later steps
 #pragma unroll
-  for (int w = 0; w < 16; ++w) dhf += red[w * 256 * MT + o256];
+  for (int w = 0; w < 16; ++w) dhf += red[w * TM * TN + ot];
   float* dg = D.dgates + (int64_t)em * 4 * H + eu;
   const int64_t o = (int64_t)em * H + eu;
   if (padded) {
@@ -591,10 +668,13 @@ extern "C" int ag_lstm_seq_bwd(const float* const* gates, const float* const* wh
       }
       if (ndir == 1) q.d[1] = q.d[0];
       // one wave of workgroups fills the 256 CUs: two row tiles per workgroup once a single one would not
+      // one wave of workgroups fills the 256 CUs; once 16x16 tiles would need more, widen the tile along the
+      // units (full 128-byte W_hh lines per workgroup)
       if ((int64_t)(H / 16) * ndir * ag_cdiv(B, 16) > 256)
-        hipLaunchKernelGGL(lstm_step_bwd_kernel<2>, dim3(H / 16, ndir, ag_cdiv(B, 32)), dim3(1024), 0, st, q);
+        hipLaunchKernelGGL((lstm_step_bwd_kernel<1, 2>), dim3(ag_cdiv(H, 32), ndir, ag_cdiv(B, 16)), dim3(1024), 0,
+                           st, q);
       else
-        hipLaunchKernelGGL(lstm_step_bwd_kernel<1>, dim3(H / 16, ndir, ag_cdiv(B, 16)), dim3(1024), 0, st, q);
+        hipLaunchKernelGGL((lstm_step_bwd_kernel<1, 1>), dim3(H / 16, ndir, ag_cdiv(B, 16)), dim3(1024), 0, st, q);
       AG_CHECK_LAUNCH("ag_lstm_seq_bwd(step)");
     }
     return AG_OK;

@@ -309,6 +309,17 @@ def main():
                 'share_of_gpu_time': share,
                 'algorithmic_per_launch': {'flops': r['flops'] / r['n'], 'bytes': r['bytes'] / r['n']},
             }
+            # SURVEY §8(d) grades the conv stacks (G trunk + D stack) as a whole as well: every conv kernel
+            # class of the discovery step together (forward, backward-data, backward-weight)
+            cv = [v for k, v in disc.items() if k.startswith('conv_')]
+            if cv:
+                cms = sum(v['ms'] for v in cv)
+                ctf = sum(v['flops'] for v in cv) / (cms * 1e-3) / 1e12
+                out['conv_stack'] = {'bound': 'mfma', 'achieved': ctf, 'peak': PEAK_F32_MFMA_TFLOPS,
+                                     'unit': 'TFLOP/s', 'frac': ctf / PEAK_F32_MFMA_TFLOPS,
+                                     'gpu_ms_per_step': cms, 'flops_per_step': sum(v['flops'] for v in cv),
+                                     'alg_gbs': sum(v['bytes'] for v in cv) / (cms * 1e-3) / 1e9,
+                                     'share_of_gpu_time': cms / sum(v['ms'] for v in disc.values())}
             tot = sum(x['ms'] for x in disc.values())
             out['kernel_table'] = [
                 {'kernel': k, 'share': round(v['ms'] / tot, 4), 'launches': v['n'],
