@@ -59,6 +59,18 @@ struct KContig {
       v[it] = q;
     }
   }
+  // whole k-tile inside K, 16-B aligned rows: unconditional loads (rows past the end are clamped - they only
+  // feed output rows the epilogue drops).  A predicated load costs a branch and serialises the requests.
+  __device__ __forceinline__ void load_fast(const float* __restrict__ G, int ld, int r0, int nrows, int k0, int tid) {
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      const int idx = tid + it * 256;
+      const int r = idx / GKQ, kq = idx % GKQ;
+      const int gr = min(r0 + r, nrows - 1);
+      v[it] = *reinterpret_cast<const f32x4*>(G + (int64_t)gr * ld + k0 + kq * 4);
+    }
+  }
+  static __device__ __forceinline__ bool fast_ok(int r0, int nrows) { (void)r0; (void)nrows; return true; }
   template <int PITCH>
   __device__ __forceinline__ void store(float* S, int tid) const {
 #pragma unroll
@@ -99,6 +111,17 @@ struct RContig {
       v[it] = q;
     }
   }
+  __device__ __forceinline__ void load_fast(const float* __restrict__ G, int ld, int r0, int nrows, int k0, int tid) {
+    // nrows % 4 == 0: a 16-byte piece is entirely inside or entirely outside; outside pieces are clamped
+    // onto the last valid piece (they only feed outputs the epilogue drops)
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      const int idx = tid + it * 256;
+      const int k = idx / R4, r = (idx % R4) * 4;
+      v[it] = *reinterpret_cast<const f32x4*>(G + (int64_t)(k0 + k) * ld + min(r0 + r, nrows - 4));
+    }
+  }
+  static __device__ __forceinline__ bool fast_ok(int r0, int nrows) { (void)r0; return (nrows & 3) == 0; }
   template <int PITCH>
   __device__ __forceinline__ void store(float* S, int tid) const {
 #pragma unroll
@@ -136,6 +159,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
 
   const int kbeg = blockIdx.z * p.kchunk;
   const int kend = (kbeg + p.kchunk < p.K) ? kbeg + p.kchunk : p.K;
+  const bool fast = p.vecA && p.vecB && la.fast_ok(m0, p.M) && lb.fast_ok(n0, p.N);
   la.load(p.A, p.lda, m0, p.M, kbeg, p.K, p.vecA, tid);
   lb.load(p.B, p.ldb, n0, p.N, kbeg, p.K, p.vecB, tid);
   la.template store<PA>(As[0], tid);
@@ -145,8 +169,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
   for (int k0 = kbeg; k0 < kend; k0 += GBK) {
     const bool more = k0 + GBK < kend;
     if (more) {
-      la.load(p.A, p.lda, m0, p.M, k0 + GBK, p.K, p.vecA, tid);
-      lb.load(p.B, p.ldb, n0, p.N, k0 + GBK, p.K, p.vecB, tid);
+      if (fast && k0 + 2 * GBK <= p.K) {
+        la.load_fast(p.A, p.lda, m0, p.M, k0 + GBK, tid);
+        lb.load_fast(p.B, p.ldb, n0, p.N, k0 + GBK, tid);
+      } else {
+        la.load(p.A, p.lda, m0, p.M, k0 + GBK, p.K, p.vecA, tid);
+        lb.load(p.B, p.ldb, n0, p.N, k0 + GBK, p.K, p.vecB, tid);
+      }
     }
     const float* Ac = As[buf];
     const float* Bc = Bs[buf];
@@ -171,6 +200,29 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
     buf ^= 1;
   }
 
+  if (p.ksplit == 1 && m0 + BM <= p.M && n0 + BN <= p.N) {
+    // interior tile: no bounds tests; the uniform epilogue options are tested once per element by scalar branches
+    const bool hb = p.bias != nullptr, hr = p.res != nullptr, hbeta = p.beta != 0.f;
+    float bj[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bj[j] = hb ? p.bias[n0 + wn0 + 32 * j + l31] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = m0 + wm0 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
+        float* dst = p.C + (int64_t)row * p.ldc + n0 + wn0 + l31;
+        const float* rs = p.res + (int64_t)row * p.ldres + n0 + wn0 + l31;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          float v = p.alpha * acc[i][j][e] + bj[j];
+          if (hbeta) v += p.beta * dst[32 * j];
+          if (hr) v += rs[32 * j];
+          dst[32 * j] = ag_apply_act(v, p.act, p.slope);
+        }
+      }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
