@@ -23,7 +23,8 @@ class WnDesc(C.Structure):
 
 
 class WnBwdDesc(C.Structure):
-    _fields_ = [('v', vp), ('g', vp), ('dw', vp), ('dv', vp), ('dg', vp), ('rows', i32), ('cols', i32)]
+    _fields_ = [('v', vp), ('g', vp), ('dw', vp), ('dv', vp), ('dg', vp), ('rows', i32), ('cols', i32),
+                ('accumulate', i32), ('pad_', i32)]
 
 
 class ConvArgs(C.Structure):

@@ -63,9 +63,14 @@ __global__ __launch_bounds__(256) void weight_norm_bwd_kernel(const ag_wn_bwd_de
   dot = ag_wave_sum(dot);
   const float inv = 1.f / sqrtf(ss);
   const float g = d.g[r];
-  if (lane == 0) d.dg[r] = dot * inv;
   const float a = g * inv, bcoef = dot * inv * inv;
   float* dv = d.dv + (int64_t)r * d.cols;
+  if (d.accumulate) {
+    if (lane == 0) d.dg[r] += dot * inv;
+    for (int i = lane; i < d.cols; i += 64) dv[i] += a * (dw[i] - v[i] * bcoef);
+    return;
+  }
+  if (lane == 0) d.dg[r] = dot * inv;
   for (int i = lane; i < d.cols; i += 64) dv[i] = a * (dw[i] - v[i] * bcoef);
 }
 

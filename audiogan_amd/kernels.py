@@ -139,7 +139,7 @@ def weight_norm_fwd(entries):
 
 
 def weight_norm_bwd(entries):
-    """entries: list of dict(v, g, dw, dv, dg); dv/dg are written."""
+    """entries: list of dict(v, g, dw, dv, dg[, accumulate]); dv/dg are written (or added to)."""
     descs, max_rows = [], 1
     for e in entries:
         for k in ('v', 'g', 'dw', 'dv', 'dg'):
@@ -149,7 +149,8 @@ def weight_norm_bwd(entries):
         cols = e['v'].numel() // rows
         assert e['dw'].numel() == e['v'].numel() == e['dv'].numel() and e['dg'].numel() == rows
         descs.append(_lib.WnBwdDesc(e['v'].data_ptr(), e['g'].data_ptr(), e['dw'].data_ptr(),
-                                    e['dv'].data_ptr(), e['dg'].data_ptr(), rows, cols))
+                                    e['dv'].data_ptr(), e['dg'].data_ptr(), rows, cols,
+                                    1 if e.get('accumulate') else 0, 0))
         max_rows = max(max_rows, rows)
     tab = _table('wnb', descs, entries[0]['v'].device)
     check(lib.ag_weight_norm_bwd(_p(tab), len(descs), max_rows, _stream()), 'ag_weight_norm_bwd')

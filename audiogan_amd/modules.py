@@ -196,7 +196,7 @@ class Generator(nn.Module):
         if t_eff < nframes:
             x, s = x[:, :t_eff * fs], s[:, :t_eff]
         stop_list = ([stops[:, t:t + 1] for t in range(t_eff)] if stops is not None else
-                     [torch.zeros(batch_size, 1, dtype=torch.long, device=dev) for _ in range(t_eff)])
+                     list(torch.zeros(t_eff, batch_size, 1, dtype=torch.long, device=dev).unbind(0)))
         wave = ops.GTrunkFn.apply(x, self._trunk, *self._trunk.group.params())
         return wave, s, stop_list, out_len
 

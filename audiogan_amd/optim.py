@@ -44,10 +44,29 @@ class _Fused(object):
         if getattr(self, 'bucket', None) is not None:
             self.bucket.zero()
             return
-        for p in self.params:
-            if p.grad is not None:
-                p.grad.detach_()
-                p.grad.zero_()
+        # gradients that exist are moved ONCE into one flat buffer (``.grad`` become views), so that
+        # clearing them is one memset instead of one launch per parameter tensor; parameters that have
+        # never received a gradient keep ``.grad is None`` (the step skips them, as torch.optim does)
+        views = getattr(self, '_gviews', None)
+        if views is None or any(p.grad is not v for p, v in views):
+            have = [p for p in self.params if p.grad is not None]
+            if not have:
+                return
+            flat = torch.zeros(sum(p.numel() for p in have), device=have[0].device, dtype=torch.float32)
+            views, o = [], 0
+            for p in have:
+                p.grad = flat[o:o + p.numel()].view(p.shape)
+                views.append((p, p.grad))
+                o += p.numel()
+            self._gflat, self._gviews = flat, views
+            return
+        self._gflat.zero_()
+        if len(views) != len(self.params):
+            for p in self.params:
+                if p.grad is not None and not any(p is q for q, _ in views):
+                    self._gviews = None      # a new gradient appeared: re-flatten next time
+                    p.grad.detach_()
+                    p.grad.zero_()
 
     def state_dict(self):
         self._ensure()

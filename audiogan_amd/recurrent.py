@@ -14,7 +14,7 @@ import torch
 
 from . import kernels as K
 from .kernels import ACT_NONE, ACT_TANH
-from .common import WNGroup, _zeros_like_list
+from .common import WNGroup, _zeros_like_list, grad_target
 
 
 def _small(A, B, Cm, tb=False, beta=0.0, bias=None, act=ACT_NONE, res=None):
@@ -73,6 +73,7 @@ class LSTMSeqFn(torch.autograd.Function):
                     K.lstm_cell_fwd(g[t], c[k], c[k + 1], h_out=hn, y_out=y[t, :, d * H:(d + 1) * H],
                                     h_prev=hp, valid=lengths, t=t)
         ctx.ndir, ctx.has_len = ndir, lengths is not None
+        ctx.params = w
         ctx.save_for_backward(x2, y, lengths if lengths is not None else x2.new_empty(0),
                               *(gates_all + c_all + [t_.data for t_ in w]))
         ctx.shape = (T, B, F, H)
@@ -115,21 +116,32 @@ class LSTMSeqFn(torch.autograd.Function):
                 K.gemm(dg2, w_ih, dx2, beta=0.0 if d == 0 else 1.0)
                 outs += [None, None, None, None]
                 continue
-            dw_ih = torch.empty_like(w_ih)
-            K.gemm(dg2, x2, dw_ih, ta=True)
+            tg = [grad_target(p_) for p_ in ctx.params[4 * d:4 * d + 4]]
+            direct = all(t_ is not None for t_ in tg)
             # h_prev of processing step k is the layer output of step k-1 (zero at padded steps,
             # where dgates is zero as well)
-            dw_hh = torch.zeros_like(w_hh)
+            if direct:      # accumulate straight into .grad
+                dw_ih, dw_hh = tg[0], tg[1]
+                K.gemm(dg2, x2, dw_ih, ta=True, beta=1.0)
+            else:
+                dw_ih = torch.empty_like(w_ih)
+                K.gemm(dg2, x2, dw_ih, ta=True)
+                dw_hh = torch.zeros_like(w_hh)
             if T > 1:
                 if d == 0:
                     K.gemm(dgs[d][1:].view((T - 1) * B, 4 * H), y[:-1].view((T - 1) * B, ndir * H)[:, :H],
-                           dw_hh, ta=True)
+                           dw_hh, ta=True, beta=1.0)
                 else:
                     K.gemm(dgs[d][:-1].view((T - 1) * B, 4 * H),
-                           y[1:].view((T - 1) * B, ndir * H)[:, H:2 * H], dw_hh, ta=True)
+                           y[1:].view((T - 1) * B, ndir * H)[:, H:2 * H], dw_hh, ta=True, beta=1.0)
+            K.gemm(dg2, w_ih, dx2, beta=0.0 if d == 0 else 1.0)
+            if direct:
+                K.col_sum(dg2, tg[2])
+                K.col_sum(dg2, tg[3])
+                outs += [None, None, None, None]
+                continue
             db = torch.zeros(4 * H, device=dev)
             K.col_sum(dg2, db)
-            K.gemm(dg2, w_ih, dx2, beta=0.0 if d == 0 else 1.0)
             outs += [dw_ih, dw_hh, db, db.clone()]
         dx = dx2.view(T, B, F) if ctx.needs_input_grad[0] else None
         return (dx, None, None) + tuple(outs)

@@ -72,6 +72,8 @@ typedef struct ag_wn_bwd_desc {
   float* dg;       /* [rows] */
   int32_t rows;
   int32_t cols;
+  int32_t accumulate; /* 1: dv += ..., dg += ... (gradient accumulation straight into .grad) */
+  int32_t pad_;
 } ag_wn_bwd_desc;
 
 int ag_weight_norm_bwd(const ag_wn_bwd_desc* descs_dev, int n, int max_rows, void* stream);

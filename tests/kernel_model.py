@@ -56,8 +56,13 @@ def weight_norm_bwd(entries):
         v2, dw2 = v.reshape(rows, -1), dw.reshape(rows, -1)
         inv = 1.0 / v2.norm(dim=1, keepdim=True)
         dot = (v2 * dw2).sum(1, keepdim=True)
-        e['dg'].copy_((dot * inv).view(-1))
-        e['dv'].copy_((g.view(rows, 1) * inv * (dw2 - v2 * dot * inv * inv)).view(v.shape))
+        dg_, dv_ = (dot * inv).view(-1), (g.view(rows, 1) * inv * (dw2 - v2 * dot * inv * inv)).view(v.shape)
+        if e.get('accumulate'):
+            e['dg'].add_(dg_)
+            e['dv'].add_(dv_)
+        else:
+            e['dg'].copy_(dg_)
+            e['dv'].copy_(dv_)
 
 
 def prep_conv_weight(w, wpa, wpb, stride):
