@@ -262,33 +262,54 @@ __global__ __launch_bounds__(256) void leaky_bwd_kernel(const float* __restrict_
                                                         float* __restrict__ dp, int64_t dp_bs,
                                                         int64_t dp_cs, float* __restrict__ ad,
                                                         int64_t ad_bs, int64_t ad_cs,
-                                                        const int64_t* __restrict__ lens, int C, int L,
-                                                        float slope) {
-  const int b = blockIdx.z, c = blockIdx.y;
-  const int64_t lenb = lens ? lens[b] : (int64_t)1 << 60;
-  const float* dyr = dy + (int64_t)b * dy_bs + (int64_t)c * dy_cs;
-  const float* yr = y + (int64_t)b * y_bs + (int64_t)c * y_cs;
-  float* dpr = dp + (int64_t)b * dp_bs + (int64_t)c * dp_cs;
-  float* adr = ad ? ad + (int64_t)b * ad_bs + (int64_t)c * ad_cs : nullptr;
-  for (int t = blockIdx.x * 256 + threadIdx.x; t < L; t += gridDim.x * 256) {
-    float g = dyr[t];
-    g = (yr[t] > 0.f) ? g : g * slope;
-    if (t >= lenb) g = 0.f;
-    dpr[t] = g;
-    if (adr) adr[t] += g;
+                                                        const int64_t* __restrict__ lens,
+                                                        float* __restrict__ bias_grad, int B, int C,
+                                                        int L, int bper, float slope) {
+  const int c = blockIdx.y;
+  float bsum = 0.f;
+  // bper clips per workgroup: with a bias gradient every workgroup ends in ONE atomic, and all channels of a
+  // small layer share a cache line - 8192 same-line atomics cost more than the whole pass
+  for (int b = blockIdx.z * bper; b < min(B, (int)(blockIdx.z + 1) * bper); ++b) {
+    const int64_t lenb = lens ? lens[b] : (int64_t)1 << 60;
+    const float* dyr = dy + (int64_t)b * dy_bs + (int64_t)c * dy_cs;
+    const float* yr = y + (int64_t)b * y_bs + (int64_t)c * y_cs;
+    float* dpr = dp + (int64_t)b * dp_bs + (int64_t)c * dp_cs;
+    float* adr = ad ? ad + (int64_t)b * ad_bs + (int64_t)c * ad_cs : nullptr;
+    for (int t = blockIdx.x * 256 + threadIdx.x; t < L; t += gridDim.x * 256) {
+      float g = dyr[t];
+      g = (yr[t] > 0.f) ? g : g * slope;
+      if (t >= lenb) g = 0.f;
+      dpr[t] = g;
+      if (adr) adr[t] += g;
+      bsum += g;
+    }
+  }
+  if (bias_grad) {     // uniform branch
+    __shared__ float red[4];
+    bsum = ag_wave_sum(bsum);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = bsum;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(bias_grad + c, red[0] + red[1] + red[2] + red[3]);
   }
 }
 
 extern "C" int ag_leaky_bwd(const float* dy, int64_t dy_bs, int64_t dy_cs, const float* y,
                             int64_t y_bs, int64_t y_cs, float* dpre, int64_t dp_bs, int64_t dp_cs,
                             float* add_into, int64_t ad_bs, int64_t ad_cs, const int64_t* lens_i64,
-                            int B, int C, int L, float slope, void* stream) {
+                            float* bias_grad, int B, int C, int L, float slope, void* stream) {
   AG_REQUIRE(dy && y && dpre && B > 0 && C > 0 && L > 0, "ag_leaky_bwd: bad args");
   AG_REQUIRE(B <= 65535 && C <= 65535, "ag_leaky_bwd: B or C > 65535");
   int gx = ag_cdiv(L, 256 * 4);
   if (gx < 1) gx = 1;
-  hipLaunchKernelGGL(leaky_bwd_kernel, dim3(gx, C, B), dim3(256), 0, (hipStream_t)stream, dy, dy_bs,
-                     dy_cs, y, y_bs, y_cs, dpre, dp_bs, dp_cs, add_into, ad_bs, ad_cs, lens_i64, C, L, slope);
+  int bper = 1;
+  if (bias_grad) {
+    bper = (int)(((int64_t)gx * C * B) / 2048);
+    if (bper < 8) bper = 8;
+    if (bper > B) bper = B;
+  }
+  hipLaunchKernelGGL(leaky_bwd_kernel, dim3(gx, C, ag_cdiv(B, bper)), dim3(256), 0, (hipStream_t)stream, dy, dy_bs,
+                     dy_cs, y, y_bs, y_cs, dpre, dp_bs, dp_cs, add_into, ad_bs, ad_cs, lens_i64, bias_grad, B, C, L,
+                     bper, slope);
   AG_CHECK_LAUNCH("ag_leaky_bwd");
   return AG_OK;
 }
@@ -363,24 +384,42 @@ __global__ __launch_bounds__(256) void conv_o1_bwdx_kernel(const float* __restri
     if (t0 + j < L) d[t0 + j] = accumulate ? d[t0 + j] + acc[j] : acc[j];
 }
 
+// one workgroup = one channel x 1024 time steps x a slice of the batch; a thread owns 4 consecutive steps
+// (its dy values and the 4+K-1 wide x window stay in registers across the K taps)
 __global__ __launch_bounds__(256) void conv_o1_wgrad_kernel(const float* __restrict__ dy, int64_t dy_bs,
                                                             const float* __restrict__ x, int64_t x_bs, int64_t x_cs,
                                                             float* __restrict__ dw, int B, int C, int L, int K, int p,
-                                                            int nsplit) {
+                                                            int bper) {
   __shared__ float red[17];
-  const int c = blockIdx.x;
+  const int c = blockIdx.y;
+  const int t0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+  const int b0 = blockIdx.z * bper;
+  const int b1 = min(B, b0 + bper);
   float acc[O1_MAXK];
 #pragma unroll
   for (int k = 0; k < O1_MAXK; ++k) acc[k] = 0.f;
-  const int64_t total = (int64_t)B * L;
-  for (int64_t i = (int64_t)blockIdx.y * 256 + threadIdx.x; i < total; i += (int64_t)nsplit * 256) {
-    const int b = (int)(i / L), t = (int)(i - (int64_t)b * L);
-    const float g = dy[(int64_t)b * dy_bs + t];
-    const float* xc = x + (int64_t)b * x_bs + (int64_t)c * x_cs;
+  if (t0 < L) {
+    for (int b = b0; b < b1; ++b) {
+      const float* dyb = dy + (int64_t)b * dy_bs;
+      const float* xc = x + (int64_t)b * x_bs + (int64_t)c * x_cs;
+      float g[4], win[4 + O1_MAXK - 1];
 #pragma unroll
-    for (int k = 0; k < O1_MAXK; ++k) {
-      const int q = t + k - p;
-      if (k < K && q >= 0 && q < L) acc[k] += g * xc[q];
+      for (int j = 0; j < 4; ++j) {
+        const float v = dyb[min(t0 + j, L - 1)];      // unconditional load, then select
+        g[j] = (t0 + j < L) ? v : 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < 4 + O1_MAXK - 1; ++i) {
+        const int q = t0 + i - p;
+        const float v = (i < 4 + K - 1) ? xc[min(max(q, 0), L - 1)] : 0.f;
+        win[i] = (q >= 0 && q < L) ? v : 0.f;
+      }
+#pragma unroll
+      for (int k = 0; k < O1_MAXK; ++k) {
+        if (k >= K) break;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[k] += g[j] * win[j + k];
+      }
     }
   }
 #pragma unroll
@@ -417,12 +456,16 @@ extern "C" int ag_conv1d_o1_bwd_data(const float* dy, int64_t dy_bs, const float
 extern "C" int ag_conv1d_o1_wgrad(const float* dy, int64_t dy_bs, const float* x, int64_t x_bs, int64_t x_cs,
                                   float* dw, int B, int C, int L, int K, int pad, void* stream) {
   AG_REQUIRE(dy && x && dw && B > 0 && C > 0 && L > 0 && K > 0 && K <= O1_MAXK, "ag_conv1d_o1_wgrad: bad args");
-  int nsplit = ag_cdiv(2048, C);
-  const int64_t cap = ag_cdiv64((int64_t)B * L, 256 * 8);
-  if (nsplit > cap) nsplit = (int)cap;
-  if (nsplit < 1) nsplit = 1;
-  hipLaunchKernelGGL(conv_o1_wgrad_kernel, dim3(C, nsplit), dim3(256), 0, (hipStream_t)stream, dy, dy_bs, x, x_bs,
-                     x_cs, dw, B, C, L, K, pad, nsplit);
+  AG_REQUIRE(C <= 65535, "ag_conv1d_o1_wgrad: C > 65535");
+  // enough workgroups to fill the chip (~8 per CU), the rest of the batch is looped inside
+  const int gx = ag_cdiv(L, 1024);
+  int gz = ag_cdiv(2048, gx * C);
+  if (gz > B) gz = B;
+  if (gz < 1) gz = 1;
+  const int bper = ag_cdiv(B, gz);
+  gz = ag_cdiv(B, bper);
+  hipLaunchKernelGGL(conv_o1_wgrad_kernel, dim3(gx, C, gz), dim3(256), 0, (hipStream_t)stream, dy, dy_bs, x, x_bs,
+                     x_cs, dw, B, C, L, K, pad, bper);
   AG_CHECK_LAUNCH("ag_conv1d_o1_wgrad");
   return AG_OK;
 }

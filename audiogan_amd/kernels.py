@@ -221,17 +221,21 @@ def channel_sum(dy, db):
     check(lib.ag_channel_sum(_p(dy), bs, cs, _p(db), B, Cc, L, _stream()), 'ag_channel_sum')
 
 
-def leaky_bwd(dy, y, dpre, lens=None, slope=LEAKY_SLOPE, add_into=None):
+def leaky_bwd(dy, y, dpre, lens=None, slope=LEAKY_SLOPE, add_into=None, bias_grad=None):
     """dpre = dy * (y > 0 ? 1 : slope) * (t < lens[b]); all [B,C,L] views; dpre may alias dy.
-    add_into (optional [B,C,L] view, must not overlap dpre): add_into += dpre."""
+    add_into (optional [B,C,L] view, must not overlap dpre): add_into += dpre.
+    bias_grad (optional [C], pre-zeroed): bias_grad[c] += sum_{b,t} dpre[b,c,t]."""
     a = _bcl(dy, 'dy'); b = _bcl(y, 'y'); c = _bcl(dpre, 'dpre')
     d = _bcl(add_into, 'add_into') if add_into is not None else (0, 0)
     _chk(lens, 'lens', torch.int64)
     assert tuple(dy.shape) == tuple(y.shape) == tuple(dpre.shape)
     assert add_into is None or tuple(add_into.shape) == tuple(dy.shape)
     B, Cc, L = dy.shape
+    if bias_grad is not None:
+        _chk(bias_grad, 'bias_grad')
+        assert bias_grad.is_contiguous() and bias_grad.numel() == Cc
     check(lib.ag_leaky_bwd(_p(dy), a[0], a[1], _p(y), b[0], b[1], _p(dpre), c[0], c[1], _p(add_into),
-                           d[0], d[1], _p(lens), B, Cc, L, slope, _stream()), 'ag_leaky_bwd')
+                           d[0], d[1], _p(lens), _p(bias_grad), B, Cc, L, slope, _stream()), 'ag_leaky_bwd')
 
 
 # ------------------------------------------------------------------------------------

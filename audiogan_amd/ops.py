@@ -133,15 +133,16 @@ class GTrunkFn(torch.autograd.Function):
             out_v = slab[:, cin:cin + ds.cout]
             dout = dslab[:, cin:cin + ds.cout]
             add = dslab[:, cin - ds.cout:cin] if cin >= ds.cout else None
-            K.leaky_bwd(dout, out_v, dout, add_into=add)          # dout now holds d(pre-activation)
+            # dout now holds d(pre-activation); the bias gradient is summed in the same pass
+            K.leaky_bwd(dout, out_v, dout, add_into=add, bias_grad=dws[4 * i + 3] if wg else None)
             hid = hids[i]
             if wg:
-                conv_wgrad(ds, hid, dout, dws[4 * i + 2], dws[4 * i + 3])
+                conv_wgrad(ds, hid, dout, dws[4 * i + 2], None)
             dhid = torch.empty_like(hid)
             conv_bwd_data(ds, qw, dout, dhid)
-            K.leaky_bwd(dhid, hid, dhid)
+            K.leaky_bwd(dhid, hid, dhid, bias_grad=dws[4 * i + 1] if wg else None)
             if wg:
-                conv_wgrad(cs, slab[:, :cin], dhid, dws[4 * i], dws[4 * i + 1])
+                conv_wgrad(cs, slab[:, :cin], dhid, dws[4 * i], None)
             conv_bwd_data(cs, pw, dhid, dslab[:, :cin], accumulate=True)
         grads = trunk.group.backward(dws) if wg else [None] * (2 * len(trunk.group.items))
         dx0 = dslab[:, 0, :].contiguous() if ctx.needs_input_grad[0] else None
@@ -195,14 +196,15 @@ class DConvStackFn(torch.autograd.Function):
                 if g is None:
                     continue
                 d = torch.empty_like(acts[i])
-                K.leaky_bwd(g.contiguous(), acts[i], d, lens=ctx.lens_list[i])     # out of place: no clone
+                K.leaky_bwd(g.contiguous(), acts[i], d, lens=ctx.lens_list[i],     # out of place: no clone
+                            bias_grad=dws[2 * i + 1] if wg else None)
             else:
                 if g is not None:
                     K.axpby(g.contiguous(), d, 1.0, 1.0)
-                K.leaky_bwd(d, acts[i], d, lens=ctx.lens_list[i])
+                K.leaky_bwd(d, acts[i], d, lens=ctx.lens_list[i], bias_grad=dws[2 * i + 1] if wg else None)
             xin = acts[i - 1] if i > 0 else x.contiguous().view(B, 1, L)
             if wg:
-                conv_wgrad(sp, xin, d, dws[2 * i], dws[2 * i + 1])
+                conv_wgrad(sp, xin, d, dws[2 * i], None)
             if i > 0 or ctx.needs_input_grad[0]:
                 dx = torch.empty_like(xin)
                 conv_bwd_data(sp, prep[2 * i], d, dx)

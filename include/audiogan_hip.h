@@ -148,11 +148,13 @@ int ag_channel_sum(const float* dy, int64_t bs, int64_t cs, float* db, int B, in
 /* dpre = dy * (y > 0 ? 1 : slope) * (t < lens[b])   elementwise on [B,C,L] views.
  * LeakyReLU keeps the sign, so the saved OUTPUT y is enough (no pre-activation).
  * add_into (optional, same shape): add_into += dpre  -- the gradient of the
- * "act += x[:, -out:, :]" skip connection of dense_res_bottleneck (audiogan.py:281-282). */
+ * "act += x[:, -out:, :]" skip connection of dense_res_bottleneck (audiogan.py:281-282).
+ * bias_grad (optional, [C]): bias_grad[c] += sum_{b,t} dpre[b,c,t] -- the bias gradient of the conv that
+ * produced y, taken in the same pass (atomics; pre-zeroed by the caller). */
 int ag_leaky_bwd(const float* dy, int64_t dy_bs, int64_t dy_cs, const float* y, int64_t y_bs,
                  int64_t y_cs, float* dpre, int64_t dp_bs, int64_t dp_cs, float* add_into,
-                 int64_t ad_bs, int64_t ad_cs, const int64_t* lens_i64, int B, int C, int L,
-                 float slope, void* stream);
+                 int64_t ad_bs, int64_t ad_cs, const int64_t* lens_i64, float* bias_grad, int B, int C,
+                 int L, float slope, void* stream);
 
 /* ---------------------------------------------------------------------------
  * Dense fp32 GEMM on MFMA (NN.Linear / LSTM gate products: audiogan.py:260,380,

@@ -125,7 +125,7 @@ def channel_sum(dy, db):
     db.add_(dy.sum((0, 2)))
 
 
-def leaky_bwd(dy, y, dpre, lens=None, slope=LEAKY_SLOPE, add_into=None):
+def leaky_bwd(dy, y, dpre, lens=None, slope=LEAKY_SLOPE, add_into=None, bias_grad=None):
     B, C, L = dy.shape
     g = torch.where(y > 0, dy, dy * slope)
     if lens is not None:
@@ -133,6 +133,8 @@ def leaky_bwd(dy, y, dpre, lens=None, slope=LEAKY_SLOPE, add_into=None):
     dpre.copy_(g)
     if add_into is not None:
         add_into.add_(g)
+    if bias_grad is not None:
+        bias_grad.add_(g.sum((0, 2)))
 
 
 def gemm(A, B, Cm, ta=False, tb=False, alpha=1.0, beta=0.0, bias=None, res=None, act=ACT_NONE,

@@ -133,9 +133,11 @@ def test_conv_slab_views_and_residual_grad(K):
     close(s_d[:, :8], slab[:, :8], rtol=0, atol=0)         # neighbours untouched
     dsl = torch.randn(B, 12, L, generator=gen)
     d_d = dev(dsl.clone())
-    K.leaky_bwd(d_d[:, 8:12], s_d[:, 8:12], d_d[:, 8:12], add_into=d_d[:, 4:8])
+    db = torch.full((4,), 0.5).cuda()                      # accumulates: starts from a non-zero value
+    K.leaky_bwd(d_d[:, 8:12], s_d[:, 8:12], d_d[:, 8:12], add_into=d_d[:, 4:8], bias_grad=db)
     g = torch.where(ref > 0, dsl[:, 8:12], dsl[:, 8:12] * 0.01)
     close(d_d[:, 8:12], g)
+    close(db, 0.5 + g.sum((0, 2)), rtol=1e-4, atol=1e-4)   # bias gradient in the same pass
     close(d_d[:, 4:8], dsl[:, 4:8] + g)
     close(d_d[:, :4], dsl[:, :4], rtol=0, atol=0)
 
