@@ -57,6 +57,8 @@ SIGNATURES = {
                                         C.c_int, vp]),
     'ag_conv1d_o1_wgrad': (C.c_int, [vp, i64, vp, i64, i64, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     'ag_channel_sum': (C.c_int, [vp, i64, i64, vp, C.c_int, C.c_int, C.c_int, vp]),
+    'ag_lstm_front_bwd_step': (C.c_int, [vp, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int, vp, vp, C.c_int, vp, vp, vp,
+                                         vp, vp, vp, C.c_int, C.c_int, vp]),
     'ag_leaky_bwd': (C.c_int, [vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, vp, C.c_int,
                                C.c_int, C.c_int, f32, vp]),
     'ag_gemm': (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp, C.c_int, C.c_int,

@@ -416,17 +416,19 @@ __global__ __launch_bounds__(256) void conv_o1_wgrad_kernel(const float* __restr
       }
 #pragma unroll
       for (int k = 0; k < O1_MAXK; ++k) {
-        if (k >= K) break;
+        if (k < K) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[k] += g[j] * win[j + k];
+          for (int j = 0; j < 4; ++j) acc[k] += g[j] * win[j + k];
+        }
       }
     }
   }
 #pragma unroll
   for (int k = 0; k < O1_MAXK; ++k) {
-    if (k >= K) break;
-    const float s = ag_block_sum(acc[k], red);
-    if (threadIdx.x == 0) atomicAdd(dw + c * K + k, s);
+    if (k < K) {      // uniform
+      const float s = ag_block_sum(acc[k], red);
+      if (threadIdx.x == 0) atomicAdd(dw + c * K + k, s);
+    }
   }
 }
 

@@ -497,8 +497,12 @@ __global__ __launch_bounds__(256) void lstm_cell_bwd2_kernel(const CellBwd2P p) 
 // epilogue: ONE launch per time step instead of a pointwise launch plus an atomic product launch.
 // ------------------------------------------------------------------------------------------
 struct BwdStepDir {
-  const float* dg_next;  // [B,4H] dgates of the previously processed step (k+1), or NULL when k == T-1
-  const float* whh;      // [4H,H]
+  const float* dg_next;  // product operand A [B,Kp] (row pitch lda): dgates of the previously processed step
+                         // (k+1), or NULL when k == T-1
+  const float* whh;      // product operand [Kp,H]
+  const float* ax;       // optional: A is used as A * (1 - ax^2) (tanh backward applied on load), row pitch ldax
+  float* aout;           // optional: that transformed A is also stored here (row pitch ldaout)
+  int lda, Kp, ldax, ldaout, lddhp;   // lddhp: row pitch of dh_pass_in
   const float* ga;       // activated gates of step k [B,4H]
   const float* c_prev;   // [B,H]
   const float* c_new;    // [B,H]
@@ -522,7 +526,8 @@ struct BwdStepP {
 // The step is latency bound (W_hh comes from the fabric every step: L2 is not coherent across
 // launches), so every load of a wave's K range is requested before the first MFMA.
 #define BWD_UB 8      // 16-k units requested per round (8 float4 + 32 dwords in flight per lane)
-template <int MT, int NT>      // 16-clip row tiles x 16-unit column tiles per workgroup (register reuse)
+// UB: 16-k units requested per round; AX: tanh backward applied to A on load (generator front)
+template <int MT, int NT, int UB, bool AX>      // 16-clip row tiles x 16-unit column tiles per workgroup
 __global__ __launch_bounds__(1024) void lstm_step_bwd_kernel(const BwdStepP p) {
   constexpr int TM = 16 * MT, TN = 16 * NT;
   __shared__ float red[16 * TM * TN];
@@ -548,9 +553,9 @@ __global__ __launch_bounds__(1024) void lstm_step_bwd_kernel(const BwdStepP p) {
     const int64_t o = (int64_t)em * H + eu;
     cp = D.c_prev[o];
     cn = D.c_new[o];
-    dyv = D.dy[(int64_t)em * D.ldy + eu];
+    if (D.dy) dyv = D.dy[(int64_t)em * D.ldy + eu];
     if (D.dc_next) dcn = D.dc_next[o];
-    if (D.dh_pass_in) dpi = D.dh_pass_in[o];
+    if (D.dh_pass_in) dpi = D.dh_pass_in[(int64_t)em * D.lddhp + eu];
     padded = p.valid && D.t >= p.valid[em];
   }
   f32x4 acc[MT][NT];
@@ -559,20 +564,20 @@ __global__ __launch_bounds__(1024) void lstm_step_bwd_kernel(const BwdStepP p) {
 #pragma unroll
     for (int c = 0; c < NT; ++c) acc[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
   if (D.dg_next) {
-    const int KU = (4 * H) >> 4;                        // 16-k units
+    const int KU = D.Kp >> 4;                           // 16-k units
     const int u0 = KU * wid / 16, u1 = KU * (wid + 1) / 16;
     // rows / units past the end are clamped: they only feed their own (unwritten) outputs
     const float* ar[MT];
     const float* br[NT];
 #pragma unroll
-    for (int t = 0; t < MT; ++t) ar[t] = D.dg_next + (int64_t)min(m0 + 16 * t + li, B - 1) * 4 * H + 4 * g;
+    for (int t = 0; t < MT; ++t) ar[t] = D.dg_next + (int64_t)min(m0 + 16 * t + li, B - 1) * D.lda + 4 * g;
 #pragma unroll
     for (int c = 0; c < NT; ++c) br[c] = D.whh + (int64_t)(4 * g) * H + min(n0 + 16 * c + li, H - 1);
-    for (int ub = u0; ub < u1; ub += BWD_UB) {
-      f32x4 a[MT][BWD_UB];
-      float b[NT][BWD_UB][4];
+    for (int ub = u0; ub < u1; ub += UB) {
+      f32x4 a[MT][UB];
+      float b[NT][UB][4];
 #pragma unroll
-      for (int i = 0; i < BWD_UB; ++i) {
+      for (int i = 0; i < UB; ++i) {
         const int u = min(ub + i, u1 - 1);
 #pragma unroll
         for (int t = 0; t < MT; ++t) a[t][i] = *reinterpret_cast<const f32x4*>(ar[t] + 16 * u);
@@ -581,8 +586,22 @@ __global__ __launch_bounds__(1024) void lstm_step_bwd_kernel(const BwdStepP p) {
 #pragma unroll
           for (int c = 0; c < NT; ++c) b[c][i][e] = br[c][(int64_t)(16 * u + e) * H];
       }
+      if (AX) {       // generator front, A = dL/dx_t * tanh'(pre) = dxa * (1 - x_t^2)
 #pragma unroll
-      for (int i = 0; i < BWD_UB; ++i) {
+        for (int i = 0; i < UB; ++i) {
+          const int u = min(ub + i, u1 - 1);
+#pragma unroll
+          for (int t = 0; t < MT; ++t) {
+            const int row = min(m0 + 16 * t + li, B - 1);
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(D.ax + (int64_t)row * D.ldax + 4 * g + 16 * u);
+            a[t][i] = a[t][i] * (1.f - xv * xv);
+            if (D.aout && blockIdx.x == 0 && ub + i < u1 && m0 + 16 * t + li < B)
+              *reinterpret_cast<f32x4*>(D.aout + (int64_t)row * D.ldaout + 4 * g + 16 * u) = a[t][i];
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < UB; ++i) {
         if (ub + i < u1) {
 #pragma unroll
           for (int e = 0; e < 4; ++e)
@@ -613,7 +632,7 @@ __global__ __launch_bounds__(1024) void lstm_step_bwd_kernel(const BwdStepP p) {
   if (padded) {
     dg[0] = 0.f; dg[H] = 0.f; dg[2 * H] = 0.f; dg[3 * H] = 0.f;
     D.dc_prev[o] = dcn;
-    D.dh_pass_out[o] = dhf;
+    if (D.dh_pass_out) D.dh_pass_out[o] = dhf;
     return;
   }
   const float dhv = dhf + dyv;
@@ -624,7 +643,55 @@ __global__ __launch_bounds__(1024) void lstm_step_bwd_kernel(const BwdStepP p) {
   dg[2 * H] = dc * ig * (1.f - gg * gg);
   dg[3 * H] = dhv * tc * og * (1.f - og);
   D.dc_prev[o] = dc * fg;
-  D.dh_pass_out[o] = 0.f;
+  if (D.dh_pass_out) D.dh_pass_out[o] = 0.f;
+}
+
+static void launch_bwd_step(const BwdStepP& q, int ndir, hipStream_t st) {
+  const int B = q.B, H = q.H;
+  // one wave of workgroups fills the 256 CUs; once 16x16 tiles would need more, widen the tile along the
+  // units (full 128-byte W_hh lines per workgroup)
+  if ((int64_t)(H / 16) * ndir * ag_cdiv(B, 16) > 256)
+    hipLaunchKernelGGL((lstm_step_bwd_kernel<1, 2, 8, false>), dim3(ag_cdiv(H, 32), ndir, ag_cdiv(B, 16)), dim3(1024),
+                       0, st, q);
+  else
+    hipLaunchKernelGGL((lstm_step_bwd_kernel<1, 1, 8, false>), dim3(H / 16, ndir, ag_cdiv(B, 16)), dim3(1024), 0, st,
+                       q);
+}
+
+// One fused backward step of a single LSTMCell whose h feeds a tanh projection (Generator front,
+// audiogan.py:428-460), for frame t:
+//   gx   = dxa * (1 - x_t^2)                      (d(pre-tanh) of the projection; stored to gx_out)
+//   dh   = dh_acc + gx * W_proj                   (W_proj [Kp = frame, H])
+//   (dgates, dc_prev) = cell_bwd(dh, dc_next, gates, c_prev, c_new)
+extern "C" int ag_lstm_front_bwd_step(const float* dxa, int lddxa, const float* x, int ldx, float* gx_out, int ldgx,
+                                      int Kp, const float* w_proj, const float* dh_acc, int lddh, const float* gates,
+                                      const float* c_prev, const float* c_new, const float* dc_next, float* dgates,
+                                      float* dc_prev, int B, int H, void* stream) {
+  AG_REQUIRE(dxa && x && w_proj && dh_acc && gates && c_prev && c_new && dgates && dc_prev,
+             "ag_lstm_front_bwd_step: null tensor");
+  AG_REQUIRE(B > 0 && B <= 65535 && H % 16 == 0 && Kp > 0 && Kp % 16 == 0 && lddh >= H,
+             "ag_lstm_front_bwd_step: bad shape");
+  AG_REQUIRE(lddxa % 4 == 0 && ldx % 4 == 0 && (!gx_out || ldgx % 4 == 0) && (((uintptr_t)dxa | (uintptr_t)x |
+             (uintptr_t)gx_out) & 15) == 0, "ag_lstm_front_bwd_step: rows must be 16-byte aligned");
+  BwdStepP q;
+  q.valid = nullptr; q.B = B; q.H = H;
+  BwdStepDir& D = q.d[0];
+  D.dg_next = dxa; D.lda = lddxa; D.Kp = Kp; D.whh = w_proj;
+  D.ax = x; D.ldax = ldx; D.aout = gx_out; D.ldaout = ldgx;
+  D.ga = gates; D.c_prev = c_prev; D.c_new = c_new;
+  D.dy = nullptr; D.ldy = 0;
+  D.dc_next = dc_next; D.dh_pass_in = dh_acc; D.lddhp = lddh;
+  D.dgates = dgates; D.dc_prev = dc_prev; D.dh_pass_out = nullptr;
+  D.t = 0;
+  q.d[1] = q.d[0];
+  if ((int64_t)(H / 16) * ag_cdiv(B, 16) > 256)
+    hipLaunchKernelGGL((lstm_step_bwd_kernel<1, 2, 2, true>), dim3(ag_cdiv(H, 32), 1, ag_cdiv(B, 16)), dim3(1024), 0,
+                       (hipStream_t)stream, q);
+  else
+    hipLaunchKernelGGL((lstm_step_bwd_kernel<1, 1, 2, true>), dim3(H / 16, 1, ag_cdiv(B, 16)), dim3(1024), 0,
+                       (hipStream_t)stream, q);
+  AG_CHECK_LAUNCH("ag_lstm_front_bwd_step");
+  return AG_OK;
 }
 
 // Whole layer backward through time: per step ONE pointwise launch and ONE K-split skinny
@@ -653,6 +720,7 @@ extern "C" int ag_lstm_seq_bwd(const float* const* gates, const float* const* wh
         const int tn = d == 0 ? k + 1 : T - 2 - k;     // time index of processing step k+1
         BwdStepDir& D = q.d[d];
         D.dg_next = (k == T - 1) ? nullptr : dgates[d] + (int64_t)tn * BG;
+        D.lda = 4 * H; D.Kp = 4 * H; D.ax = nullptr; D.aout = nullptr; D.ldax = D.ldaout = 0; D.lddhp = H;
         D.whh = whh[d];
         D.ga = gates[d] + (int64_t)t * BG;
         D.c_prev = c_all[d] + (int64_t)k * BH;
@@ -668,13 +736,7 @@ extern "C" int ag_lstm_seq_bwd(const float* const* gates, const float* const* wh
       }
       if (ndir == 1) q.d[1] = q.d[0];
       // one wave of workgroups fills the 256 CUs: two row tiles per workgroup once a single one would not
-      // one wave of workgroups fills the 256 CUs; once 16x16 tiles would need more, widen the tile along the
-      // units (full 128-byte W_hh lines per workgroup)
-      if ((int64_t)(H / 16) * ndir * ag_cdiv(B, 16) > 256)
-        hipLaunchKernelGGL((lstm_step_bwd_kernel<1, 2>), dim3(ag_cdiv(H, 32), ndir, ag_cdiv(B, 16)), dim3(1024), 0,
-                           st, q);
-      else
-        hipLaunchKernelGGL((lstm_step_bwd_kernel<1, 1>), dim3(H / 16, ndir, ag_cdiv(B, 16)), dim3(1024), 0, st, q);
+      launch_bwd_step(q, ndir, st);
       AG_CHECK_LAUNCH("ag_lstm_seq_bwd(step)");
     }
     return AG_OK;

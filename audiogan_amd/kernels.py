@@ -503,6 +503,30 @@ def skinny_gemm(A, B, Cm, tb=False, beta=0.0, bias=None, act=ACT_NONE, slope=LEA
                              slope, int(atomic), _stream()), 'ag_skinny_gemm')
 
 
+def lstm_front_bwd_ok(B, H, fs, dxa_t, x_t):
+    return (H % 16 == 0 and fs % 16 == 0 and B <= 65535 and dxa_t.stride(1) == 1 and x_t.stride(1) == 1
+            and dxa_t.stride(0) % 4 == 0 and x_t.stride(0) % 4 == 0 and _al16(dxa_t) and _al16(x_t))
+
+
+def lstm_front_bwd_step(dxa_t, x_t, gx_out, w_proj, dh_acc, gates, c_prev, c_new, dc_next, dgates, dc_prev):
+    """fused backward of one Generator-front frame: gx = dxa_t*(1-x_t^2) -> gx_out; dh = dh_acc + gx @ w_proj;
+    LSTMCell backward -> dgates, dc_prev.  dxa_t / x_t: [B,fs] row views; the rest contiguous."""
+    B, fs = dxa_t.shape
+    H = w_proj.size(1)
+    for t_, n, shp in ((gx_out, 'gx_out', (B, fs)), (w_proj, 'w_proj', (fs, H)),
+                       (gates, 'gates', (B, 4 * H)), (c_prev, 'c_prev', (B, H)), (c_new, 'c_new', (B, H)),
+                       (dgates, 'dgates', (B, 4 * H)), (dc_prev, 'dc_prev', (B, H))):
+        _chk(t_, n)
+        assert t_.is_contiguous() and tuple(t_.shape) == shp, (n, tuple(t_.shape), shp)
+    _chk(dxa_t, 'dxa_t'); _chk(x_t, 'x_t'); _chk(dc_next, 'dc_next'); _chk(dh_acc, 'dh_acc')
+    assert tuple(x_t.shape) == (B, fs) and lstm_front_bwd_ok(B, H, fs, dxa_t, x_t)
+    assert tuple(dh_acc.shape) == (B, H) and dh_acc.stride(1) == 1
+    assert dc_next is None or (dc_next.is_contiguous() and tuple(dc_next.shape) == (B, H))
+    check(lib.ag_lstm_front_bwd_step(_p(dxa_t), dxa_t.stride(0), _p(x_t), x_t.stride(0), _p(gx_out), fs, fs,
+                                     _p(w_proj), _p(dh_acc), dh_acc.stride(0), _p(gates), _p(c_prev), _p(c_new), _p(dc_next),
+                                     _p(dgates), _p(dc_prev), B, H, _stream()), 'ag_lstm_front_bwd_step')
+
+
 def lstm_step_ok(B, H, x=None, wx=None):
     ok = B <= 256 and H % 8 == 0
     if x is not None:

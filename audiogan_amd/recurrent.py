@@ -213,20 +213,9 @@ class GFrontFn(torch.autograd.Function):
         return x, s.view(T, B).t()
 
     @staticmethod
-    def backward(ctx, dx, ds):
-        front = ctx.front
-        fs, nl, S = front.fs, front.nl, front.ss
-        T, B, Fz = ctx.dims
-        prep = front.group.prepare()
-        assert front.group._key == ctx.key, 'parameters changed between forward and backward'
-        sv = ctx.saved_tensors
-        zc, x = sv[0], sv[1]
-        gates, hs, cs = sv[2:2 + nl], sv[2 + nl:2 + 2 * nl], sv[2 + 2 * nl:2 + 3 * nl]
-        dev = zc.device
-        lw = [[p.w for p in prep[4 * l:4 * l + 4]] for l in range(nl)]
-        pw, sw = prep[4 * nl].w, prep[4 * nl + 2].w
-        wx = lw[0][0][:, :fs]
-        dws = _zeros_like_list([it['v'] for it in front.group.items])
+    def _bwd_frames(T, B, fs, S, nl, x, dx, ds, gates, cs, lw, wx, pw, sw, hs, dws):
+        """per-frame chain, one launch per operation (any number of layers)"""
+        dev = x.device
         # dxa[:, frame t] accumulates dL/dx_t: output gradient + feedback from frame t+1
         dxa = dx.contiguous().clone() if dx is not None else torch.zeros(B, T * fs, device=dev)
         # dha[l][t] accumulates dL/dh_l[t]: recurrent term from frame t+1, the layer above / the
@@ -253,6 +242,55 @@ class GFrontFn(torch.autograd.Function):
                     _small_acc(dgs[l][t], lw[l][0], dha[l - 1][t])           # into h_{l-1}[t]
                 elif t > 0:
                     _small_acc(dgs[0][t], wx, dxa[:, (t - 1) * fs:t * fs])   # into x_{t-1}
+        return dgs, dxt
+
+    @staticmethod
+    def _bwd_frames_fused(T, B, fs, S, x, dx, ds, gates, cs, w_hh, wx, pw, sw, hs, dws, nl):
+        """single-layer front: TWO launches per frame.  dacc[t] = [dL/dh_t | dL/dx_t] lives in one [B, S+fs]
+        row so that  dacc[t-1] += dgates_t @ [W_hh | W_ih[:, :fs]]  is ONE product, and the tanh backward of the
+        projection, its product and the cell backward are one fused step (ag_lstm_front_bwd_step)."""
+        dev = x.device
+        dacc = torch.zeros(T, B, S + fs, device=dev)
+        if dx is not None:
+            dacc[:, :, S:].copy_(dx.contiguous().view(B, T, fs).transpose(0, 1))
+        if ds is not None:
+            ds_tb = ds.t().contiguous().view(T * B, 1)
+            K.gemm(ds_tb, hs.view(T * B, S), dws[4 * nl + 2], ta=True)
+            K.col_sum(ds_tb, dws[4 * nl + 3])
+            K.gemm(ds_tb, sw, dacc.view(T * B, S + fs)[:, :S])
+        wcat = torch.cat([w_hh, wx], 1)                # [4S, S+fs]
+        dgs = torch.empty(T, B, 4 * S, device=dev)
+        dxt = torch.empty(T, B, fs, device=dev)
+        dcs = [torch.empty(B, S, device=dev), torch.empty(B, S, device=dev)]
+        for t in reversed(range(T)):
+            K.lstm_front_bwd_step(dacc[t, :, S:], x[:, t * fs:(t + 1) * fs], dxt[t], pw, dacc[t, :, :S], gates[t], cs[t],
+                                  cs[t + 1], dcs[(t + 1) & 1] if t < T - 1 else None, dgs[t], dcs[t & 1])
+            if t > 0:
+                K.skinny_gemm(dgs[t], wcat, dacc[t - 1], atomic=True)
+        return [dgs], dxt
+
+    @staticmethod
+    def backward(ctx, dx, ds):
+        front = ctx.front
+        fs, nl, S = front.fs, front.nl, front.ss
+        T, B, Fz = ctx.dims
+        prep = front.group.prepare()
+        assert front.group._key == ctx.key, 'parameters changed between forward and backward'
+        sv = ctx.saved_tensors
+        zc, x = sv[0], sv[1]
+        gates, hs, cs = sv[2:2 + nl], sv[2 + nl:2 + 2 * nl], sv[2 + 2 * nl:2 + 3 * nl]
+        dev = zc.device
+        lw = [[p.w for p in prep[4 * l:4 * l + 4]] for l in range(nl)]
+        pw, sw = prep[4 * nl].w, prep[4 * nl + 2].w
+        wx = lw[0][0][:, :fs]
+        dws = _zeros_like_list([it['v'] for it in front.group.items])
+        fused = (nl == 1 and T > 0 and (S + fs) % 4 == 0
+                 and K.lstm_front_bwd_ok(B, S, fs, x[:, :fs], x[:, :fs]) and K.skinny_ok(gates[0][0], lw[0][1], False))
+        if fused:
+            dgs, dxt = GFrontFn._bwd_frames_fused(T, B, fs, S, x, dx, ds, gates[0], cs[0], lw[0][1], wx, pw, sw,
+                                                  hs[0], dws, nl)
+        else:
+            dgs, dxt = GFrontFn._bwd_frames(T, B, fs, S, nl, x, dx, ds, gates, cs, lw, wx, pw, sw, hs, dws)
         # parameter gradients, one GEMM per tensor over all frames
         dxt2 = dxt.view(T * B, fs)
         K.gemm(dxt2, hs[-1].view(T * B, S), dws[4 * nl], ta=True)

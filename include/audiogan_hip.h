@@ -237,6 +237,17 @@ int ag_lstm_seq_bwd(const float* const* gates, const float* const* whh, const fl
                     const int64_t* valid_i64, int T, int B, int H, int ndir, int k_begin, int k_end,
                     int phases, void* stream);
 
+/* One fused backward step of the Generator front (audiogan.py:428-460: LSTMCell -> tanh(Linear) fed back), frame t:
+ *   gx     = dxa * (1 - x_t^2)                        d(pre-tanh) of the projection, stored to gx_out [B,Kp]
+ *   dh     = dh_acc + gx * w_proj                      w_proj [Kp = frame size, H]; dh_acc [B,H] rows, pitch lddh
+ *   (dgates, dc_prev) = LSTMCell backward(dh, dc_next; gates, c_prev, c_new)
+ * ONE launch instead of tanh-backward + product + cell-backward.  dxa / x / gx_out are [B,Kp] row views (pitches in
+ * floats, multiples of 4, 16-byte aligned); Kp % 16 == 0, H % 16 == 0; dc_next may be NULL (last frame). */
+int ag_lstm_front_bwd_step(const float* dxa, int lddxa, const float* x, int ldx, float* gx_out, int ldgx, int Kp,
+                           const float* w_proj, const float* dh_acc, int lddh, const float* gates, const float* c_prev,
+                           const float* c_new, const float* dc_next, float* dgates, float* dc_prev, int B, int H,
+                           void* stream);
+
 /* ---------------------------------------------------------------------------
  * Masked BCE-with-logits per sample (audiogan.py:187-197 + :204-211 + the
  * "/ nframes ... .mean()" at :739-740,766,780,864,897), fused:

@@ -125,6 +125,17 @@ def channel_sum(dy, db):
     db.add_(dy.sum((0, 2)))
 
 
+def lstm_front_bwd_ok(B, H, fs, dxa_t, x_t):
+    return H % 16 == 0 and fs % 16 == 0
+
+
+def lstm_front_bwd_step(dxa_t, x_t, gx_out, w_proj, dh_acc, gates, c_prev, c_new, dc_next, dgates, dc_prev):
+    gx = dxa_t * (1 - x_t * x_t)
+    gx_out.copy_(gx)
+    dh = dh_acc + gx @ w_proj
+    lstm_cell_bwd(gates, c_prev, c_new, dh, None, dc_next, dgates, dc_prev)
+
+
 def leaky_bwd(dy, y, dpre, lens=None, slope=LEAKY_SLOPE, add_into=None, bias_grad=None):
     B, C, L = dy.shape
     g = torch.where(y > 0, dy, dy * slope)

@@ -418,3 +418,29 @@ def test_act_bwd2d(K):
     out = torch.empty(64, 256).cuda()
     K.act_bwd2d(dev(dy)[:, 512:768], dev(y)[:, 512:768], out, K.ACT_TANH)
     close(out, dy[:, 512:768] * (1 - y[:, 512:768] ** 2), rtol=1e-5)
+
+
+@pytest.mark.parametrize('B,H,fs,T', [(64, 1024, 256, 3), (5, 32, 16, 2), (40, 512, 48, 1), (130, 64, 32, 2)])
+def test_lstm_front_bwd_step(K, B, H, fs, T):
+    """fused Generator-front backward step (tanh' on load, projection product, cell backward) on row views"""
+    gen = torch.Generator().manual_seed(21)
+    dacc = torch.randn(T, B, H + fs, generator=gen)            # [dL/dh | dL/dx] joint rows
+    x = torch.tanh(torch.randn(B, T * fs, generator=gen))
+    wp = torch.randn(fs, H, generator=gen) / fs ** 0.5
+    gates = torch.sigmoid(torch.randn(B, 4 * H, generator=gen))
+    gates[:, 2 * H:3 * H] = torch.tanh(torch.randn(B, H, generator=gen))
+    cp, cn, dcn = (torch.randn(B, H, generator=gen) for _ in range(3))
+    t = T - 1
+    for dc_next in (None, dcn):
+        rg, rdg, rdc = torch.empty(B, fs), torch.empty(B, 4 * H), torch.empty(B, H)
+        KM.lstm_front_bwd_step(dacc[t, :, H:], x[:, t * fs:(t + 1) * fs], rg, wp, dacc[t, :, :H], gates, cp, cn,
+                               dc_next, rdg, rdc)
+        d_acc, d_x = dev(dacc), dev(x)
+        g_, dg_, dc_ = torch.empty(B, fs).cuda(), torch.empty(B, 4 * H).cuda(), torch.empty(B, H).cuda()
+        assert K.lstm_front_bwd_ok(B, H, fs, d_acc[t, :, H:], d_x[:, t * fs:(t + 1) * fs])
+        K.lstm_front_bwd_step(d_acc[t, :, H:], d_x[:, t * fs:(t + 1) * fs], g_, dev(wp), d_acc[t, :, :H], dev(gates),
+                              dev(cp), dev(cn), dev(dc_next) if dc_next is not None else None, dg_, dc_)
+        close(g_, rg, rtol=1e-5, atol=1e-6)
+        close(dg_, rdg, rtol=1e-3, atol=1e-5)
+        close(dc_, rdc, rtol=1e-3, atol=1e-5)
+        close(d_acc, dacc, rtol=0, atol=0)                     # inputs untouched
