@@ -85,7 +85,7 @@ __global__ __launch_bounds__(512) void conv_engine_kernel(const ConvP p) {
     // dependent memory round trips instead of one per loop iteration.
     // Input samples are fetched as 16-byte pieces aligned to a multiple of 4 samples (window start
     // rounded down), then scattered into the polyphase rows.
-    constexpr int UX = 2, UW = 4;
+    constexpr int UX = 2, UW = 6;
     const int step = nsw * 64;
     const int base4 = base - (((base % 4) + 4) % 4);       // floor to a multiple of 4 (base may be < 0)
     const int nq = (base - base4 + span + 3) / 4;          // float4 pieces per channel
@@ -166,6 +166,19 @@ __global__ __launch_bounds__(512) void conv_engine_kernel(const ConvP p) {
 
   stage(0, 0, wid, 8);
   __syncthreads();
+  // Both waves of a SIMD share its VALU issue, arbitrated by priority, then age: the staging waves (4-7, the
+  // younger half) would only get the slots the MFMA waves leave over and a chunk's staging would take
+  // longer than its MFMAs.  Their instruction count is small, so give them priority for the whole loop.
+  if (__builtin_amdgcn_readfirstlane(threadIdx.x) >= 256) {
+    __builtin_amdgcn_s_setprio(2);
+    // staging waves: their own loop (one barrier per chunk, like the MFMA waves), so that no accumulator
+    // register is live here and a whole chunk's loads fit in flight at once
+    for (int ci = 0; ci < nchunk; ++ci) {
+      if (ci + 1 < nchunk) stage((ci + 1) * p.CC, (ci + 1) & 1, cw, 4);
+      __syncthreads();
+    }
+    return;
+  }
   f32x16 acc[TILES_O][TILES_T];
 #pragma unroll
   for (int i = 0; i < TILES_O; ++i)
@@ -175,11 +188,6 @@ __global__ __launch_bounds__(512) void conv_engine_kernel(const ConvP p) {
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   for (int ci = 0; ci < nchunk; ++ci) {
-    if (wid >= 4) {
-      if (ci + 1 < nchunk) stage((ci + 1) * p.CC, (ci + 1) & 1, cw, 4);
-      __syncthreads();
-      continue;
-    }
     const float* xs = smem + (ci & 1) * bufsz;
     const float* ws = xs + (size_t)p.CC * chs;
     // ---- MFMA over (channel pair, tap)
@@ -220,7 +228,6 @@ __global__ __launch_bounds__(512) void conv_engine_kernel(const ConvP p) {
     }
     __syncthreads();
   }
-  if (wid >= 4) return;
 
   // ---- epilogue: bias + residual + activation + length mask (+ accumulate)
   const int64_t lenb = a.lens_i64 ? a.lens_i64[b] : (int64_t)1 << 60;
@@ -380,6 +387,15 @@ static int launch_cfg(ConvP& p, hipStream_t st) {
   }
 }
 
+// The ragged last column(s) of a transposed conv go to a second, narrow-tile launch after the main one.
+// (Running it beside the main launch on a side stream - fork / join events, a parallel branch under graph
+// capture - was measured: slower, both eagerly and in the replayed step.)
+template <typename MainFn, typename TailFn>
+static int main_and_tail(hipStream_t st, MainFn mainf, TailFn tailf) {
+  const int rc = mainf(st);
+  return rc != AG_OK ? rc : tailf(st);
+}
+
 extern "C" int ag_conv1d_engine(const ag_conv_args* args, void* stream) {
   AG_REQUIRE(args != nullptr, "ag_conv1d_engine: null args");
   ConvP p;
@@ -419,27 +435,29 @@ extern "C" int ag_conv1d_engine(const ag_conv_args* args, void* stream) {
   const int tail = p.n_cnt % 128, main_cols = p.n_cnt - tail;
   if (p.Mrows <= 64) {
     if (tail > 0 && tail <= 32 && main_cols > 0) {
-      ConvP q = p;
-      q.n_cnt = main_cols;
-      int rc = launch_cfg<2, 1, 1, 4>(q, st);
-      if (rc != AG_OK) return rc;
-      q = p;
-      q.n_lo += main_cols;
-      q.n_cnt = tail;
-      return launch_cfg<1, 1, 2, 2>(q, st);                   // 64 x 64
+      ConvP qm = p, qt = p;
+      qm.n_cnt = main_cols;
+      qt.n_lo += main_cols;
+      qt.n_cnt = tail;
+      return main_and_tail(st, [&](hipStream_t s_) { return launch_cfg<2, 1, 1, 4>(qm, s_); },
+                           [&](hipStream_t s_) { return launch_cfg<1, 1, 2, 2>(qt, s_); });   // 64 x 64
     }
     return launch_cfg<2, 1, 1, 4>(p, st);                     // 64 x 128
   }
   if (p.n_cnt <= 64) return launch_cfg<2, 1, 2, 2>(p, st);   // 128 x 64
+  // fewer than two 128x128 workgroups per CU: one MFMA wave per SIMD cannot keep the matrix pipe fed, take
+  // half-width tiles (twice the workgroups, two co-resident per CU)
+  if ((int64_t)ag_cdiv(p.n_cnt, 128) * ag_cdiv(p.Mrows, 128) * a.B < 512) return launch_cfg<2, 1, 2, 2>(p, st);
   if (tail > 0 && tail <= 32 && main_cols > 0) {
-    ConvP q = p;
-    q.n_cnt = main_cols;
-    int rc = launch_cfg<2, 2, 2, 2>(q, st);
-    if (rc != AG_OK) return rc;
-    q = p;
-    q.n_lo += main_cols;
-    q.n_cnt = tail;
-    return launch_cfg<1, 1, 4, 1>(q, st);                     // 128 x 32
+    ConvP qm = p, qt = p;
+    qm.n_cnt = main_cols;
+    qt.n_lo += main_cols;
+    qt.n_cnt = tail;
+    // (main: half-width tiles when there would be fewer than two 128x128 workgroups per CU, as above)
+    const bool half = (int64_t)(main_cols / 128) * ag_cdiv(p.Mrows, 128) * a.B < 512;
+    return main_and_tail(st, [&](hipStream_t s_) { return half ? launch_cfg<2, 1, 2, 2>(qm, s_)
+                                                                : launch_cfg<2, 2, 2, 2>(qm, s_); },
+                         [&](hipStream_t s_) { return launch_cfg<1, 1, 4, 1>(qt, s_); });     // 128 x 32
   }
   return launch_cfg<2, 2, 2, 2>(p, st);                       // 128 x 128
 }
