@@ -173,7 +173,90 @@ __global__ __launch_bounds__(512) void conv_engine_kernel(const ConvP p) {
     __builtin_amdgcn_s_setprio(2);
     // staging waves: their own loop (one barrier per chunk, like the MFMA waves), so that no accumulator
     // register is live here and a whole chunk's loads fit in flight at once
-    for (int ci = 0; ci < nchunk; ++ci) {
+    // Fast path: with 16-byte pieces that are entirely inside or entirely outside the signal (Lin % 4 == 0) and a
+    // chunk that fits one round of loads, every lane's source offsets, LDS targets and predicates are the same
+    // for every chunk.  They are computed ONCE here; per chunk the staging waves then issue plain loads off two
+    // moving base pointers and masked LDS writes - the integer divisions of the generic path (which compete with
+    // the MFMA waves for the SIMD's issue slots) leave the loop.
+    constexpr int FX = 4, FW = 8;                 // 16-byte pieces per lane: input / weights (one round of loads)
+    const int base4 = base - (((base % 4) + 4) % 4);
+    const int nq = (base - base4 + span + 3) / 4;
+    const int xtot = p.CC * nq, wtot = p.CC * taps * (OT / 4);
+    const bool fastp = p.xvec && (a.Lin % 4 == 0) && a.Lin >= 4 && xtot <= FX * 256 && wtot <= FW * 256 &&
+                       (int64_t)p.CC * a.x_cs < (1 << 30);
+    int xsrc[FX], wsrc[FW];       // source offsets (xsrc < 0: piece outside the signal -> zeros)
+    int xl[FX][4], wl[FW];        // LDS targets (-1: no write)
+    if (fastp) {
+#pragma unroll
+      for (int u = 0; u < FX; ++u) {
+        const int e = cw * 64 + lane + u * 256;
+        const bool valid = e < xtot;
+        const int cc = valid ? e / nq : 0, i4 = valid ? e - cc * nq : 0;
+        const int g = base4 + 4 * i4;
+        const bool inr = g >= 0 && g + 3 < a.Lin;
+        xsrc[u] = (valid && inr) ? (int)(cc * a.x_cs) + g : -1;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int rem = g + q - base;
+          int off = -1;
+          if (valid && rem >= 0 && rem < span) {
+            int r, qq;
+            if (S0 > 0) {
+              r = rem % SD;
+              qq = rem / SD;
+            } else if (TAPS > 0) {
+              r = 0;
+              qq = rem;
+            } else if (p.sp_shift >= 0) {
+              r = rem & (p.sp - 1);
+              qq = rem >> p.sp_shift;
+            } else {
+              qq = rem / p.sp;
+              r = rem - qq * p.sp;
+            }
+            off = cc * chs + r * rowlen + qq;
+          }
+          xl[u][q] = off;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < FW; ++u) {
+        const int idx = cw * 64 + lane + u * 256;
+        const int r4 = idx % (OT / 4), ct = idx / (OT / 4);
+        const int row = row0 + r4 * 4;
+        const bool ok = idx < wtot && row < p.Mpad;
+        wsrc[u] = ok ? ct * p.Mpad + row : 0;
+        wl[u] = ok ? ct * OT + r4 * 4 : -1;
+      }
+    }
+    // chunks 1 .. nfast are full (all CC channels exist) and take the fast path; the generic path finishes
+    // (at most the last, partial chunk - in a loop of its own so that the state above is dead there)
+    int nfast = 0;
+    if (fastp)
+      while (nfast + 1 < nchunk && (nfast + 2) * p.CC <= a.C) ++nfast;
+    int ci = 0;
+    for (; ci < nfast; ++ci) {
+      const int c0 = (ci + 1) * p.CC;
+      float* xs = smem + ((ci + 1) & 1) * bufsz;
+      float* ws = xs + (size_t)p.CC * chs;
+      const float* xc0 = xb + (int64_t)c0 * a.x_cs;
+      const float* wc0 = a.wp + (int64_t)c0 * taps * p.Mpad;
+      f32x4 xv[FX], wv[FW];
+#pragma unroll
+      for (int u = 0; u < FX; ++u) xv[u] = *reinterpret_cast<const f32x4*>(xc0 + max(xsrc[u], 0));
+#pragma unroll
+      for (int u = 0; u < FW; ++u) wv[u] = *reinterpret_cast<const f32x4*>(wc0 + wsrc[u]);
+#pragma unroll
+      for (int u = 0; u < FX; ++u)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (xl[u][q] >= 0) xs[xl[u][q]] = xsrc[u] < 0 ? 0.f : xv[u][q];
+#pragma unroll
+      for (int u = 0; u < FW; ++u)
+        if (wl[u] >= 0) *reinterpret_cast<f32x4*>(ws + wl[u]) = wv[u];
+      __syncthreads();
+    }
+    for (; ci < nchunk; ++ci) {
       if (ci + 1 < nchunk) stage((ci + 1) * p.CC, (ci + 1) & 1, cw, 4);
       __syncthreads();
     }
@@ -365,6 +448,14 @@ static int launch_cfg(ConvP& p, hipStream_t st) {
   if (cc < 2) cc = 2;
   if (cc > 32) cc = 32;
   if (cc > p.Cpad) cc = p.Cpad;
+  // the staging waves' fast path holds 4 input and 8 weight 16-byte pieces per lane (256 lanes): trim the chunk
+  // to that when it costs at most a third of the channels
+  {
+    const int nq = (p.sp * p.ncols + 6) / 4 + 1;
+    int cf = cc;
+    while (cf > 2 && (cf * nq > 4 * 256 || cf * p.taps * (OT / 4) > 8 * 256)) cf -= 2;
+    if (3 * cf >= 2 * cc) cc = cf;
+  }
   p.CC = cc;
   const size_t lds = 2 * (size_t)cc * per_c;
   if (lds > 160 * 1024) {
