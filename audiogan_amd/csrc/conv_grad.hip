@@ -116,6 +116,88 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgP p) {
   if (nmine > 0) stage(blockIdx.z, 0, wid, 8);
   __syncthreads();
 
+  if (__builtin_amdgcn_readfirstlane(threadIdx.x) >= 256) {
+    // ---- staging waves.  They share each SIMD's issue slots with an MFMA wave (arbitrated by priority, then
+    // age - they are the younger half), so they get static priority and, on the fast path, a loop without
+    // integer divisions: every lane's source offsets and LDS targets are the same for every chunk (pieces are
+    // 16-byte aligned in the signal, so a piece is entirely inside or outside it); only two base pointers move.
+    __builtin_amdgcn_s_setprio(2);
+    constexpr int FS = 4, FL = 5;
+    const int shift = (((-p.p) % 4) + 4) % 4;            // (s*t0 - p) mod 4, the same for every chunk
+    const int PR = (shift + span + 3) / 4;               // aligned pieces per lg row
+    const int q4 = p.TC >> 2;
+    const int stot = AT * q4, ltot4 = nch * PR;
+    const bool fastp = p.vec && (p.Lsh % p.TC == 0) && ((p.s * p.TC) % 4 == 0) && (p.Llg % 4 == 0) && p.Llg >= 4 &&
+                       (p.lg_cs % 4 == 0) && (p.lg_bs % 4 == 0) && (((uintptr_t)p.lg & 15) == 0) &&
+                       stot <= FS * 256 && ltot4 <= FL * 256 && (int64_t)AT * p.sh_cs < (1 << 30) &&
+                       (int64_t)p.maxch * p.lg_cs < (1 << 30);
+    int ssrc[FS], sl[FS], lsrc[FL], li0[FL], lrow[FL];
+    if (fastp) {
+#pragma unroll
+      for (int u = 0; u < FS; ++u) {
+        const int e = cw * 64 + lane + u * 256;
+        const int r = e / q4, q = e - r * q4;
+        const bool ok = e < stot && a0 + r < p.A;
+        ssrc[u] = ok ? (int)((a0 + r) * p.sh_cs) + 4 * q : 0;
+        sl[u] = e < stot ? (4 * q) * SP + r : -1;          // rows past A are staged as zeros
+        if (e < stot && !ok) ssrc[u] = -1;
+      }
+#pragma unroll
+      for (int u = 0; u < FL; ++u) {
+        const int e = cw * 64 + lane + u * 256;
+        const int r = e / PR, m = e - r * PR;
+        const bool ok = e < ltot4;
+        lsrc[u] = ok ? (int)((c_lo + r) * p.lg_cs) + 4 * m : 0;
+        li0[u] = ok ? 4 * m - shift : -(1 << 20);          // window index of the piece's first element
+        lrow[u] = r * p.lgp;
+      }
+    }
+    int ci = 0;
+    if (fastp) {
+      for (; ci < nmine; ++ci) {
+        if (ci + 1 < nmine) {
+          const int ch = blockIdx.z + (ci + 1) * gridDim.z;
+          const int b = ch / p.nchunk;
+          const int t0 = (ch - b * p.nchunk) * p.TC;
+          const int g0 = p.s * t0 - p.p;
+          float* shs = smem + ((ci + 1) & 1) * bufsz;
+          float* lgs = shs + (size_t)p.TC * SP;
+          const float* sbase = p.sh + (int64_t)b * p.sh_bs + t0;
+          const float* lrow0 = p.lg + (int64_t)b * p.lg_bs;
+          f32x4 sv[FS], lv[FL];
+          bool lok[FL];
+#pragma unroll
+          for (int u = 0; u < FS; ++u) sv[u] = *reinterpret_cast<const f32x4*>(sbase + max(ssrc[u], 0));
+#pragma unroll
+          for (int u = 0; u < FL; ++u) {
+            const int gp = g0 + li0[u];                    // global index of the piece's first element
+            lok[u] = gp >= 0 && gp + 3 < p.Llg;
+            lv[u] = *reinterpret_cast<const f32x4*>(lrow0 + (lok[u] ? lsrc[u] + (g0 - shift) : 0));
+          }
+#pragma unroll
+          for (int u = 0; u < FS; ++u)
+            if (sl[u] >= 0) {
+#pragma unroll
+              for (int x = 0; x < 4; ++x) shs[sl[u] + x * SP] = ssrc[u] < 0 ? 0.f : sv[u][x];
+            }
+#pragma unroll
+          for (int u = 0; u < FL; ++u)
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+              const int i = li0[u] + x;
+              if (i >= 0 && i < span) lgs[lrow[u] + i] = lok[u] ? lv[u][x] : 0.f;
+            }
+        }
+        __syncthreads();
+      }
+    }
+    for (; ci < nmine; ++ci) {
+      if (ci + 1 < nmine) stage(blockIdx.z + (ci + 1) * gridDim.z, (ci + 1) & 1, cw, 4);
+      __syncthreads();
+    }
+    return;
+  }
+
   // per-lane column constants
   int joff[TN];
   bool jok[TN];
@@ -136,11 +218,6 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgP p) {
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   for (int ci = 0; ci < nmine; ++ci) {
-    if (wid >= 4) {
-      if (ci + 1 < nmine) stage(blockIdx.z + (ci + 1) * gridDim.z, (ci + 1) & 1, cw, 4);
-      __syncthreads();
-      continue;
-    }
     const float* shs = smem + (ci & 1) * bufsz;
     const float* lgs = shs + (size_t)p.TC * SP;
     const float* arow = shs + h * SP + wa * 32 * TA + l31;
@@ -158,7 +235,6 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgP p) {
     }
     __syncthreads();
   }
-  if (wid >= 4) return;
 
 #pragma unroll
   for (int i = 0; i < TA; ++i)
