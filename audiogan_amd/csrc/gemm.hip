@@ -71,6 +71,21 @@ struct KContig {
     }
   }
   static __device__ __forceinline__ bool fast_ok(int r0, int nrows) { (void)r0; (void)nrows; return true; }
+  // per-lane source pointers at k = 0, computed once: the k loop then only adds the (uniform) k offset
+  const float* base[ITER];
+  __device__ __forceinline__ void init_fast(const float* __restrict__ G, int ld, int r0, int nrows, int tid) {
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      const int idx = tid + it * 256;
+      const int r = idx / GKQ, kq = idx % GKQ;
+      base[it] = G + (int64_t)min(r0 + r, nrows - 1) * ld + kq * 4;
+    }
+  }
+  __device__ __forceinline__ void load_hoisted(int ld, int k0) {
+    (void)ld;
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) v[it] = *reinterpret_cast<const f32x4*>(base[it] + k0);
+  }
   template <int PITCH>
   __device__ __forceinline__ void store(float* S, int tid) const {
 #pragma unroll
@@ -122,6 +137,20 @@ struct RContig {
     }
   }
   static __device__ __forceinline__ bool fast_ok(int r0, int nrows) { (void)r0; return (nrows & 3) == 0; }
+  const float* base[ITER];
+  __device__ __forceinline__ void init_fast(const float* __restrict__ G, int ld, int r0, int nrows, int tid) {
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      const int idx = tid + it * 256;
+      const int k = idx / R4, r = (idx % R4) * 4;
+      base[it] = G + (int64_t)k * ld + min(r0 + r, nrows - 4);
+    }
+  }
+  __device__ __forceinline__ void load_hoisted(int ld, int k0) {
+    const int64_t koff = (int64_t)k0 * ld;      // uniform
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) v[it] = *reinterpret_cast<const f32x4*>(base[it] + koff);
+  }
   template <int PITCH>
   __device__ __forceinline__ void store(float* S, int tid) const {
 #pragma unroll
@@ -160,6 +189,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
   const int kbeg = blockIdx.z * p.kchunk;
   const int kend = (kbeg + p.kchunk < p.K) ? kbeg + p.kchunk : p.K;
   const bool fast = p.vecA && p.vecB && la.fast_ok(m0, p.M) && lb.fast_ok(n0, p.N);
+  if (fast) {
+    la.init_fast(p.A, p.lda, m0, p.M, tid);
+    lb.init_fast(p.B, p.ldb, n0, p.N, tid);
+  }
   la.load(p.A, p.lda, m0, p.M, kbeg, p.K, p.vecA, tid);
   lb.load(p.B, p.ldb, n0, p.N, kbeg, p.K, p.vecB, tid);
   la.template store<PA>(As[0], tid);
@@ -170,8 +203,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
     const bool more = k0 + GBK < kend;
     if (more) {
       if (fast && k0 + 2 * GBK <= p.K) {
-        la.load_fast(p.A, p.lda, m0, p.M, k0 + GBK, tid);
-        lb.load_fast(p.B, p.ldb, n0, p.N, k0 + GBK, tid);
+        la.load_hoisted(p.lda, k0 + GBK);
+        lb.load_hoisted(p.ldb, k0 + GBK);
       } else {
         la.load(p.A, p.lda, m0, p.M, k0 + GBK, p.K, p.vecA, tid);
         lb.load(p.B, p.ldb, n0, p.N, k0 + GBK, p.K, p.vecB, tid);
