@@ -75,7 +75,7 @@ SIGNATURES = {
                                  f32, vp, C.c_int, f32, C.c_int, vp]),
     'ag_lstm_step_fwd': (C.c_int, [vp, vp, C.c_int, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_int,
                                    C.c_int, C.c_int, vp]),
-    'ag_lstm_seq_fwd': (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    'ag_lstm_seq_fwd': (C.c_int, [vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     'ag_lstm_seq_bwd': (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     'ag_bce_logits_fwd': (C.c_int, [vp, C.c_int, f32, vp, vp, vp, f32, C.c_int, C.c_int, vp]),
     'ag_bce_logits_bwd': (C.c_int, [vp, C.c_int, f32, vp, vp, f32, vp, C.c_int, C.c_int, C.c_int, vp]),

@@ -242,6 +242,7 @@ struct LstmDir {
   float* c_out;        // [B, H]
   float* h_out;        // [B, H]  (state; carried for padded rows)
   float* y_out;        // [B, ldy] slice of the layer output (0 for padded rows); may be NULL
+  const float* cb;     // optional [B, 4H]: time-invariant part of the pre-activations (static input + biases)
   int ldx, ldwx, Kx, ldy;
   int t;               // time index (for the valid mask)
 };
@@ -283,6 +284,10 @@ __global__ __launch_bounds__(512) void lstm_step_fwd_kernel(const LstmStepP p) {
     if (epi[t]) {
       const float* pre = D.pre + (int64_t)em * 4 * H + eu;
       pre4[t][0] = pre[0]; pre4[t][1] = pre[H]; pre4[t][2] = pre[2 * H]; pre4[t][3] = pre[3 * H];
+      if (D.cb) {
+        const float* cb = D.cb + (int64_t)em * 4 * H + eu;
+        pre4[t][0] += cb[0]; pre4[t][1] += cb[H]; pre4[t][2] += cb[2 * H]; pre4[t][3] += cb[3 * H];
+      }
       cp[t] = D.c_prev[(int64_t)em * H + eu];
       padded[t] = p.valid && D.t >= p.valid[em];
       if (padded[t]) hp[t] = D.h_prev[(int64_t)em * H + eu];
@@ -390,7 +395,7 @@ extern "C" int ag_lstm_step_fwd(float* gates_pre, const float* x, int ldx, const
   p.valid = nullptr; p.B = B; p.H = H; p.skip_h = first_step ? 1 : 0;
   LstmDir& d = p.d[0];
   d.pre = gates_pre; d.x = (first_step ? nullptr : x); d.wx = wx; d.h_prev = h_prev; d.whh = whh;
-  d.c_prev = c_prev; d.c_out = c_out; d.h_out = h_out; d.y_out = nullptr;
+  d.cb = nullptr; d.c_prev = c_prev; d.c_out = c_out; d.h_out = h_out; d.y_out = nullptr;
   d.ldx = ldx; d.ldwx = ldwx; d.Kx = Kx; d.ldy = 0; d.t = 0;
   p.d[1] = d;
   return launch_lstm_step(p, 1, (hipStream_t)stream);
@@ -401,8 +406,9 @@ extern "C" int ag_lstm_step_fwd(float* gates_pre, const float* x, int ldx, const
 //   whh   [ndir][4H,H];  c_all [ndir][T+1,B,H] (c_all[.,0] = 0 on entry);  hbuf [ndir][2][B,H] scratch
 //   y     [T,B,ndir*H] layer output.  Direction 1 runs the sequence in reverse.
 extern "C" int ag_lstm_seq_fwd(float* const* pre, const float* const* whh, float* const* c_all,
-                               float* const* hbuf, float* y, const int64_t* valid_i64, int T, int B, int H,
-                               int ndir, int k_begin, int k_end, void* stream) {
+                               float* const* hbuf, float* y, const int64_t* valid_i64,
+                               const float* const* static_pre, int T, int B, int H, int ndir, int k_begin,
+                               int k_end, void* stream) {
   AG_REQUIRE(pre && whh && c_all && hbuf && y, "ag_lstm_seq_fwd: null table");
   AG_REQUIRE(ndir == 1 || ndir == 2, "ag_lstm_seq_fwd: ndir must be 1 or 2");
   AG_REQUIRE(T > 0 && 0 <= k_begin && k_begin <= k_end && k_end <= T, "ag_lstm_seq_fwd: bad step range");
@@ -424,6 +430,7 @@ extern "C" int ag_lstm_seq_fwd(float* const* pre, const float* const* whh, float
       LstmDir& D = p.d[d];
       D.pre = pre[d] + (int64_t)t * B * 4 * H;
       D.x = nullptr; D.wx = nullptr; D.ldx = D.ldwx = D.Kx = 0;
+      D.cb = static_pre ? static_pre[d] : nullptr;
       D.h_prev = hbuf[d] + (k & 1) * BH;
       D.h_out = hbuf[d] + ((k + 1) & 1) * BH;
       D.whh = whh[d];

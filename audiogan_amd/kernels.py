@@ -556,17 +556,18 @@ def _ptr_table(tensors):
     return arr
 
 
-def lstm_seq_fwd(pre, whh, c_all, hbuf, y, valid):
-    """pre/whh/c_all/hbuf: lists (one per direction) of contiguous tensors; see ag_lstm_seq_fwd"""
+def lstm_seq_fwd(pre, whh, c_all, hbuf, y, valid, static=None):
+    """pre/whh/c_all/hbuf: lists (one per direction) of contiguous tensors; static: optional list of [B,4H]
+    tensors added to every step's pre-activations; see ag_lstm_seq_fwd"""
     T = pre[0].size(0)
     if Profiler.enabled:      # one call per step so that every launch can be timed on its own
         for k_ in range(T):
-            _lstm_seq_fwd_range(pre, whh, c_all, hbuf, y, valid, k_, k_ + 1)
+            _lstm_seq_fwd_range(pre, whh, c_all, hbuf, y, valid, k_, k_ + 1, static)
     else:
-        _lstm_seq_fwd_range(pre, whh, c_all, hbuf, y, valid, 0, T)
+        _lstm_seq_fwd_range(pre, whh, c_all, hbuf, y, valid, 0, T, static)
 
 
-def _lstm_seq_fwd_range(pre, whh, c_all, hbuf, y, valid, k0, k1):
+def _lstm_seq_fwd_range(pre, whh, c_all, hbuf, y, valid, k0, k1, static=None):
     ndir = len(pre)
     T, B, H4 = pre[0].shape
     H = H4 // 4
@@ -577,8 +578,14 @@ def _lstm_seq_fwd_range(pre, whh, c_all, hbuf, y, valid, k0, k1):
             assert t_.is_contiguous() and tuple(t_.shape) == shp, (tuple(t_.shape), shp)
     _chk(y, 'y'); _chk(valid, 'valid', torch.int64)
     assert y.is_contiguous() and tuple(y.shape) == (T, B, ndir * H)
+    if static is not None:
+        assert len(static) == ndir
+        for t_ in static:
+            _chk(t_, 'static')
+            assert t_.is_contiguous() and tuple(t_.shape) == (B, 4 * H)
     check(lib.ag_lstm_seq_fwd(_ptr_table(pre), _ptr_table(whh), _ptr_table(c_all), _ptr_table(hbuf), _p(y),
-                              _p(valid), T, B, H, ndir, k0, k1, _stream()), 'ag_lstm_seq_fwd')
+                              _p(valid), _ptr_table(static) if static is not None else None, T, B, H, ndir, k0, k1,
+                              _stream()), 'ag_lstm_seq_fwd')
 
 
 def lstm_seq_bwd(gates, whh, c_all, dy, dgates, dhbuf, dcbuf, valid):

@@ -266,9 +266,10 @@ class Discriminator(nn.Module):
         """the rest of forward() (audiogan.py:537-549): biLSTM over [conv features, c] + heads -> logits"""
         ss, es = self._state_size, self._embed_size
         b, tq = a.size(0), a.size(2)
-        seq = torch.cat([a.permute(2, 0, 1), c.unsqueeze(0).expand(tq, b, es)], 2)
+        # layer 0 sees cat([features_t, c]) at every frame (:541): c goes in as the layer's time-invariant input
+        seq = a.permute(2, 0, 1)
         for layer in range(self._num_layers):
-            seq = ops.LSTMSeqFn.apply(seq.contiguous(), n, 2, *self._rnn_weights(layer))
+            seq = ops.LSTMSeqFn.apply(seq.contiguous(), n, 2, c if layer == 0 else None, *self._rnn_weights(layer))
         # the heads are per-row: keep the LSTM's (time, clip) row order and transpose only the logits
         logits = ops.DHeadFn.apply(seq.reshape(tq * b, ss), self._head, *self._head.group.params())
         return logits.view(tq, b).t()
@@ -306,7 +307,7 @@ class Embedder(nn.Module):
             for suffix in ('', '_reverse'):
                 for n in ('weight_ih', 'weight_hh', 'bias_ih', 'bias_hh'):
                     w.append(getattr(self.rnn, '%s_l%d%s' % (n, layer, suffix)))
-            seq = ops.LSTMSeqFn.apply(seq, length, 2, *w)
+            seq = ops.LSTMSeqFn.apply(seq, length, 2, None, *w)
         h = o // 2
         # last hidden state: forward direction at t = len-1, reverse direction at t = 0
         idx = (length - 1).clamp(min=0)

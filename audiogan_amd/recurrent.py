@@ -37,30 +37,50 @@ def _small_acc(A, B, Cm, tb=False):
 # LSTM layer over a padded sequence (uni- or bidirectional), NN.LSTM parameter layout
 # --------------------------------------------------------------------------------------
 class LSTMSeqFn(torch.autograd.Function):
-    """x: [T,B,F]; lengths: int64 [B] on device or None; weights per direction:
-    (w_ih [4H,F], w_hh [4H,H], b_ih [4H], b_hh [4H]).  Returns y [T,B,D*H] with zeros at
-    padded steps (pad_packed_sequence semantics, audiogan.py:214-229)."""
+    """x: [T,B,Fx]; lengths: int64 [B] on device or None; ``static``: None or [B,Fc], a time-invariant part
+    of the input (the layer sees cat([x_t, static]) at every step, audiogan.py:541); weights per direction:
+    (w_ih [4H,Fx+Fc], w_hh [4H,H], b_ih [4H], b_hh [4H]).  Returns y [T,B,D*H] with zeros at padded steps
+    (pad_packed_sequence semantics, audiogan.py:214-229).
+
+    The static part is projected ONCE per clip (c @ W_ih[:, Fx:]^T + biases -> [B,4H]) and added inside the
+    step kernel, instead of being concatenated to all T frames and multiplied T times; its weight / input
+    gradients come from the time sum of dgates (the same pass that gives the bias gradient)."""
 
     @staticmethod
-    def forward(ctx, x, lengths, ndir, *w):
-        T, B, F = x.shape
+    def forward(ctx, x, lengths, ndir, static, *w):
+        T, B, Fx = x.shape
         H = w[1].size(1)
         dev = x.device
-        x2 = x.contiguous().view(T * B, F)
+        x2 = x.contiguous().view(T * B, Fx)
+        Fc = static.size(1) if static is not None else 0
+        assert w[0].size(1) == Fx + Fc
+        st = static.contiguous() if static is not None else None
         y = torch.empty(T, B, ndir * H, device=dev)
-        gates_all, c_all, whh = [], [], []
+        gates_all, c_all, whh, cbs = [], [], [], []
+        fused = K.lstm_step_ok(B, H)
         for d in range(ndir):
             w_ih, w_hh, b_ih, b_hh = w[4 * d:4 * d + 4]
             g = torch.empty(T, B, 4 * H, device=dev)
-            K.gemm(x2, w_ih.data, g.view(T * B, 4 * H), tb=True, bias=b_ih.data + b_hh.data)
+            bsum = b_ih.data + b_hh.data
+            if st is not None:
+                cb = torch.empty(B, 4 * H, device=dev)
+                K.gemm(st, w_ih.data[:, Fx:], cb, tb=True, bias=bsum)
+                if fused:
+                    K.gemm(x2, w_ih.data[:, :Fx], g.view(T * B, 4 * H), tb=True)
+                    cbs.append(cb)
+                else:       # generic per-step path: fold the static term into the pre-activations up front
+                    g.copy_(cb.unsqueeze(0).expand(T, B, 4 * H))
+                    K.gemm(x2, w_ih.data[:, :Fx], g.view(T * B, 4 * H), tb=True, beta=1.0)
+            else:
+                K.gemm(x2, w_ih.data, g.view(T * B, 4 * H), tb=True, bias=bsum)
             c = torch.empty(T + 1, B, H, device=dev)   # c[k+1] = cell after the k-th processed step
             c[0].zero_()
             gates_all.append(g)
             c_all.append(c)
             whh.append(w_hh.data.contiguous())
         hbuf = [torch.empty(2, B, H, device=dev) for _ in range(ndir)]
-        if K.lstm_step_ok(B, H):
-            K.lstm_seq_fwd(gates_all, whh, c_all, hbuf, y, lengths)
+        if fused:
+            K.lstm_seq_fwd(gates_all, whh, c_all, hbuf, y, lengths, static=cbs if cbs else None)
         else:
             for d in range(ndir):
                 g, c = gates_all[d], c_all[d]
@@ -72,21 +92,23 @@ class LSTMSeqFn(torch.autograd.Function):
                         K.gemm(hp, whh[d], g[t], tb=True, beta=1.0)
                     K.lstm_cell_fwd(g[t], c[k], c[k + 1], h_out=hn, y_out=y[t, :, d * H:(d + 1) * H],
                                     h_prev=hp, valid=lengths, t=t)
-        ctx.ndir, ctx.has_len = ndir, lengths is not None
+        ctx.ndir, ctx.has_len, ctx.has_static = ndir, lengths is not None, st is not None
         ctx.params = w
         ctx.save_for_backward(x2, y, lengths if lengths is not None else x2.new_empty(0),
+                              st if st is not None else x2.new_empty(0),
                               *(gates_all + c_all + [t_.data for t_ in w]))
-        ctx.shape = (T, B, F, H)
+        ctx.shape = (T, B, Fx, H)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        T, B, F, H = ctx.shape
+        T, B, Fx, H = ctx.shape
         ndir = ctx.ndir
         sv = ctx.saved_tensors
         x2, y = sv[0], sv[1]
         lengths = sv[2] if ctx.has_len else None
-        gates_all, c_all, w = list(sv[3:3 + ndir]), list(sv[3 + ndir:3 + 2 * ndir]), sv[3 + 2 * ndir:]
+        st = sv[3] if ctx.has_static else None
+        gates_all, c_all, w = list(sv[4:4 + ndir]), list(sv[4 + ndir:4 + 2 * ndir]), sv[4 + 2 * ndir:]
         dev = x2.device
         dy = dy.contiguous()
         whh = [w[4 * d + 1].contiguous() for d in range(ndir)]
@@ -106,14 +128,24 @@ class LSTMSeqFn(torch.autograd.Function):
                                     dg[t], dcb[d][k & 1], dh_pass=dpass, valid=lengths, t=t)
                     if k > 0:
                         K.gemm(dg[t], whh[d], dpass, beta=1.0)
-        dx2 = torch.empty(T * B, F, device=dev)
+        dx2 = torch.empty(T * B, Fx, device=dev)
         outs = []
-        wg = any(ctx.needs_input_grad[3:])
+        wg = any(ctx.needs_input_grad[4:])
+        need_ds = st is not None and ctx.needs_input_grad[3]
+        dstatic = torch.zeros_like(st) if need_ds else None
         for d in range(ndir):
             w_ih, w_hh = w[4 * d], w[4 * d + 1]
+            wx = w_ih[:, :Fx] if st is not None else w_ih
             dg2 = dgs[d].view(T * B, 4 * H)
+            K.gemm(dg2, wx, dx2, beta=0.0 if d == 0 else 1.0)
+            dgsum = None
+            if st is not None and (wg or need_ds):
+                # sum over time of dgates: the static input and the biases see every step's gradient
+                dgsum = torch.zeros(B, 4 * H, device=dev)
+                K.col_sum(dgs[d].view(T, B * 4 * H), dgsum.view(-1))
+                if need_ds:
+                    K.gemm(dgsum, w_ih[:, Fx:], dstatic, beta=1.0)
             if not wg:
-                K.gemm(dg2, w_ih, dx2, beta=0.0 if d == 0 else 1.0)
                 outs += [None, None, None, None]
                 continue
             tg = [grad_target(p_) for p_ in ctx.params[4 * d:4 * d + 4]]
@@ -122,11 +154,12 @@ class LSTMSeqFn(torch.autograd.Function):
             # where dgates is zero as well)
             if direct:      # accumulate straight into .grad
                 dw_ih, dw_hh = tg[0], tg[1]
-                K.gemm(dg2, x2, dw_ih, ta=True, beta=1.0)
             else:
-                dw_ih = torch.empty_like(w_ih)
-                K.gemm(dg2, x2, dw_ih, ta=True)
+                dw_ih = torch.zeros_like(w_ih)
                 dw_hh = torch.zeros_like(w_hh)
+            K.gemm(dg2, x2, dw_ih[:, :Fx] if st is not None else dw_ih, ta=True, beta=1.0)
+            if st is not None:
+                K.gemm(dgsum, st, dw_ih[:, Fx:], ta=True, beta=1.0)
             if T > 1:
                 if d == 0:
                     K.gemm(dgs[d][1:].view((T - 1) * B, 4 * H), y[:-1].view((T - 1) * B, ndir * H)[:, :H],
@@ -134,17 +167,17 @@ class LSTMSeqFn(torch.autograd.Function):
                 else:
                     K.gemm(dgs[d][:-1].view((T - 1) * B, 4 * H),
                            y[1:].view((T - 1) * B, ndir * H)[:, H:2 * H], dw_hh, ta=True, beta=1.0)
-            K.gemm(dg2, w_ih, dx2, beta=0.0 if d == 0 else 1.0)
+            src, rows = (dgsum, B) if dgsum is not None else (dg2, T * B)
             if direct:
-                K.col_sum(dg2, tg[2])
-                K.col_sum(dg2, tg[3])
+                K.col_sum(src.view(rows, 4 * H), tg[2])
+                K.col_sum(src.view(rows, 4 * H), tg[3])
                 outs += [None, None, None, None]
                 continue
             db = torch.zeros(4 * H, device=dev)
-            K.col_sum(dg2, db)
+            K.col_sum(src.view(rows, 4 * H), db)
             outs += [dw_ih, dw_hh, db, db.clone()]
-        dx = dx2.view(T, B, F) if ctx.needs_input_grad[0] else None
-        return (dx, None, None) + tuple(outs)
+        dx = dx2.view(T, B, Fx) if ctx.needs_input_grad[0] else None
+        return (dx, None, None, dstatic) + tuple(outs)
 
 
 # --------------------------------------------------------------------------------------

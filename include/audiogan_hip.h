@@ -225,13 +225,16 @@ int ag_lstm_step_fwd(float* gates_pre, const float* x, int ldx, const float* wx,
  *   pre[d]   [T,B,4H] x-projection + biases; overwritten with the activated gates
  *   whh[d]   [4H,H];  c_all[d] [T+1,B,H] with c_all[d][0] = 0;  hbuf[d] [2,B,H] scratch
  *   y        [T,B,ndir*H]; direction 1 walks the sequence backwards
+ *   static_pre  NULL, or a table of [B,4H] tensors added to the pre-activations of EVERY step: the projection of
+ *            a time-invariant part of the input (the Discriminator concatenates the conditioning vector c to
+ *            every frame, audiogan.py:541) plus the biases - computed once per clip instead of once per frame
  * Processing steps [k_begin, k_end) are enqueued (0, T for the whole layer; the state buffers
  * carry over between calls, forward in increasing and backward in decreasing step order).
  * ag_lstm_seq_bwd's `phases` is 3 in normal use; 1 enqueues only the pointwise cell backward and
  * 2 only the recurrent product of each step (lets a profiler time the two kernels separately). */
 int ag_lstm_seq_fwd(float* const* pre, const float* const* whh, float* const* c_all,
-                    float* const* hbuf, float* y, const int64_t* valid_i64, int T, int B, int H,
-                    int ndir, int k_begin, int k_end, void* stream);
+                    float* const* hbuf, float* y, const int64_t* valid_i64, const float* const* static_pre,
+                    int T, int B, int H, int ndir, int k_begin, int k_end, void* stream);
 int ag_lstm_seq_bwd(const float* const* gates, const float* const* whh, const float* const* c_all,
                     const float* dy, float* const* dgates, float* const* dhbuf, float* const* dcbuf,
                     const int64_t* valid_i64, int T, int B, int H, int ndir, int k_begin, int k_end,

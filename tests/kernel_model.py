@@ -342,7 +342,7 @@ def lstm_step_fwd(gates_pre, x, wx, h_prev, whh, c_prev, c_out, h_out, first_ste
     lstm_cell_fwd(gates_pre, c_prev, c_out, h_out=h_out)
 
 
-def lstm_seq_fwd(pre, whh, c_all, hbuf, y, valid):
+def lstm_seq_fwd(pre, whh, c_all, hbuf, y, valid, static=None):
     ndir = len(pre)
     T, B, H4 = pre[0].shape
     H = H4 // 4
@@ -353,6 +353,8 @@ def lstm_seq_fwd(pre, whh, c_all, hbuf, y, valid):
             hp, hn = hbuf[d][k & 1], hbuf[d][(k + 1) & 1]
             if k > 0:
                 pre[d][t].add_(hp @ whh[d].t())
+            if static is not None:
+                pre[d][t].add_(static[d])
             lstm_cell_fwd(pre[d][t], c_all[d][k], c_all[d][k + 1], h_out=hn,
                           y_out=y[t, :, d * H:(d + 1) * H], h_prev=hp, valid=valid, t=t)
 

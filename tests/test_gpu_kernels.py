@@ -371,7 +371,10 @@ def test_lstm_seq_fwd_bwd(K, T, B, H, ndir, ragged):
         hb = [to(torch.zeros(2, B, H)) for _ in range(ndir)]
         y = to(torch.full((T, B, ndir * H), float('nan')))
         v = to(valid) if valid is not None else None
-        mod.lstm_seq_fwd(p, w, c, hb, y, v)
+        # odd T: also exercise the time-invariant pre-activation term (static input + biases, added in the step)
+        st = [to(torch.randn(B, 4 * H, generator=torch.Generator().manual_seed(17 + d_))) for d_ in range(ndir)] \
+            if T % 2 == 1 else None
+        mod.lstm_seq_fwd(p, w, c, hb, y, v, static=st)
         dy = to(torch.randn(T, B, ndir * H, generator=torch.Generator().manual_seed(16)))
         dg = [to(torch.full((T, B, 4 * H), float('nan'))) for _ in range(ndir)]
         dh = [to(torch.zeros(2, B, H)) for _ in range(ndir)]
