@@ -10,7 +10,7 @@ import torch.distributed as dist
 class GradBucket(object):
     """Owns the flat gradient buffer of one network."""
 
-    def __init__(self, params, group=None, early=None):
+    def __init__(self, params, group=None, early=None, force_collective=False):
         """``early``: parameters whose gradients are final before the rest of backward has run (they
         are laid out first, so their all-reduce can be issued while backward continues)."""
         params = [p for p in params]
@@ -27,6 +27,8 @@ class GradBucket(object):
             p.grad = self.flat[o:o + p.numel()].view(p.shape)
             o += p.numel()
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        # force_collective: issue the all-reduce even in a 1-rank group (single-GPU rehearsal of the RCCL path)
+        self.force = bool(force_collective) and dist.is_available() and dist.is_initialized()
         self._work = None
 
     def zero(self):
@@ -46,7 +48,7 @@ class GradBucket(object):
         """sum over ranks; returns the scale the optimiser must apply (1/world).  part: 'all', 'early'
         (the leading n_early elements) or 'late' (the rest).  async_op=True: the collective runs on
         RCCL's own stream (after everything already enqueued on the current stream); call wait()."""
-        if self.world > 1:
+        if self.world > 1 or self.force:
             buf = {'all': self.flat, 'early': self.flat[:self.n_early], 'late': self.flat[self.n_early:]}[part]
             if buf.numel():
                 self._work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)

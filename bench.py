@@ -117,6 +117,21 @@ def cpu_baseline(batch, steps, opt_kind, threads=0, budget_s=45.0):
                                            opt_kind))
 
 
+class _StdoutToStderr(object):
+    """RCCL prints a version banner on fd 1 when a communicator is created; the bench's stdout must stay
+    ONE JSON line, so fd 1 points at fd 2 while the process group comes up"""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -146,9 +161,20 @@ def main():
     assert torch.cuda.is_available(), 'bench.py needs a GPU (no CPU fallback)'
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    if world > 1:
+    # AG_REHEARSE_RCCL=1 (with --force-phases): a 1-rank RCCL group whose all-reduces are really issued, to
+    # rehearse the N>1 sequence (communicator set-up, async collective between graph replays) on one GPU
+    rehearse = os.environ.get('AG_REHEARSE_RCCL') == '1' and world == 1
+    if world > 1 or rehearse:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl')
+        os.environ.setdefault('MASTER_PORT', '29533')
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
+        with _StdoutToStderr():
+            dist.init_process_group('nccl')
+            # the communicator itself is created lazily by the first collective: do that here, not in the step
+            t_ = torch.ones(1, device=dev)
+            dist.all_reduce(t_)
+            torch.cuda.synchronize()
 
     import audiogan_amd as A
     from audiogan_amd import train, ddp, kernels as K
@@ -159,8 +185,8 @@ def main():
     if multi:
         ddp.broadcast_parameters(g)
         ddp.broadcast_parameters(d)
-        bd = ddp.GradBucket(list(d.parameters()), early=d.early_params())
-        bg = ddp.GradBucket(list(g.parameters()))
+        bd = ddp.GradBucket(list(d.parameters()), early=d.early_params(), force_collective=rehearse)
+        bg = ddp.GradBucket(list(g.parameters()), force_collective=rehearse)
         opt_d.bucket, opt_g.bucket = bd, bg
         hook_d, hook_g = bd.all_reduce, bg.all_reduce
     batch = synthetic_batch(args.batch, dev, seed=1000 + rank)
@@ -333,7 +359,7 @@ def main():
             out['cpu_baseline'] = cpu_baseline(args.cpu_batch, args.cpu_steps, args.opt,
                                                min(32, os.cpu_count() or 1))
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or rehearse:
         dist.barrier()
         dist.destroy_process_group()
 
