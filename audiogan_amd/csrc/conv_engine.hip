@@ -344,8 +344,30 @@ __global__ __launch_bounds__(512) void conv_engine_kernel(const ConvP p) {
   // registers 4g..4g+3, i.e. VW consecutive output positions of one channel -> vector stores.
   const int s = a.stride;
   const int VW = (s % 4 == 0) ? 4 : ((s % 2 == 0) ? 2 : 1);
+  // stride % 4 == 0 (the generator's transposed convs and the backward of its strided convs): the residual - or
+  // for `accumulate` the old output - of a whole row tile is requested up front, one 16-byte load per group.
+  // Inside the per-group branches below every such load is followed by its own wait: 16 dependent round trips
+  // per workgroup, more than the MFMA loop of these thin layers takes.
+  const bool pre_res = VW == 4 && rb != nullptr;
+  const bool pre_acc = VW == 4 && !pre_res && a.accumulate;
 #pragma unroll
   for (int i = 0; i < TILES_O; ++i) {
+    f32x4u pre[4][TILES_T];
+    if (pre_res || pre_acc) {
+      const float* pb = pre_res ? rb : yb;
+      const int64_t pcs = pre_res ? a.res_cs : a.y_cs;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int rowb = row0 + wrow0 + 32 * i + 8 * g + 4 * h;
+        const int o = rowb / s, r = rowb - o * s;
+#pragma unroll
+        for (int j = 0; j < TILES_T; ++j) {
+          const int u0 = s * (n0 + wcol0 + 32 * j + l31) + r - a.pad;
+          const bool ok = rowb < p.Mrows && u0 >= 0 && u0 + 4 <= a.Lout;
+          pre[g][j] = *reinterpret_cast<const f32x4u*>(ok ? pb + (int64_t)o * pcs + u0 : pb);
+        }
+      }
+    }
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int rowb = row0 + wrow0 + 32 * i + 8 * g + 4 * h;
@@ -368,10 +390,11 @@ __global__ __launch_bounds__(512) void conv_engine_kernel(const ConvP p) {
           else { v[0] = (sub == 0 ? v4[0] : sub == 1 ? v4[1] : sub == 2 ? v4[2] : v4[3]) + bo; v[1] = v[2] = v[3] = 0.f; }
           const bool full = u0 >= 0 && u0 + VW <= a.Lout;
           if (full && VW == 4) {
-            if (rsrc) { const f32x4u rv = *reinterpret_cast<const f32x4u*>(rsrc); v[0] += rv[0]; v[1] += rv[1]; v[2] += rv[2]; v[3] += rv[3]; }
+            if (pre_res) { const f32x4u rv = pre[g][j]; v[0] += rv[0]; v[1] += rv[1]; v[2] += rv[2]; v[3] += rv[3]; }
 #pragma unroll
             for (int q = 0; q < 4; ++q) { v[q] = ag_apply_act(v[q], a.act, a.slope); if (u0 + q >= lenb) v[q] = 0.f; }
-            if (a.accumulate) { const f32x4u ov = *reinterpret_cast<const f32x4u*>(dst); v[0] += ov[0]; v[1] += ov[1]; v[2] += ov[2]; v[3] += ov[3]; }
+            if (pre_acc) { const f32x4u ov = pre[g][j]; v[0] += ov[0]; v[1] += ov[1]; v[2] += ov[2]; v[3] += ov[3]; }
+            else if (a.accumulate) { const f32x4u ov = *reinterpret_cast<const f32x4u*>(dst); v[0] += ov[0]; v[1] += ov[1]; v[2] += ov[2]; v[3] += ov[3]; }
             f32x4u out = {v[0], v[1], v[2], v[3]};
             *reinterpret_cast<f32x4u*>(dst) = out;
           } else if (full && VW == 2) {
