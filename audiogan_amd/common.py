@@ -3,8 +3,19 @@ import torch
 
 from . import kernels as K
 
-# bumped whenever parameters are rewritten through raw pointers (fused optimiser)
+# bumped whenever parameters are rewritten through raw pointers (fused optimiser): globally, and per parameter
+# (attribute ``_ag_epoch``) so that a block only re-materialises its weights when ITS parameters were stepped
 PARAM_EPOCH = [0]
+
+
+def param_epoch(p):
+    return getattr(p, '_ag_epoch', 0)
+
+
+def bump_param_epoch(params):
+    PARAM_EPOCH[0] += 1
+    for p in params:
+        p._ag_epoch = getattr(p, '_ag_epoch', 0) + 1
 
 
 # Parameter gradients are accumulated by the kernels straight into an already allocated ``.grad``
@@ -67,8 +78,8 @@ class WNGroup(object):
         dev = self.items[0]['v'].device
         if self._bufs is None or self._bufs[0].w.device != dev:
             self._alloc(dev)
-        key = (PARAM_EPOCH[0],) + tuple((it['v'].data_ptr(), it['v']._version, it['g'].data_ptr(),
-                                         it['g']._version) for it in self.items)
+        key = tuple((it['v'].data_ptr(), it['v']._version, param_epoch(it['v']), it['g'].data_ptr(),
+                     it['g']._version, param_epoch(it['g'])) for it in self.items)
         if key != self._key:
             ents = []
             for it, p in zip(self.items, self._bufs):

@@ -14,7 +14,7 @@ import torch.nn as nn
 
 from . import kernels as K
 from . import ops
-from .common import PARAM_EPOCH, Prepared, _zeros_like_list
+from .common import PARAM_EPOCH, Prepared, _zeros_like_list, param_epoch  # noqa: F401
 from .kernels import ACT_NONE, ACT_LEAKY, ACT_TANH
 from .ops import ConvSpec, conv_fwd, conv_bwd_data, conv_wgrad
 
@@ -44,7 +44,7 @@ class PlainGroup(object):
                 self._bufs.append(Prepared(w=None, wpa=torch.zeros(K.wpa_numel(d0, d1, kk), device=dev),
                                            wpb=torch.zeros(K.wpb_numel(d0, d1, kk, it['stride']), device=dev)))
             self._key = None
-        key = (PARAM_EPOCH[0],) + tuple((it['w'].data_ptr(), it['w']._version) for it in self.items)
+        key = tuple((it['w'].data_ptr(), it['w']._version, param_epoch(it['w'])) for it in self.items)
         if key != self._key:
             for it, p in zip(self.items, self._bufs):
                 K.prep_conv_weight(it['w'].data.contiguous(), p.wpa, p.wpb, it['stride'])

@@ -7,7 +7,8 @@ obsolete graph (computation_graph.py:58-59), which equal torch.optim.Adam's.
 import torch
 
 from . import kernels as K
-from . import ops
+from . import ops  # noqa: F401
+from . import common
 
 
 class _Fused(object):
@@ -111,7 +112,7 @@ class _Fused(object):
             assert not (f & 1), 'NaN in gradients (check_grad)'
             assert not (f & 2), '|grad| > 1e5 (check_grad)'
         self._launch(ps, gs, s1, s2, st['norms'], clip_norm, grad_scale)
-        ops.PARAM_EPOCH[0] += 1
+        common.bump_param_epoch(self.params)
         self.last_norm_sum, self.last_flags = st['norm_sum'], st['flags']
         return st['norm_sum']
 

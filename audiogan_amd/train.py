@@ -34,14 +34,16 @@ def d_step(g, d, opt_d, real, real_len, c, z, noise_real, noise_fake, dgradclip=
 
 
 def g_step(g, d, opt_g, c, z, noise_fake, ggradclip=0.1, g_optim='boundary_seeking', stop='never',
-           grad_hook=None, check=False):
+           grad_hook=None, check=False, pre=None):
     """One generator iteration: loss through D into G (audiogan.py:841-845, 857-864, 897,
-    902-903, 909-921)."""
+    902-903, 909-921).  ``pre``: the result of ``g(z=z, c=c, stop=stop)`` when the caller has already run the
+    generator's forward (it does not involve D, so it may be enqueued on a second stream beside the critic
+    iteration - bench.py does that)."""
     flags = [p.requires_grad for p in d.parameters()]
     for p in d.parameters():
         p.requires_grad_(False)
     try:
-        fake, _, _, fake_len = g(z=z, c=c, stop=stop)
+        fake, _, _, fake_len = pre if pre is not None else g(z=z, c=c, stop=stop)
         cls_g, _, _, nf_g = d(fake + noise_fake, fake_len, c)
         tgt = 0.5 if g_optim == 'boundary_seeking' else 0.0
         loss, _ = masked_bce_mean(cls_g, tgt, nf_g)

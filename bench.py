@@ -66,10 +66,26 @@ def synthetic_batch(batch, dev, seed):
     return {k: v.to(dev) for k, v in out.items()}
 
 
-def one_step(train, g, d, opt_g, opt_d, b, hook_d=None, hook_g=None):
+_SIDE = [None]
+
+
+def one_step(train, g, d, opt_g, opt_d, b, hook_d=None, hook_g=None, overlap=False):
+    """the canonical step.  overlap=True: the generator iteration's G forward (which depends on neither D nor the
+    critic iteration) is enqueued on a second stream beside the critic iteration; its latency-bound frame loop
+    then shares the GPU with the critic's equally latency-bound biLSTM chains.  Same work, same results."""
+    pre = None
+    if overlap:
+        if _SIDE[0] is None:
+            _SIDE[0] = torch.cuda.Stream()
+        main = torch.cuda.current_stream()
+        _SIDE[0].wait_stream(main)
+        with torch.cuda.stream(_SIDE[0]):
+            pre = g(z=b['z'], c=b['c'], stop='never')
     train.d_step(g, d, opt_d, b['real'], b['real_len'], b['c'], b['z'], b['noise_real'], b['noise_fake'],
                  1.0, grad_hook=hook_d)
-    train.g_step(g, d, opt_g, b['c'], b['z'], b['noise_fake'], 0.1, grad_hook=hook_g)
+    if overlap:
+        torch.cuda.current_stream().wait_stream(_SIDE[0])
+    train.g_step(g, d, opt_g, b['c'], b['z'], b['noise_fake'], 0.1, grad_hook=hook_g, pre=pre)
 
 
 def pmc_traffic(kernel):
@@ -146,6 +162,9 @@ def main():
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--force-phases', action='store_true',
                     help='use the multi-GPU code path (gradient buckets + 4 graphs per step) on one GPU')
+    ap.add_argument('--no-overlap', action='store_true',
+                    help='keep the G forward of the generator iteration on the main stream (default: on a second '
+                         'stream beside the critic iteration; single-GPU graph only)')
     ap.add_argument('--no-graph', action='store_true',
                     help='enqueue every kernel from Python each step instead of replaying a hipGraph')
     args = ap.parse_args()
@@ -236,7 +255,7 @@ def main():
         try:
             K.reserve_table_arena()
             if not multi:
-                graph = capture(lambda: one_step(train, g, d, opt_g, opt_d, batch))
+                graph = capture(lambda: one_step(train, g, d, opt_g, opt_d, batch, overlap=not args.no_overlap))
                 graph.replay()
             else:
                 scale = 1.0 / world
@@ -312,7 +331,9 @@ def main():
                                    'per-parameter clip d=1 g=0.1' % (args.batch, args.opt),
                        'global_batch': world * args.batch, 'clip_len': L,
                        'parallelism': 'dp%d' % world,
-                       'launch': ('hipGraph replay (1 graph per step)' if graph is not None else
+                       'launch': ('hipGraph replay (1 graph per step%s)' % ('' if args.no_overlap else
+                                  '; generator forward of the G iteration on a second stream beside the critic '
+                                  'iteration') if graph is not None else
                                   'hipGraph replay (5 graphs per step; D all-reduce overlaps the conv-stack backward)'
                                   if phases is not None
                                   else 'eager' + (' (capture failed: %s)' % capture_error if capture_error else ''))},
