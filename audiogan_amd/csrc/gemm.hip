@@ -6,6 +6,7 @@
 //
 // LDS tiles are k-major (As[k][m], Bs[k][n]) so that both MFMA operands are unit-stride,
 // conflict-free ds_read_b32; the loaders transpose k-contiguous operands on the way in.
+#include <cstdlib>
 #include <type_traits>
 
 #include "common.h"
@@ -284,6 +285,178 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// 128x128 tile fed by LDS-DMA (global_load_lds_dwordx4: global -> LDS without a VGPR stop, no ds_write):
+// ablation builds of gemm_kernel showed its MFMA + LDS-read loop alone at 116-129 TF and the register-staged
+// global -> LDS traffic costing the other 15 %.
+//   * A DMA instruction writes LDS at (wave-uniform base + lane * 16 B), so the LDS image is the lane order:
+//     k-contiguous operands land as [row][16 k] (64-byte rows), row-contiguous ones as [k][128 rows].
+//   * [row][16 k] is read with ONE ds_read_b128 per 8 k: a lane takes 4 consecutive k of its row and the four
+//     MFMAs of the group use them as k = 8q + 4h + e (h = lane >> 5; both operands use that k order).  64-byte rows
+//     would put rows m, m+4, m+8, m+12 on the same banks, so the 16-byte piece kq of row r is stored in slot
+//     kq ^ ((r >> 2) & 3) - applied to the SOURCE address of the DMA lane and to the reader's slot.
+//   * two LDS buffers in ONE array; tile i+1 is requested before the MFMAs of tile i, and the __syncthreads() that
+//     ends the iteration (vmcnt(0) + barrier) is what orders the DMA bytes before the next iteration's reads.
+// Needs K % 16 == 0 (per slice), 16-byte aligned rows, and row counts % 4 == 0 for row-contiguous operands.
+// ------------------------------------------------------------------------------------------
+#define LDS_AS(p) ((__attribute__((address_space(3))) void*)(p))
+#define GLB_AS(p) ((const __attribute__((address_space(1))) void*)(p))
+
+template <int TA, int TB>
+__global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmP p) {
+  constexpr int BM = 128, BN = 128, TILE = 128 * 16;      // floats per operand tile
+  __shared__ __attribute__((aligned(16))) float sm[2 * 2 * TILE];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int wm0 = (wid >> 1) * 64, wn0 = (wid & 1) * 64;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+
+  // per-lane DMA sources at k = 0 (two 16-byte pieces per operand per tile)
+  const float* asrc[2];
+  const float* bsrc[2];
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int idx = tid + 256 * it;
+    if (TA == 0) {        // A [M][K]: piece (row r, slot s) <- k piece s ^ ((r >> 2) & 3)
+      const int r = idx >> 2, sl = idx & 3;
+      asrc[it] = p.A + (int64_t)min(m0 + r, p.M - 1) * p.lda + 4 * (sl ^ ((r >> 2) & 3));
+    } else {              // A [K][M]
+      const int k = idx >> 5, r4 = idx & 31;
+      asrc[it] = p.A + (int64_t)k * p.lda + min(m0 + 4 * r4, p.M - 4);
+    }
+    if (TB == 1) {        // B [N][K]
+      const int r = idx >> 2, sl = idx & 3;
+      bsrc[it] = p.B + (int64_t)min(n0 + r, p.N - 1) * p.ldb + 4 * (sl ^ ((r >> 2) & 3));
+    } else {              // B [K][N]
+      const int k = idx >> 5, r4 = idx & 31;
+      bsrc[it] = p.B + (int64_t)k * p.ldb + min(n0 + 4 * r4, p.N - 4);
+    }
+  }
+  const int64_t astep = TA == 0 ? 1 : (int64_t)p.lda, bstep = TB == 1 ? 1 : (int64_t)p.ldb;   // per unit of k
+
+  auto stage = [&](int k0, int buf) {
+    float* As = sm + buf * 2 * TILE;
+    float* Bs = As + TILE;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int wbase = (wid * 64 + 256 * it) * 4;          // wave-uniform LDS float offset of this instruction
+      __builtin_amdgcn_global_load_lds(GLB_AS(asrc[it] + (int64_t)k0 * astep), LDS_AS(As + wbase), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(GLB_AS(bsrc[it] + (int64_t)k0 * bstep), LDS_AS(Bs + wbase), 16, 0, 0);
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int kbeg = blockIdx.z * p.kchunk;
+  const int kend = (kbeg + p.kchunk < p.K) ? kbeg + p.kchunk : p.K;
+  stage(kbeg, 0);
+  __syncthreads();
+  int buf = 0;
+  for (int k0 = kbeg; k0 < kend; k0 += 16) {
+    if (k0 + 16 < kend) stage(k0 + 16, buf ^ 1);
+    const float* As = sm + buf * 2 * TILE;
+    const float* Bs = As + TILE;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      f32x4 av[2], bv[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int m = wm0 + 32 * i + l31;
+        if (TA == 0) {
+          av[i] = *reinterpret_cast<const f32x4*>(As + m * 16 + 4 * ((2 * q + h) ^ ((m >> 2) & 3)));
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) av[i][e] = As[(8 * q + 4 * h + e) * 128 + m];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int n = wn0 + 32 * j + l31;
+        if (TB == 1) {
+          bv[j] = *reinterpret_cast<const f32x4*>(Bs + n * 16 + 4 * ((2 * q + h) ^ ((n >> 2) & 3)));
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) bv[j][e] = Bs[(8 * q + 4 * h + e) * 128 + n];
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][e], bv[j][e], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+    buf ^= 1;
+  }
+
+  if (p.ksplit == 1 && m0 + BM <= p.M && n0 + BN <= p.N) {
+    const bool hb = p.bias != nullptr, hr = p.res != nullptr, hbeta = p.beta != 0.f;
+    float bj[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) bj[j] = hb ? p.bias[n0 + wn0 + 32 * j + l31] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = m0 + wm0 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
+        float* dst = p.C + (int64_t)row * p.ldc + n0 + wn0 + l31;
+        const float* rs = p.res + (int64_t)row * p.ldres + n0 + wn0 + l31;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          float v = p.alpha * acc[i][j][e] + bj[j];
+          if (hbeta) v += p.beta * dst[32 * j];
+          if (hr) v += rs[32 * j];
+          dst[32 * j] = ag_apply_act(v, p.act, p.slope);
+        }
+      }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = m0 + wm0 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
+      if (row >= p.M) continue;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int col = n0 + wn0 + 32 * j + l31;
+        if (col >= p.N) continue;
+        float v = p.alpha * acc[i][j][e];
+        float* dst = p.C + (int64_t)row * p.ldc + col;
+        if (p.ksplit > 1) {
+          if (blockIdx.z == 0) {
+            if (p.bias) v += p.bias[col];
+            if (p.res) v += p.res[(int64_t)row * p.ldres + col];
+          }
+          atomicAdd(dst, v);
+          continue;
+        }
+        if (p.beta != 0.f) v += p.beta * *dst;
+        if (p.bias) v += p.bias[col];
+        if (p.res) v += p.res[(int64_t)row * p.ldres + col];
+        *dst = ag_apply_act(v, p.act, p.slope);
+      }
+    }
+}
+
+static int launch_gemm_dma(const GemmP& p, int ta, int tb, hipStream_t st) {
+  dim3 grid(ag_cdiv(p.N, 128), ag_cdiv(p.M, 128), p.ksplit);
+  if (ta == 0 && tb == 0) hipLaunchKernelGGL((gemm_dma_kernel<0, 0>), grid, dim3(256), 0, st, p);
+  if (ta == 0 && tb == 1) hipLaunchKernelGGL((gemm_dma_kernel<0, 1>), grid, dim3(256), 0, st, p);
+  if (ta == 1 && tb == 0) hipLaunchKernelGGL((gemm_dma_kernel<1, 0>), grid, dim3(256), 0, st, p);
+  if (ta == 1 && tb == 1) hipLaunchKernelGGL((gemm_dma_kernel<1, 1>), grid, dim3(256), 0, st, p);
+  AG_CHECK_LAUNCH("ag_gemm");
+  return AG_OK;
+}
+
 template <int TM, int TN, int WM, int WN>
 static int launch_gemm(const GemmP& p, int ta, int tb, hipStream_t st) {
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
@@ -343,7 +516,13 @@ extern "C" int ag_gemm(const float* A, int lda, int ta, const float* B, int ldb,
       }
     }
   }
-  if (use128) return launch_gemm<2, 2, 2, 2>(p, ta, tb, st);  // 128x128
+  if (use128) {
+    // LDS-DMA variant: whole 16-k tiles only, 16-byte aligned rows, row-contiguous operands with rows % 4 == 0
+    const bool dma = p.vecA && p.vecB && K % 16 == 0 && p.kchunk % 16 == 0 && (ta == 0 || M % 4 == 0) &&
+                     (tb == 1 || N % 4 == 0) && M >= 4 && N >= 4 && getenv("AG_GEMM_NODMA") == nullptr;
+    if (dma) return launch_gemm_dma(p, ta, tb, st);
+    return launch_gemm<2, 2, 2, 2>(p, ta, tb, st);  // 128x128
+  }
   return launch_gemm<1, 1, 2, 2>(p, ta, tb, st);              // 64x64
 }
 
