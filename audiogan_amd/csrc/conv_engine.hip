@@ -164,6 +164,13 @@ __global__ __launch_bounds__(512) void conv_engine_kernel(const ConvP p) {
     }
   };
 
+  // the bias of this workgroup's rows goes to LDS once (behind the two staging buffers): read per output group in
+  // the epilogue it would be 16-32 dependent global loads per lane
+  float* bias_s = smem + 2 * bufsz;
+  if (tid < OT) {
+    const int row = row0 + tid;
+    bias_s[tid] = (a.bias && row < p.Mrows) ? a.bias[a.mode == 0 ? row : row / a.stride] : 0.f;
+  }
   stage(0, 0, wid, 8);
   __syncthreads();
   // Both waves of a SIMD share its VALU issue, arbitrated by priority, then age: the staging waves (4-7, the
@@ -323,7 +330,7 @@ __global__ __launch_bounds__(512) void conv_engine_kernel(const ConvP p) {
       for (int e = 0; e < 16; ++e) {
         const int o = row0 + wrow0 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
         if (o >= p.Mrows) continue;
-        const float bo = a.bias ? a.bias[o] : 0.f;
+        const float bo = bias_s[o - row0];
 #pragma unroll
         for (int j = 0; j < TILES_T; ++j) {
           const int t = n0 + wcol0 + 32 * j + l31;
@@ -381,7 +388,7 @@ __global__ __launch_bounds__(512) void conv_engine_kernel(const ConvP p) {
           if (row >= p.Mrows) break;
           const int o = row / s, r = row - o * s;
           const int u0 = s * n + r - a.pad;
-          const float bo = a.bias ? a.bias[o] : 0.f;
+          const float bo = bias_s[row - row0];
           float* dst = yb + (int64_t)o * a.y_cs + u0;
           const float* rsrc = rb ? rb + (int64_t)o * a.res_cs + u0 : nullptr;
           float v[4];
@@ -480,7 +487,7 @@ static int launch_cfg(ConvP& p, hipStream_t st) {
     if (3 * cf >= 2 * cc) cc = cf;
   }
   p.CC = cc;
-  const size_t lds = 2 * (size_t)cc * per_c;
+  const size_t lds = 2 * (size_t)cc * per_c + (size_t)OT * sizeof(float);   // two buffers + the bias of the row tile
   if (lds > 160 * 1024) {
     ag_set_error("conv engine: tile needs %zu B of LDS", lds);
     return AG_ERR_UNSUPPORTED;
