@@ -279,6 +279,60 @@ static int launch_wgrad(WgP& p, hipStream_t st) {
   return AG_OK;
 }
 
+// Single-input-channel layer with a short kernel (D1: 1 -> 16 k7 s2): dw is 16 x 7 values, an MFMA tile would be
+// > 95 % padding and a thousand workgroups would fight over 112 atomic addresses (100 us).  Plain reduction:
+template <int KMAX, int AG>
+__global__ __launch_bounds__(256) void conv_c1_wgrad_kernel(const float* __restrict__ sh, int64_t sh_bs, int64_t sh_cs,
+                                                            const float* __restrict__ lg, int64_t lg_bs,
+                                                            float* __restrict__ dw, int B, int A, int Lsh, int Llg,
+                                                            int K, int s, int p, int bper) {
+  // a thread owns ONE time step (consecutive threads = consecutive steps: dy loads coalesce, x loads are s floats
+  // apart) and AG output channels: the K-wide x window is loaded once per clip and reused by the AG channels
+  __shared__ float red[4][AG * KMAX];
+  const int a0 = blockIdx.y * AG;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int b0 = blockIdx.z * bper, b1 = min(B, b0 + bper);
+  float acc[AG][KMAX];
+#pragma unroll
+  for (int i = 0; i < AG; ++i)
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) acc[i][k] = 0.f;
+  if (t < Lsh) {
+    const int q0 = s * t - p;
+    for (int b = b0; b < b1; ++b) {
+      const float* xr = lg + (int64_t)b * lg_bs;
+      float win[KMAX];
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k) {
+        const int q = q0 + k;
+        const float xv = xr[min(max(q, 0), Llg - 1)];          // unconditional load, then select
+        win[k] = (k < K && q >= 0 && q < Llg) ? xv : 0.f;
+      }
+      const float* dyr = sh + (int64_t)b * sh_bs + t;
+#pragma unroll
+      for (int i = 0; i < AG; ++i) {
+        const float g = dyr[(int64_t)min(a0 + i, A - 1) * sh_cs];
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) acc[i][k] += g * win[k];
+      }
+    }
+  }
+  // one barrier for all AG*KMAX sums: wave shuffles, per-wave partials in LDS, then one thread per value
+#pragma unroll
+  for (int i = 0; i < AG; ++i)
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+      const float v = ag_wave_sum(acc[i][k]);
+      if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][i * KMAX + k] = v;
+    }
+  __syncthreads();
+  if (threadIdx.x < AG * KMAX) {
+    const int i = threadIdx.x / KMAX, k = threadIdx.x % KMAX;
+    if (k < K && a0 + i < A)
+      atomicAdd(dw + (a0 + i) * K + k, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+  }
+}
+
 extern "C" int ag_conv1d_wgrad(const float* sh, int64_t sh_bs, int64_t sh_cs, const float* lg,
                                int64_t lg_bs, int64_t lg_cs, float* dw, int B, int A, int Lsh, int C,
                                int Llg, int K, int stride, int pad, void* stream) {
@@ -292,6 +346,19 @@ extern "C" int ag_conv1d_wgrad(const float* sh, int64_t sh_bs, int64_t sh_cs, co
   p.CK = C * K;
   p.vec = (((uintptr_t)sh & 15) == 0) && (sh_bs % 4 == 0) && (sh_cs % 4 == 0);
   hipStream_t st = (hipStream_t)stream;
+  if (C == 1 && K <= 8) {       // (K = 17, A = 128 - G1.conv - measured faster on the MFMA path: 43 vs 88 us)
+    const int ag = 8;
+    const int gx = ag_cdiv(Lsh, 256), gy = ag_cdiv(A, ag);
+    int gz = ag_cdiv(512, gx * gy);     // ~2 workgroups per CU: each ends in AG*K atomics on a handful of lines
+    if (gz > B) gz = B;
+    if (gz < 1) gz = 1;
+    const int bper = ag_cdiv(B, gz);
+    gz = ag_cdiv(B, bper);
+    hipLaunchKernelGGL((conv_c1_wgrad_kernel<8, 8>), dim3(gx, gy, gz), dim3(256), 0, st, sh, sh_bs, sh_cs, lg, lg_bs,
+                       dw, B, A, Lsh, Llg, K, stride, pad, bper);
+    AG_CHECK_LAUNCH("ag_conv1d_wgrad");
+    return AG_OK;
+  }
   if (A <= 32) return launch_wgrad<1, 1, 1, 4>(p, st);             // 32 x 128
   if (A <= 64 || p.CK <= 64) return launch_wgrad<1, 1, 2, 2>(p, st);  // 64 x 64
   return launch_wgrad<2, 2, 2, 2>(p, st);                           // 128 x 128
