@@ -84,13 +84,14 @@ def d_backward(g, d, opt_d, real, real_len, c, z, noise_real, noise_fake, stop='
     return loss.detach()
 
 
-def g_backward(g, d, opt_g, c, z, noise_fake, g_optim='boundary_seeking', stop='never'):
-    """forward + backward of the generator iteration (through D, whose weights get no gradient)"""
+def g_backward(g, d, opt_g, c, z, noise_fake, g_optim='boundary_seeking', stop='never', pre=None):
+    """forward + backward of the generator iteration (through D, whose weights get no gradient);
+    ``pre``: the generator's forward result when the caller already ran it (see g_step)"""
     flags = [p.requires_grad for p in d.parameters()]
     for p in d.parameters():
         p.requires_grad_(False)
     try:
-        fake, _, _, fake_len = g(z=z, c=c, stop=stop)
+        fake, _, _, fake_len = pre if pre is not None else g(z=z, c=c, stop=stop)
         cls_g, _, _, nf_g = d(fake + noise_fake, fake_len, c)
         loss, _ = masked_bce_mean(cls_g, 0.5 if g_optim == 'boundary_seeking' else 0.0, nf_g)
         opt_g.zero_grad()

@@ -261,12 +261,26 @@ def main():
                 scale = 1.0 / world
                 # critic: graph 1a ends where the gradients of heads + biLSTM are final; their all-reduce
                 # (93 % of D's bytes) then runs on RCCL's stream WHILE graph 1b does the conv-stack backward
-                g1a = capture(lambda: train.d_backward_early(g, d, opt_d, b_['real'], b_['real_len'], b_['c'],
-                                                             b_['z'], b_['noise_real'], b_['noise_fake'], keep))
+                def critic_early():
+                    # the G forward of the generator iteration is a parallel branch of this graph (as in the
+                    # single-graph step): fork, run it beside the critic, join before the capture ends
+                    if not args.no_overlap:
+                        if _SIDE[0] is None:
+                            _SIDE[0] = torch.cuda.Stream()
+                        _SIDE[0].wait_stream(torch.cuda.current_stream())
+                        with torch.cuda.stream(_SIDE[0]):
+                            keep['pre'] = g(z=b_['z'], c=b_['c'], stop='never')
+                    train.d_backward_early(g, d, opt_d, b_['real'], b_['real_len'], b_['c'], b_['z'],
+                                           b_['noise_real'], b_['noise_fake'], keep)
+                    if not args.no_overlap:
+                        torch.cuda.current_stream().wait_stream(_SIDE[0])
+
+                g1a = capture(critic_early)
                 g1b = capture(lambda: train.d_backward_late(keep), warm=False)
                 bd.all_reduce()
                 g2 = capture(lambda: opt_d.step(clip_norm=1.0, grad_scale=scale))
-                g3 = capture(lambda: train.g_backward(g, d, opt_g, b_['c'], b_['z'], b_['noise_fake']))
+                g3 = capture(lambda: train.g_backward(g, d, opt_g, b_['c'], b_['z'], b_['noise_fake'],
+                                                      pre=keep.get('pre')), warm=args.no_overlap)
                 bg.all_reduce()
                 g4 = capture(lambda: opt_g.step(clip_norm=0.1, grad_scale=scale))
                 phases = (g1a, g1b, g2, g3, g4)
