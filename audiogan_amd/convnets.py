@@ -120,8 +120,9 @@ class LinearFn(torch.autograd.Function):
     def forward(ctx, x, w, b):
         x = x.contiguous()
         y = torch.empty(x.size(0), w.size(0), device=x.device)
-        K.gemm(x, w.data.contiguous(), y, tb=True, bias=b.data if b is not None else None)
-        ctx.save_for_backward(x, w.data)
+        wc = w.data.contiguous()            # w may be a transposed / permuted view of the parameter
+        K.gemm(x, wc, y, tb=True, bias=b.data.contiguous() if b is not None else None)
+        ctx.save_for_backward(x, wc)
         ctx.has_b = b is not None
         return y
 
@@ -134,7 +135,7 @@ class LinearFn(torch.autograd.Function):
             dx = torch.empty_like(x)
             K.gemm(dy, w.contiguous(), dx)
         if ctx.needs_input_grad[1]:
-            dw = torch.empty_like(w)
+            dw = torch.empty(w.shape, device=w.device)
             K.gemm(dy, x, dw, ta=True)
         if ctx.has_b and ctx.needs_input_grad[2]:
             db = torch.zeros(w.size(0), device=x.device)
