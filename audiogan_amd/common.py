@@ -26,7 +26,7 @@ DIRECT_GRADS = [True]
 
 def grad_target(p):
     """the buffer to accumulate dL/dp into, or None (no .grad yet / feature off -> return the gradient)"""
-    if not DIRECT_GRADS[0] or not isinstance(p, torch.nn.Parameter):
+    if not DIRECT_GRADS[0] or not isinstance(p, torch.nn.Parameter) or not p.requires_grad:
         return None
     g = p.grad
     if g is None or not g.is_contiguous() or g.dtype != torch.float32 or g.requires_grad:
@@ -94,8 +94,8 @@ class WNGroup(object):
         Returns the flat list [dv0, dg0, dv1, dg1, ...]."""
         ents, outs = [], []
         for it, dw in zip(self.items, dws):
-            if dw is None:
-                outs += [None, None]
+            if dw is None or not (it['v'].requires_grad or it['g'].requires_grad):
+                outs += [None, None]        # no gradient arrived / tensor frozen (e.g. stopper-only backward)
                 continue
             tv, tg = grad_target(it['v']), grad_target(it['g'])
             if tv is not None and tg is not None:

@@ -53,3 +53,48 @@ def length_mask(size, length):
     b, n = int(size[0]), int(size[1])
     ar = torch.arange(n, device=length.device).unsqueeze(0)
     return (ar < length.view(b, 1)).float()
+
+
+def stopper_surrogate_loss(stop_logits, stops, reward, weight=None):
+    """Log-prob surrogate of the reference's REINFORCE update of the stop head (audiogan.py:444-451 draws
+    ``stop_t ~ Categorical([1 - sigmoid(s_t), sigmoid(s_t)])``; :866-887 builds ``reward = -(loss) - baseline``
+    per sample, times the frame weights; :887-902 ``stop_t.reinforce(reward[:, t])`` + backward into the stopper's
+    parameters only).  ``.reinforce`` no longer exists in torch; minimising
+
+        L = - sum_{b,t} reward[b,t] * log p(stops[b,t] | s[b,t])
+
+    gives the same gradient.  ``stops``: [B,T] tensor or the forward's ``stop_list`` (list of [B,1]); ``reward``:
+    [B] or [B,T] (treated as a constant); ``weight``: optional [B,T] frame mask.  Use it inside
+    ``only_stopper_trains(g)`` to reproduce the reference's freezing of every other generator parameter."""
+    import torch.nn.functional as F
+    if isinstance(stops, (list, tuple)):
+        stops = torch.cat([t.view(-1, 1) for t in stops], 1)
+    stops = stops.to(stop_logits.device).float()
+    T_ = min(stops.size(1), stop_logits.size(1))
+    s, stops = stop_logits[:, :T_], stops[:, :T_]
+    r = reward.detach()
+    if r.dim() == 1:
+        r = r.view(-1, 1).expand_as(s)
+    r = r[:, :T_]
+    if weight is not None:
+        r = r * weight[:, :T_].to(r.device)
+    logp = stops * F.logsigmoid(s) + (1.0 - stops) * F.logsigmoid(-s)
+    return -(r * logp).sum()
+
+
+class only_stopper_trains(object):
+    """context manager: every generator parameter except the stop head is frozen (audiogan.py:897-901)"""
+
+    def __init__(self, g):
+        self.g = g
+
+    def __enter__(self):
+        keep = set(id(p) for p in self.g.stopper.parameters())
+        self.flags = [(p, p.requires_grad) for p in self.g.parameters()]
+        for p, _ in self.flags:
+            p.requires_grad_(id(p) in keep)
+        return self
+
+    def __exit__(self, *exc):
+        for p, r in self.flags:
+            p.requires_grad_(r)

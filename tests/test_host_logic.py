@@ -111,6 +111,46 @@ def test_generator_stop_draws_match_oracle():
     np.testing.assert_array_equal(length.numpy(), len_o.numpy())
 
 
+def test_stopper_surrogate_trains_only_the_stop_head():
+    """REINFORCE of the stop head as a log-prob surrogate: gradients equal the oracle's autograd of the same
+    expression, only the stopper's parameters receive any (others frozen as audiogan.py:897-901) - also when the
+    gradients are accumulated straight into existing .grad buffers"""
+    from audiogan_amd import losses
+    torch.manual_seed(4)
+    go = O.Generator(8, 4, 3, 12, 1, struct=[[5, 2, 4, 2]])
+    g = M.Generator(8, 4, 3, 12, 1, struct=[[5, 2, 4, 2]])
+    g.load_state_dict(go.state_dict(), strict=True)
+    z, c = torch.randn(3, 6, 3), torch.randn(3, 4)
+    stop = torch.tensor([[0, 0, 0, 1, 0, 0], [0, 0, 0, 0, 1, 0], [0, 0, 0, 0, 0, 0]])
+    reward = torch.tensor([0.3, -1.2, 0.7])
+    for p in g.parameters():                 # existing .grad buffers: the direct-accumulation path
+        p.grad = torch.zeros_like(p)
+    _, so, stops_o, _ = go(z=z, c=c, stop=stop)
+    _, s, stops, _ = g(z=z, c=c, stop=stop)
+    st = torch.cat(stops_o, 1).float()
+    ref = -(reward.view(-1, 1) * (st * torch.nn.functional.logsigmoid(so) +
+                                  (1 - st) * torch.nn.functional.logsigmoid(-so))).sum()
+    for p in go.parameters():
+        p.requires_grad_(False)
+    for p in go.stopper.parameters():
+        p.requires_grad_(True)
+    ref.backward()
+    with losses.only_stopper_trains(g):
+        loss = losses.stopper_surrogate_loss(s, stops, reward)
+        loss.backward()
+    np.testing.assert_allclose(float(loss), float(ref), rtol=1e-5)
+    stop_ids = set(id(p) for p in g.stopper.parameters())
+    ref_grads = dict(go.named_parameters())
+    for name, p in g.named_parameters():
+        if id(p) in stop_ids:
+            if name.endswith('bias_v'):
+                continue
+            np.testing.assert_allclose(p.grad.numpy(), ref_grads[name].grad.numpy(), rtol=1e-4, atol=1e-6, err_msg=name)
+        else:
+            assert float(p.grad.abs().max()) == 0.0, name
+        assert p.requires_grad
+
+
 def _tiny_pair():
     torch.manual_seed(11)
     go = O.Generator(16, 6, 5, 24, 1, struct=[[9, 4, 8, 4], [9, 4, 8, 4]])
