@@ -185,11 +185,16 @@ __global__ __launch_bounds__(512) void conv_engine_kernel(const ConvP p) {
     // for every chunk.  They are computed ONCE here; per chunk the staging waves then issue plain loads off two
     // moving base pointers and masked LDS writes - the integer divisions of the generic path (which compete with
     // the MFMA waves for the SIMD's issue slots) leave the loop.
-    constexpr int FX = 4, FW = 8;                 // 16-byte pieces per lane: input / weights (one round of loads)
+    // 16-byte pieces per lane (one round of loads): input / weights.  Narrow row tiles stage mostly input
+    // (wide time tile, stride-s window), wide ones mostly weights (launch_cfg trims the chunk to these).
+    constexpr int FX = OT <= 32 ? 7 : 4, FW = OT <= 32 ? 3 : 8;
     const int base4 = base - (((base % 4) + 4) % 4);
     const int nq = (base - base4 + span + 3) / 4;
     const int xtot = p.CC * nq, wtot = p.CC * taps * (OT / 4);
-    const bool fastp = p.xvec && (a.Lin % 4 == 0) && a.Lin >= 4 && xtot <= FX * 256 && wtot <= FW * 256 &&
+    int nfast = 0;                      // full chunks after chunk 0 (all CC channels exist)
+    while (nfast + 1 < nchunk && (nfast + 2) * p.CC <= a.C) ++nfast;
+    // (the per-lane set-up below is not worth a single chunk)
+    const bool fastp = nfast >= 2 && p.xvec && (a.Lin % 4 == 0) && a.Lin >= 4 && xtot <= FX * 256 && wtot <= FW * 256 &&
                        (int64_t)p.CC * a.x_cs < (1 << 30);
     int xsrc[FX], wsrc[FW];       // source offsets (xsrc < 0: piece outside the signal -> zeros)
     int xl[FX][4], wl[FW];        // LDS targets (-1: no write)
@@ -238,9 +243,7 @@ __global__ __launch_bounds__(512) void conv_engine_kernel(const ConvP p) {
     }
     // chunks 1 .. nfast are full (all CC channels exist) and take the fast path; the generic path finishes
     // (at most the last, partial chunk - in a loop of its own so that the state above is dead there)
-    int nfast = 0;
-    if (fastp)
-      while (nfast + 1 < nchunk && (nfast + 2) * p.CC <= a.C) ++nfast;
+    if (!fastp) nfast = 0;
     int ci = 0;
     for (; ci < nfast; ++ci) {
       const int c0 = (ci + 1) * p.CC;
@@ -478,12 +481,13 @@ static int launch_cfg(ConvP& p, hipStream_t st) {
   if (cc < 2) cc = 2;
   if (cc > 32) cc = 32;
   if (cc > p.Cpad) cc = p.Cpad;
-  // the staging waves' fast path holds 4 input and 8 weight 16-byte pieces per lane (256 lanes): trim the chunk
-  // to that when it costs at most a third of the channels
+  // the staging waves' fast path holds FX input and FW weight 16-byte pieces per lane (256 lanes; 7/3 for 32-row tiles, else 4/8
+  // by row-tile height): trim the chunk to that when it costs at most a third of the channels
   {
     const int nq = (p.sp * p.ncols + 6) / 4 + 1;
     int cf = cc;
-    while (cf > 2 && (cf * nq > 4 * 256 || cf * p.taps * (OT / 4) > 8 * 256)) cf -= 2;
+    constexpr int FXH = OT <= 32 ? 7 : 4, FWH = OT <= 32 ? 3 : 8;   // = the kernel's FX, FW
+    while (cf > 2 && (cf * nq > FXH * 256 || cf * p.taps * (OT / 4) > FWH * 256)) cf -= 2;
     if (3 * cf >= 2 * cc) cc = cf;
   }
   p.CC = cc;
