@@ -81,6 +81,8 @@ SIGNATURES = {
     'ag_bce_logits_bwd': (C.c_int, [vp, C.c_int, f32, vp, vp, f32, vp, C.c_int, C.c_int, C.c_int, vp]),
     'ag_act_fwd': (C.c_int, [vp, vp, i64, C.c_int, f32, vp]),
     'ag_act_bwd': (C.c_int, [vp, vp, vp, i64, C.c_int, f32, vp]),
+    'ag_time_moments_fwd': (C.c_int, [vp, i64, i64, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
+    'ag_time_moments_bwd': (C.c_int, [vp, i64, i64, vp, vp, vp, vp, vp, i64, i64, C.c_int, C.c_int, C.c_int, vp]),
     'ag_act_bwd2d': (C.c_int, [vp, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, f32, vp]),
     'ag_axpby': (C.c_int, [vp, vp, i64, f32, f32, vp]),
     'ag_grad_norms': (C.c_int, [vp, C.c_int, vp, vp, vp, f32, vp, vp]),

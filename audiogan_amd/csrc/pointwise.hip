@@ -494,3 +494,99 @@ extern "C" int ag_act_bwd2d(const float* dy, int lddy, const float* y, int ldy, 
   AG_CHECK_LAUNCH("ag_act_bwd2d");
   return AG_OK;
 }
+
+
+// ------------------------------------------------------------------------------------------
+// Feature-matching statistics over time (audiogan.py:341-350, calc_dists): for every (clip, channel) row of an
+// activation h [B,C,L] with valid length len[b]
+//   m = sum_t h_t / len                       (the sum runs over ALL t: D has zeroed the padded steps)
+//   cen_t = h_t - m * [t < len]
+//   s = sqrt(sum_t cen_t^2) / len ,   f = (sum_t cen_t^4)^(1/4) / len
+// one wave per row, two passes over the row (mean, then central moments).  Backward:
+//   dh_t = gm/len + gs * (cen_t - A1/len) / (len * sqrt(S2)) + gf * (cen_t^3 - A3/len) / (len * S4^(3/4)),
+//   A1 = sum_t cen_t [t<len],  A3 = sum_t cen_t^3 [t<len]
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void time_moments_fwd_kernel(const float* __restrict__ h, int64_t bs, int64_t cs,
+                                                               const int64_t* __restrict__ lens, float* __restrict__ m,
+                                                               float* __restrict__ s, float* __restrict__ f, int B,
+                                                               int C, int L) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= B * C) return;
+  const int b = row / C, c = row - b * C;
+  const float* hr = h + (int64_t)b * bs + (int64_t)c * cs;
+  const int len = (int)lens[b];
+  const float lf = (float)len;
+  float sum = 0.f;
+  for (int t = lane; t < L; t += 64) sum += hr[t];
+  sum = ag_wave_sum(sum);
+  const float mean = sum / lf;
+  float s2 = 0.f, s4 = 0.f;
+  for (int t = lane; t < L; t += 64) {
+    const float cen = hr[t] - (t < len ? mean : 0.f);
+    const float c2 = cen * cen;
+    s2 += c2;
+    s4 += c2 * c2;
+  }
+  s2 = ag_wave_sum(s2);
+  s4 = ag_wave_sum(s4);
+  if (lane == 0) {
+    m[row] = mean;
+    s[row] = sqrtf(s2) / lf;
+    f[row] = sqrtf(sqrtf(s4)) / lf;
+  }
+}
+
+__global__ __launch_bounds__(256) void time_moments_bwd_kernel(const float* __restrict__ h, int64_t bs, int64_t cs,
+                                                               const int64_t* __restrict__ lens,
+                                                               const float* __restrict__ gm, const float* __restrict__ gs,
+                                                               const float* __restrict__ gf, float* __restrict__ dh,
+                                                               int64_t dbs, int64_t dcs, int B, int C, int L) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= B * C) return;
+  const int b = row / C, c = row - b * C;
+  const float* hr = h + (int64_t)b * bs + (int64_t)c * cs;
+  float* dr = dh + (int64_t)b * dbs + (int64_t)c * dcs;
+  const int len = (int)lens[b];
+  const float lf = (float)len;
+  float sum = 0.f;
+  for (int t = lane; t < L; t += 64) sum += hr[t];
+  const float mean = ag_wave_sum(sum) / lf;
+  float s2 = 0.f, s4 = 0.f, a1 = 0.f, a3 = 0.f;
+  for (int t = lane; t < L; t += 64) {
+    const bool in = t < len;
+    const float cen = hr[t] - (in ? mean : 0.f);
+    const float c2 = cen * cen;
+    s2 += c2;
+    s4 += c2 * c2;
+    if (in) { a1 += cen; a3 += c2 * cen; }
+  }
+  s2 = ag_wave_sum(s2); s4 = ag_wave_sum(s4); a1 = ag_wave_sum(a1); a3 = ag_wave_sum(a3);
+  const float km = (gm ? gm[row] : 0.f) / lf;
+  // zero rows: sqrt'(0) is infinite; torch gives nan/inf there too - keep finite by dropping the term
+  const float ks = (gs && s2 > 0.f) ? gs[row] / (lf * sqrtf(s2)) : 0.f;
+  const float kf = (gf && s4 > 0.f) ? gf[row] / (lf * sqrtf(sqrtf(s4)) * sqrtf(s4)) : 0.f;
+  const float m1 = a1 / lf, m3 = a3 / lf;
+  for (int t = lane; t < L; t += 64) {
+    const float cen = hr[t] - (t < len ? mean : 0.f);
+    dr[t] = km + ks * (cen - m1) + kf * (cen * cen * cen - m3);
+  }
+}
+
+extern "C" int ag_time_moments_fwd(const float* h, int64_t bs, int64_t cs, const int64_t* lens_i64, float* m, float* s,
+                                   float* f, int B, int C, int L, void* stream) {
+  AG_REQUIRE(h && lens_i64 && m && s && f && B > 0 && C > 0 && L > 0, "ag_time_moments_fwd: bad args");
+  hipLaunchKernelGGL(time_moments_fwd_kernel, dim3(ag_cdiv(B * C, 4)), dim3(256), 0, (hipStream_t)stream, h, bs, cs,
+                     lens_i64, m, s, f, B, C, L);
+  AG_CHECK_LAUNCH("ag_time_moments_fwd");
+  return AG_OK;
+}
+
+extern "C" int ag_time_moments_bwd(const float* h, int64_t bs, int64_t cs, const int64_t* lens_i64, const float* gm,
+                                   const float* gs, const float* gf, float* dh, int64_t dbs, int64_t dcs, int B, int C,
+                                   int L, void* stream) {
+  AG_REQUIRE(h && lens_i64 && dh && B > 0 && C > 0 && L > 0, "ag_time_moments_bwd: bad args");
+  hipLaunchKernelGGL(time_moments_bwd_kernel, dim3(ag_cdiv(B * C, 4)), dim3(256), 0, (hipStream_t)stream, h, bs, cs,
+                     lens_i64, gm, gs, gf, dh, dbs, dcs, B, C, L);
+  AG_CHECK_LAUNCH("ag_time_moments_bwd");
+  return AG_OK;
+}

@@ -1,8 +1,8 @@
 """The parts of the reference's *current* D/G iterations that sit on top of the classic step
 (SURVEY.md section 8(f), rank 2): the feature-matching penalty over D's conv activations and the
 FGSM-style input / latent perturbations.  They reuse the hot-path kernels for every D/G pass and
-input gradient; the moment statistics themselves are small torch reductions over [B,C,L]
-activations (not yet fused HIP kernels).
+input gradient; the per-(clip, channel) moment statistics over time are one HIP kernel per
+activation (ag_time_moments_fwd/bwd), their batch means / stds tiny reductions over [B,C].
 
   fourth_moment, calc_dists        audiogan.py:336-359
   feature_penalty                  audiogan.py:850-855 (and :112-117)
@@ -11,7 +11,31 @@ activations (not yet fused HIP kernels).
 """
 import torch
 
-from .losses import binary_cross_entropy_with_logits_per_sample, length_mask
+from . import kernels as K
+from .losses import binary_cross_entropy_with_logits_per_sample, length_mask  # noqa: F401
+
+
+class _TimeMomentsFn(torch.autograd.Function):
+    """h [B,C,L], lengths [B] -> (m, s, f) [B,C] as in calc_dists (audiogan.py:345-350)"""
+
+    @staticmethod
+    def forward(ctx, h, lens):
+        B, C, _ = h.shape
+        lens = lens.to(h.device).long().contiguous()
+        m, s, f = (torch.empty(B, C, device=h.device) for _ in range(3))
+        if h.stride(2) != 1:
+            h = h.contiguous()
+        K.time_moments_fwd(h, lens, m, s, f)
+        ctx.save_for_backward(h, lens)
+        return m, s, f
+
+    @staticmethod
+    def backward(ctx, gm, gs, gf):
+        h, lens = ctx.saved_tensors
+        dh = torch.empty(h.shape, device=h.device)
+        cont = lambda t: t.contiguous() if t is not None else None      # noqa: E731
+        K.time_moments_bwd(h, lens, cont(gm), cont(gs), cont(gf), dh)
+        return dh, None
 
 
 def fourth_moment(v):
@@ -27,12 +51,7 @@ def calc_dists(hidden_states, hidden_state_lengths):
     over time, then batch mean and std of each; returns (statistic, std) pairs in the reference order."""
     means_d, stds_d, fourth_d = [], [], []
     for h, l in zip(hidden_states, hidden_state_lengths):
-        mask = length_mask((h.size(0), h.size(2)), l)
-        lf = l.unsqueeze(1).float()
-        m = h.sum(2) / lf
-        cen = h - m.unsqueeze(2) * mask.unsqueeze(1)
-        s = (cen ** 2).sum(2) ** (1. / 2.) / lf
-        f = (cen ** 4).sum(2) ** (1. / 4.) / lf
+        m, s, f = _TimeMomentsFn.apply(h, l)
         means_d += [(m.mean(0), m.std(0)), (s.mean(0), s.std(0)), (f.mean(0), f.std(0))]
         stds_d += [(m.std(0), m.std(0)), (s.std(0), s.std(0)), (f.std(0), f.std(0))]
         fourth_d += [(fourth_moment(m), m.std(0)), (fourth_moment(s), s.std(0)), (fourth_moment(f), f.std(0))]

@@ -751,3 +751,30 @@ def conv_o1_wgrad(dy, x, dw, K_, pad):
 
 for _n in ('conv_o1_fwd', 'conv_o1_bwd_data', 'conv_o1_wgrad'):
     _instrument(_n, None)
+
+
+# ------------------------------------------------------------------------------------
+# feature-matching statistics over time (calc_dists)
+# ------------------------------------------------------------------------------------
+def time_moments_fwd(h, lens, m, s, f):
+    """h [B,C,L] view (unit stride along L), lens int64 [B]; m, s, f [B,C] contiguous (written)"""
+    a = _bcl(h, 'h')
+    _chk(lens, 'lens', torch.int64)
+    B, Cc, L = h.shape
+    for t_, n in ((m, 'm'), (s, 's'), (f, 'f')):
+        _chk(t_, n)
+        assert t_.is_contiguous() and tuple(t_.shape) == (B, Cc)
+    check(lib.ag_time_moments_fwd(_p(h), a[0], a[1], _p(lens), _p(m), _p(s), _p(f), B, Cc, L, _stream()),
+          'ag_time_moments_fwd')
+
+
+def time_moments_bwd(h, lens, gm, gs, gf, dh):
+    a, d = _bcl(h, 'h'), _bcl(dh, 'dh')
+    _chk(lens, 'lens', torch.int64)
+    B, Cc, L = h.shape
+    assert tuple(dh.shape) == (B, Cc, L)
+    for t_, n in ((gm, 'gm'), (gs, 'gs'), (gf, 'gf')):
+        _chk(t_, n)
+        assert t_ is None or (t_.is_contiguous() and tuple(t_.shape) == (B, Cc))
+    check(lib.ag_time_moments_bwd(_p(h), a[0], a[1], _p(lens), _p(gm), _p(gs), _p(gf), _p(dh), d[0], d[1], B, Cc, L,
+                                  _stream()), 'ag_time_moments_bwd')

@@ -279,6 +279,16 @@ int ag_act_bwd2d(const float* dy, int lddy, const float* y, int ldy, float* dx, 
 /* y = a*x + b*y  on n contiguous floats */
 int ag_axpby(const float* x, float* y, int64_t n, float a, float b, void* stream);
 
+/* Feature-matching statistics over time of one activation h [B,C,L] (calc_dists, audiogan.py:341-350):
+ *   m[b,c] = sum_t h / len[b];  cen_t = h_t - m * [t < len[b]];
+ *   s[b,c] = sqrt(sum_t cen^2) / len[b];  f[b,c] = (sum_t cen^4)^(1/4) / len[b]
+ * (sums over ALL t: the critic has zeroed padded steps).  bwd: dh from the gradients of m, s, f (any may be NULL). */
+int ag_time_moments_fwd(const float* h, int64_t bs, int64_t cs, const int64_t* lens_i64, float* m, float* s, float* f,
+                        int B, int C, int L, void* stream);
+int ag_time_moments_bwd(const float* h, int64_t bs, int64_t cs, const int64_t* lens_i64, const float* gm,
+                        const float* gs, const float* gf, float* dh, int64_t dbs, int64_t dcs, int B, int C, int L,
+                        void* stream);
+
 /* ---------------------------------------------------------------------------
  * Fused optimiser: check_grad + per-PARAMETER clip + update for a whole network
  * in two launches (audiogan.py:232-253, 693-694, 786-788, 909-921).

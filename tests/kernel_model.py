@@ -426,3 +426,34 @@ def conv_o1_wgrad(dy, x, dw, K_, pad):
 
 ALL = [n for n, v in list(globals().items()) if callable(v) and not n.startswith('_')
        and n not in ('F', 'install')]
+
+
+def time_moments_fwd(h, lens, m, s, f):
+    B, C, L = h.shape
+    mask = (torch.arange(L).view(1, L) < lens.view(B, 1)).float()
+    lf = lens.view(B, 1).float()
+    mm = h.sum(2) / lf
+    cen = h - mm.unsqueeze(2) * mask.unsqueeze(1)
+    m.copy_(mm)
+    s.copy_((cen ** 2).sum(2) ** 0.5 / lf)
+    f.copy_((cen ** 4).sum(2) ** 0.25 / lf)
+
+
+def time_moments_bwd(h, lens, gm, gs, gf, dh):
+    with torch.enable_grad():       # called from inside an autograd backward
+        hh = h.detach().clone().requires_grad_(True)
+        B, C, L = hh.shape
+        mask = (torch.arange(L).view(1, L) < lens.view(B, 1)).float()
+        lf = lens.view(B, 1).float()
+        mm = hh.sum(2) / lf
+        cen = hh - mm.unsqueeze(2) * mask.unsqueeze(1)
+        z = torch.zeros(B, C)
+        tot = (mm * (gm if gm is not None else z)).sum() \
+            + (((cen ** 2).sum(2) ** 0.5 / lf) * (gs if gs is not None else z)).sum() \
+            + (((cen ** 4).sum(2) ** 0.25 / lf) * (gf if gf is not None else z)).sum()
+        g, = torch.autograd.grad(tot, hh)
+    dh.copy_(g)
+
+
+ALL = [n for n, v in list(globals().items()) if callable(v) and not n.startswith('_')
+       and n not in ('F', 'install')]

@@ -448,3 +448,28 @@ def test_lstm_front_bwd_step(K, B, H, fs, T):
         close(dg_, rdg, rtol=1e-3, atol=1e-5)
         close(dc_, rdc, rtol=1e-3, atol=1e-5)
         close(d_acc, dacc, rtol=0, atol=0)                     # inputs untouched
+
+
+@pytest.mark.parametrize('B,C,L', [(4, 16, 4096), (3, 5, 100), (2, 1, 7), (64, 512, 128)])
+def test_time_moments(K, B, C, L):
+    """calc_dists statistics over time (mean, 2nd / 4th central moment roots) and their backward, ragged lengths,
+    rows taken as a channel slice of a wider activation"""
+    gen = torch.Generator().manual_seed(31)
+    full = torch.randn(B, C + 3, L, generator=gen)
+    lens = torch.randint(max(1, L // 2), L + 1, (B,), generator=gen)
+    lens[0] = L
+    full = full * (torch.arange(L).view(1, 1, L) < lens.view(B, 1, 1)).float()      # the critic zeroes padded steps
+    h = full[:, 1:C + 1]
+    m, s, f = (torch.empty(B, C) for _ in range(3))
+    KM.time_moments_fwd(h, lens, m, s, f)
+    hd = dev(full)[:, 1:C + 1]
+    md, sd, fd = (torch.empty(B, C).cuda() for _ in range(3))
+    K.time_moments_fwd(hd, dev(lens), md, sd, fd)
+    close(md, m, rtol=1e-4, atol=1e-6); close(sd, s, rtol=1e-4, atol=1e-6); close(fd, f, rtol=1e-4, atol=1e-6)
+    gm, gs, gf = (torch.randn(B, C, generator=gen) for _ in range(3))
+    dh = torch.empty(B, C, L)
+    KM.time_moments_bwd(h, lens, gm, gs, gf, dh)
+    dhd = torch.zeros(B, C + 3, L).cuda()
+    K.time_moments_bwd(hd, dev(lens), dev(gm), dev(gs), dev(gf), dhd[:, 1:C + 1])
+    close(dhd[:, 1:C + 1], dh, rtol=2e-3, atol=1e-5)
+    assert not dhd[:, 0].any() and not dhd[:, C + 1:].any()
