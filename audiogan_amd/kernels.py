@@ -393,9 +393,9 @@ class Profiler(object):
         cls.enabled = False
         torch.cuda.synchronize()
         out = {}
-        for key, fl, by, e0, e1 in cls.records:
+        for key, fl, by, e0, e1, nl in cls.records:
             r = out.setdefault(key, dict(n=0, ms=0.0, flops=0.0, bytes=0.0))
-            r['n'] += 1
+            r['n'] += nl
             r['ms'] += e0.elapsed_time(e1)
             r['flops'] += fl
             r['bytes'] += by
@@ -411,8 +411,14 @@ def _work_gemm(A, B, Cm, ta=False, tb=False, *a_, **kw):
     M, N = Cm.shape
     Kd = A.size(0) if ta else A.size(1)
     big = _cdiv(M, 128) * _cdiv(N, 128)
-    tile = '2,2,2,2' if (M > 64 and N > 64 and (big >= 192 or Kd >= 2048)) else '1,1,2,2'
-    key = 'gemm_kernel<%s,%d,%d>' % (tile, int(ta), int(tb))
+    use128 = M > 64 and N > 64 and (big >= 192 or Kd >= 2048)
+    # mirrors ag_gemm's dispatch: the LDS-DMA kernel takes the 128x128 case when K % 16 == 0 and rows are 16-B aligned
+    dma = use128 and Kd % 16 == 0 and (not ta or M % 4 == 0) and (tb or N % 4 == 0) and \
+        A.stride(0) % 4 == 0 and B.stride(0) % 4 == 0 and _al16(A) and _al16(B)
+    if dma:
+        key = 'gemm_dma_kernel<%d,%d>' % (int(ta), int(tb))
+    else:
+        key = 'gemm_kernel<%s,%d,%d>' % ('2,2,2,2' if use128 else '1,1,2,2', int(ta), int(tb))
     return key, 2.0 * M * N * Kd, 4.0 * (M * Kd + N * Kd + M * N)
 
 
@@ -451,14 +457,16 @@ def _instrument(name, work):
     def wrapped(*a, **k):
         if not Profiler.enabled:
             return fn(*a, **k)
-        key, fl, by = work(*a, **k) if work is not None else (name, 0.0, 0.0)
+        w_ = work(*a, **k) if work is not None else (name, 0.0, 0.0)
+        key, fl, by = w_[:3]
+        nl = w_[3] if len(w_) > 3 else 1        # launches behind this call (a whole recurrent layer pass: T)
         if Profiler.only is not None and key != Profiler.only:
             return fn(*a, **k)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         r = fn(*a, **k)
         e1.record()
-        Profiler.records.append((key, fl, by, e0, e1))
+        Profiler.records.append((key, fl, by, e0, e1, nl))
         return r
     wrapped.__name__ = name
     wrapped.__doc__ = fn.__doc__
@@ -560,11 +568,9 @@ def lstm_seq_fwd(pre, whh, c_all, hbuf, y, valid, static=None):
     """pre/whh/c_all/hbuf: lists (one per direction) of contiguous tensors; static: optional list of [B,4H]
     tensors added to every step's pre-activations; see ag_lstm_seq_fwd"""
     T = pre[0].size(0)
-    if Profiler.enabled:      # one call per step so that every launch can be timed on its own
-        for k_ in range(T):
-            _lstm_seq_fwd_range(pre, whh, c_all, hbuf, y, valid, k_, k_ + 1, static)
-    else:
-        _lstm_seq_fwd_range(pre, whh, c_all, hbuf, y, valid, 0, T, static)
+    # (the profiler times the whole chain of T back-to-back launches with one pair of events and divides by T:
+    # events around every single launch add ~3 us to a 10 us kernel)
+    _lstm_seq_fwd_range(pre, whh, c_all, hbuf, y, valid, 0, T, static)
 
 
 def _lstm_seq_fwd_range(pre, whh, c_all, hbuf, y, valid, k0, k1, static=None):
@@ -592,10 +598,10 @@ def lstm_seq_bwd(gates, whh, c_all, dy, dgates, dhbuf, dcbuf, valid):
     T = gates[0].size(0)
     if Profiler.enabled:
         H = gates[0].size(2) // 4
+        if H % 16 == 0:         # the fused step kernel: the whole chain between one pair of events
+            _lstm_seq_bwd_step(gates, whh, c_all, dy, dgates, dhbuf, dcbuf, valid, 0, T, 3)
+            return
         for k_ in reversed(range(T)):
-            if H % 16 == 0:     # the fused step kernel (product of step k+1 + cell backward of step k)
-                _lstm_seq_bwd_step(gates, whh, c_all, dy, dgates, dhbuf, dcbuf, valid, k_, k_ + 1, 3)
-                continue
             _lstm_seq_bwd_cell(gates, whh, c_all, dy, dgates, dhbuf, dcbuf, valid, k_, k_ + 1, 1)
             if k_ > 0:
                 _lstm_seq_bwd_prod(gates, whh, c_all, dy, dgates, dhbuf, dcbuf, valid, k_, k_ + 1, 2)
@@ -643,10 +649,10 @@ def _work_step(gates_pre, x, wx, h_prev, whh, *a_, **kw):
     return 'lstm_step_fwd_kernel', 2.0 * B * H4 * Kd, 4.0 * (H4 * Kd + 3 * B * H4)
 
 
-def _work_seq_fwd(pre, whh, *a_, **kw):
+def _work_seq_fwd(pre, whh, c_all, hbuf, y, valid, k0, k1, *a_, **kw):
     T, B, H4 = pre[0].shape
-    nd = len(pre)
-    return 'lstm_step_fwd_kernel', 2.0 * nd * B * H4 * (H4 // 4), 4.0 * nd * (H4 * (H4 // 4) + 3 * B * H4)
+    nd, n = len(pre), k1 - k0
+    return 'lstm_step_fwd_kernel', n * 2.0 * nd * B * H4 * (H4 // 4), n * 4.0 * nd * (H4 * (H4 // 4) + 3 * B * H4), n
 
 
 def _work_seq_bwd_prod(gates, whh, *a_, **kw):
@@ -655,10 +661,10 @@ def _work_seq_bwd_prod(gates, whh, *a_, **kw):
     return 'skinny_gemm_kernel', 2.0 * nd * B * H4 * (H4 // 4), 4.0 * nd * (H4 * (H4 // 4) + 2 * B * H4)
 
 
-def _work_seq_bwd_step(gates, whh, *a_, **kw):
+def _work_seq_bwd_step(gates, whh, c_all, dy, dgates, dhbuf, dcbuf, valid, k0, k1, *a_, **kw):
     T, B, H4 = gates[0].shape
-    nd = len(gates)
-    return 'lstm_step_bwd_kernel', 2.0 * nd * B * H4 * (H4 // 4), 4.0 * nd * (H4 * (H4 // 4) + 5.5 * B * H4)
+    nd, n = len(gates), k1 - k0
+    return 'lstm_step_bwd_kernel', n * 2.0 * nd * B * H4 * (H4 // 4), n * 4.0 * nd * (H4 * (H4 // 4) + 5.5 * B * H4), n
 
 
 def _work_seq_bwd_cell(gates, whh, *a_, **kw):
