@@ -518,6 +518,7 @@ extern "C" int ag_gemm(const float* A, int lda, int ta, const float* B, int ldb,
   }
   if (use128) {
     // LDS-DMA variant: whole 16-k tiles only, 16-byte aligned rows, row-contiguous operands with rows % 4 == 0
+    // (AG_GEMM_NODMA=1 in the environment forces the register-staged kernel: A/B switch for tools/prof_gemm.py)
     const bool dma = p.vecA && p.vecB && K % 16 == 0 && p.kchunk % 16 == 0 && (ta == 0 || M % 4 == 0) &&
                      (tb == 1 || N % 4 == 0) && M >= 4 && N >= 4 && getenv("AG_GEMM_NODMA") == nullptr;
     if (dma) return launch_gemm_dma(p, ta, tb, st);
