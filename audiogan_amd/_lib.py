@@ -32,7 +32,7 @@ class ConvArgs(C.Structure):
                 ('x_bs', i64), ('x_cs', i64), ('y_bs', i64), ('y_cs', i64), ('res_bs', i64),
                 ('res_cs', i64), ('B', i32), ('C', i32), ('Lin', i32), ('O', i32), ('Lout', i32),
                 ('K', i32), ('stride', i32), ('pad', i32), ('mode', i32), ('act', i32),
-                ('slope', f32), ('accumulate', i32)]
+                ('slope', f32), ('accumulate', i32), ('wp_pad', i32)]
 
 
 class OptDesc(C.Structure):
@@ -47,7 +47,7 @@ SIGNATURES = {
     'ag_weight_norm_fwd': (C.c_int, [vp, C.c_int, C.c_int, vp]),
     'ag_weight_norm_bwd': (C.c_int, [vp, C.c_int, C.c_int, vp]),
     'ag_conv1d_engine': (C.c_int, [C.POINTER(ConvArgs), vp]),
-    'ag_prep_conv_weight': (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    'ag_prep_conv_weight': (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     'ag_wpa_numel': (i64, [C.c_int, C.c_int, C.c_int]),
     'ag_wpb_numel': (i64, [C.c_int, C.c_int, C.c_int, C.c_int]),
     'ag_conv1d_wgrad': (C.c_int, [vp, i64, i64, vp, i64, i64, vp] + [C.c_int] * 8 + [vp]),

@@ -35,10 +35,10 @@ def grad_target(p):
 
 
 class Prepared(object):
-    __slots__ = ('w', 'wpa', 'wpb')
+    __slots__ = ('w', 'wpa', 'wpb', 'pad')
 
-    def __init__(self, w=None, wpa=None, wpb=None):
-        self.w, self.wpa, self.wpb = w, wpa, wpb
+    def __init__(self, w=None, wpa=None, wpb=None, pad=0):
+        self.w, self.wpa, self.wpb, self.pad = w, wpa, wpb, pad      # pad: what the scatter layout is prepared for
 
 
 class WNGroup(object):
@@ -51,8 +51,8 @@ class WNGroup(object):
         self._bufs = None
         self._key = None
 
-    def add(self, v, g, stride=1, engine=False):
-        self.items.append(dict(v=v, g=g, stride=stride, engine=engine))
+    def add(self, v, g, stride=1, engine=False, pad=0):
+        self.items.append(dict(v=v, g=g, stride=stride, engine=engine, pad=pad))
         return len(self.items) - 1
 
     def params(self):
@@ -65,7 +65,7 @@ class WNGroup(object):
         bufs = []
         for it in self.items:
             v = it['v']
-            p = Prepared(w=torch.empty_like(v.data))
+            p = Prepared(w=torch.empty_like(v.data), pad=it.get('pad', 0))
             if it['engine']:
                 d0, d1, kk = v.shape
                 p.wpa = torch.zeros(K.wpa_numel(d0, d1, kk), device=dev)
@@ -84,7 +84,7 @@ class WNGroup(object):
             ents = []
             for it, p in zip(self.items, self._bufs):
                 ents.append(dict(v=it['v'].data, g=it['g'].data.view(-1), w=p.w, wpa=p.wpa, wpb=p.wpb,
-                                 stride=it['stride']))
+                                 stride=it['stride'], pad=it.get('pad', 0)))
             K.weight_norm_fwd(ents)
             self._key = key
         return self._bufs

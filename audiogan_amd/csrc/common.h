@@ -54,6 +54,27 @@ __device__ __forceinline__ float ag_block_sum(float v, float* sh /* >= 17 floats
   return r;
 }
 
+// "Aligned" scatter layout of a strided conv's weight (mode 1 of the conv engine, conv_engine.hip).
+// Row (o, r) of the polyphase GEMM writes output position u = s*n + r - pad.  When pad % s != 0 the phases start at
+// different n (q_r = ceil((pad - r) / s)), the column range is L/s + 1 wide and the ragged last column used to cost
+// a second launch.  Storing phase r's taps one slot later by shift_r = ceil(pad/s) - q_r (0 or 1) lines all phases
+// up on the same columns.  It is free whenever no phase needs more than the ceil(K/s) slots that exist
+// (k7 s2 p3 - the critic's convs - does; k8 s4 p2 would need a third slot and keeps the plain layout).
+__host__ __device__ inline int ag_scatter_shift(int s, int pad, int r) {
+  const int qmax = (pad + s - 1) / s;
+  const int qr = pad > r ? (pad - r + s - 1) / s : 0;
+  return qmax - qr;
+}
+__host__ __device__ inline int ag_scatter_aligned(int K, int s, int pad) {
+  if (s <= 1 || pad % s == 0) return 0;
+  const int mt = (K + s - 1) / s;
+  for (int r = 0; r < s; ++r) {
+    const int taps_r = r < K ? (K - r + s - 1) / s : 0;
+    if (taps_r + ag_scatter_shift(s, pad, r) > mt) return 0;
+  }
+  return 1;
+}
+
 __device__ __forceinline__ float ag_apply_act(float v, int act, float slope) {
   if (act == AG_ACT_LEAKY) return v > 0.f ? v : v * slope;
   if (act == AG_ACT_TANH) return tanhf(v);

@@ -36,6 +36,7 @@ struct ConvP {
   int n_lo;       // first column index (0 for mode 0, pad/s for mode 1)
   int n_cnt;      // number of columns
   int xvec;       // input rows may be read with aligned 16-byte loads
+  int aligned;    // mode 1: aligned scatter layout (common.h) - phase r's outputs are shifted by -s * shift_r
   int tapoff[MAX_TAPS];
 };
 
@@ -353,7 +354,12 @@ __global__ __launch_bounds__(512) void conv_engine_kernel(const ConvP p) {
   // mode 1: row = o*s + r, output position u = s*n + r - pad.  A lane holds 4 consecutive rows in
   // registers 4g..4g+3, i.e. VW consecutive output positions of one channel -> vector stores.
   const int s = a.stride;
-  const int VW = (s % 4 == 0) ? 4 : ((s % 2 == 0) ? 2 : 1);
+  // Aligned layout (common.h): with rho = pad % s, phases r >= rho sit one column earlier, so the s rows of a channel
+  // are the contiguous window [s*(n-a-1), +s) ROTATED by rho (pad = s*a + rho).  s == 2 (the critic's convs): the
+  // two phases of a channel are a swapped pair -> still one 8-byte store; other strides: one row at a time.
+  const int rho = a.pad % s;
+  const int VW = p.aligned ? (s == 2 ? 2 : 1) : ((s % 4 == 0) ? 4 : ((s % 2 == 0) ? 2 : 1));
+  const bool swap2 = p.aligned && s == 2;
   // stride % 4 == 0 (the generator's transposed convs and the backward of its strided convs): the residual - or
   // for `accumulate` the old output - of a whole row tile is requested up front, one 16-byte load per group.
   // Inside the per-group branches below every such load is followed by its own wait: 16 dependent round trips
@@ -390,13 +396,17 @@ __global__ __launch_bounds__(512) void conv_engine_kernel(const ConvP p) {
           const int row = rowb + sub;
           if (row >= p.Mrows) break;
           const int o = row / s, r = row - o * s;
-          const int u0 = s * n + r - a.pad;
+          const int u0 = swap2 ? (2 * n - a.pad - 1)
+                               : (s * (n - ((p.aligned && r >= rho) ? 1 : 0)) + r - a.pad);
           const float bo = bias_s[row - row0];
           float* dst = yb + (int64_t)o * a.y_cs + u0;
           const float* rsrc = rb ? rb + (int64_t)o * a.res_cs + u0 : nullptr;
           float v[4];
           if (VW == 4) { v[0] = v4[0] + bo; v[1] = v4[1] + bo; v[2] = v4[2] + bo; v[3] = v4[3] + bo; }
-          else if (VW == 2) { v[0] = (sub ? v4[2] : v4[0]) + bo; v[1] = (sub ? v4[3] : v4[1]) + bo; v[2] = v[3] = 0.f; }
+          else if (VW == 2) {
+            const float e0 = sub ? v4[2] : v4[0], e1 = sub ? v4[3] : v4[1];      // phases 0, 1 of channel o
+            v[0] = (swap2 ? e1 : e0) + bo; v[1] = (swap2 ? e0 : e1) + bo; v[2] = v[3] = 0.f;
+          }
           else { v[0] = (sub == 0 ? v4[0] : sub == 1 ? v4[1] : sub == 2 ? v4[2] : v4[3]) + bo; v[1] = v[2] = v[3] = 0.f; }
           const bool full = u0 >= 0 && u0 + VW <= a.Lout;
           if (full && VW == 4) {
@@ -526,6 +536,7 @@ extern "C" int ag_conv1d_engine(const ag_conv_args* args, void* stream) {
   ConvP p;
   p.a = *args;
   const ag_conv_args& a = p.a;
+  p.aligned = 0;
   AG_REQUIRE(a.x && a.wp && a.y, "ag_conv1d_engine: null tensor");
   AG_REQUIRE(a.B > 0 && a.C > 0 && a.O > 0 && a.Lin > 0 && a.Lout > 0, "ag_conv1d_engine: bad shape");
   AG_REQUIRE(a.K > 0 && a.stride > 0 && a.pad >= 0, "ag_conv1d_engine: bad conv params");
@@ -543,9 +554,15 @@ extern "C" int ag_conv1d_engine(const ag_conv_args* args, void* stream) {
     p.taps = ag_cdiv(a.K, a.stride);
     p.sp = 1;
     p.Mrows = a.O * a.stride;
-    p.n_lo = a.pad / a.stride;
-    const int n_hi = (a.Lout - 1 + a.pad) / a.stride;
-    p.n_cnt = n_hi - p.n_lo + 1;
+    if (a.wp_pad == a.pad && ag_scatter_aligned(a.K, a.stride, a.pad)) {
+      p.aligned = 1;                              // every phase on columns m = 0 .. ceil(Lout/s) - 1
+      p.n_lo = ag_cdiv(a.pad, a.stride);
+      p.n_cnt = ag_cdiv(a.Lout, a.stride);
+    } else {
+      p.n_lo = a.pad / a.stride;
+      const int n_hi = (a.Lout - 1 + a.pad) / a.stride;
+      p.n_cnt = n_hi - p.n_lo + 1;
+    }
   }
   AG_REQUIRE(p.taps <= MAX_TAPS, "ag_conv1d_engine: more than %d taps", MAX_TAPS);
   p.sp_shift = ilog2_exact(p.sp);
@@ -591,7 +608,7 @@ extern "C" int ag_conv1d_engine(const ag_conv_args* args, void* stream) {
 // weight layouts for plain (not weight-normed) tensors
 // ------------------------------------------------------------------------------------------
 __global__ void prep_conv_weight_kernel(const float* __restrict__ w, float* __restrict__ wpa,
-                                        float* __restrict__ wpb, int d0, int d1, int K, int s) {
+                                        float* __restrict__ wpb, int d0, int d1, int K, int s, int pad) {
   const int d0p32 = (d0 + 31) / 32 * 32;
   const int d1p2 = (d1 + 1) / 2 * 2;
   const int64_t na = (int64_t)d1p2 * K * d0p32;
@@ -613,20 +630,21 @@ __global__ void prep_conv_weight_kernel(const float* __restrict__ w, float* __re
     const int m = (int)(am % mt);
     const int a0 = (int)(am / mt);
     const int o = row / s, r = row - o * s;
-    const int k = r + s * m;
-    wpb[i] = (a0 < d0 && o < d1 && k < K) ? w[((int64_t)a0 * d1 + o) * K + k] : 0.f;
+    const int mm = m - (ag_scatter_aligned(K, s, pad) ? ag_scatter_shift(s, pad, r) : 0);   // slot -> tap
+    const int k = r + s * mm;
+    wpb[i] = (a0 < d0 && o < d1 && mm >= 0 && k < K) ? w[((int64_t)a0 * d1 + o) * K + k] : 0.f;
   }
 }
 
 extern "C" int ag_prep_conv_weight(const float* w, float* wpa, float* wpb, int d0, int d1, int K,
-                                   int stride, void* stream) {
+                                   int stride, int pad, void* stream) {
   AG_REQUIRE(w && (wpa || wpb), "ag_prep_conv_weight: null tensor");
   AG_REQUIRE(d0 > 0 && d1 > 0 && K > 0 && stride > 0, "ag_prep_conv_weight: bad shape");
   int64_t n = 0;
   if (wpa) n = ag_wpa_numel(d0, d1, K);
   if (wpb && ag_wpb_numel(d0, d1, K, stride) > n) n = ag_wpb_numel(d0, d1, K, stride);
   hipLaunchKernelGGL(prep_conv_weight_kernel, dim3((unsigned)ag_cdiv64(n, 256)), dim3(256), 0,
-                     (hipStream_t)stream, w, wpa, wpb, d0, d1, K, stride);
+                     (hipStream_t)stream, w, wpa, wpb, d0, d1, K, stride, pad);
   AG_CHECK_LAUNCH("ag_prep_conv_weight");
   return AG_OK;
 }

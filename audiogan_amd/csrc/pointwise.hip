@@ -25,13 +25,16 @@ __global__ __launch_bounds__(256) void weight_norm_fwd_kernel(const ag_wn_desc* 
   const int s = d.stride > 0 ? d.stride : 1;
   const int mt = (d.K + s - 1) / s;
   const int mp = (d.d1 * s + 31) / 32 * 32;
+  const bool aligned = d.wpb && ag_scatter_aligned(d.K, s, d.pad);
   for (int i = lane; i < d.cols; i += 64) {
     const float w = v[i] * sc;
     if (d.w) d.w[(int64_t)r * d.cols + i] = w;
     if (d.wpa) d.wpa[(int64_t)i * d0p32 + r] = w;  // i = c*K + k
     if (d.wpb) {
       const int o = i / d.K, k = i - o * d.K;
-      const int m = k / s, rr = k - m * s;
+      int m = k / s;
+      const int rr = k - m * s;
+      if (aligned) m += ag_scatter_shift(s, d.pad, rr);
       d.wpb[((int64_t)r * mt + m) * mp + o * s + rr] = w;
     }
   }

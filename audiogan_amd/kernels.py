@@ -108,8 +108,9 @@ def reserve_table_arena():
 # weight norm
 # ------------------------------------------------------------------------------------
 def weight_norm_fwd(entries):
-    """entries: list of dict(v, g, w=None, wpa=None, wpb=None, stride=1).  v is the
-    parameter tensor ([d0], [d0,d1] or [d0,d1,K]); outputs are written in place."""
+    """entries: list of dict(v, g, w=None, wpa=None, wpb=None, stride=1, pad=0).  v is the
+    parameter tensor ([d0], [d0,d1] or [d0,d1,K]); outputs are written in place.  ``pad``: the conv padding the
+    scatter layout wpb is prepared for (aligned layout, see conv_engine's wp_pad)."""
     descs, max_rows = [], 1
     for e in entries:
         v, g = e['v'], e['g']
@@ -132,7 +133,7 @@ def weight_norm_fwd(entries):
             assert e['wpb'].numel() == wpb_numel(rows, d1, K, s)
         descs.append(_lib.WnDesc(v.data_ptr(), g.data_ptr(), _p(e.get('w')).value or 0,
                                  _p(e.get('wpa')).value or 0, _p(e.get('wpb')).value or 0, 0,
-                                 rows, cols, d1, K, s, 0))
+                                 rows, cols, d1, K, s, int(e.get('pad', 0))))
         max_rows = max(max_rows, rows)
     tab = _table('wn', descs, entries[0]['v'].device)
     check(lib.ag_weight_norm_fwd(_p(tab), len(descs), max_rows, _stream()), 'ag_weight_norm_fwd')
@@ -156,7 +157,7 @@ def weight_norm_bwd(entries):
     check(lib.ag_weight_norm_bwd(_p(tab), len(descs), max_rows, _stream()), 'ag_weight_norm_bwd')
 
 
-def prep_conv_weight(w, wpa, wpb, stride):
+def prep_conv_weight(w, wpa, wpb, stride, pad=0):
     _chk(w, 'w'); _chk(wpa, 'wpa'); _chk(wpb, 'wpb')
     assert w.dim() == 3 and w.is_contiguous()
     d0, d1, K = w.shape
@@ -164,7 +165,7 @@ def prep_conv_weight(w, wpa, wpb, stride):
         assert wpa.numel() == wpa_numel(d0, d1, K)
     if wpb is not None:
         assert wpb.numel() == wpb_numel(d0, d1, K, stride)
-    check(lib.ag_prep_conv_weight(_p(w), _p(wpa), _p(wpb), d0, d1, K, stride, _stream()),
+    check(lib.ag_prep_conv_weight(_p(w), _p(wpa), _p(wpb), d0, d1, K, stride, int(pad), _stream()),
           'ag_prep_conv_weight')
 
 
@@ -172,9 +173,9 @@ def prep_conv_weight(w, wpa, wpb, stride):
 # conv engine
 # ------------------------------------------------------------------------------------
 def conv_engine(x, wp, y, K, stride, pad, mode, bias=None, res=None, lens=None, act=ACT_NONE,
-                slope=LEAKY_SLOPE, accumulate=False):
+                slope=LEAKY_SLOPE, accumulate=False, wp_pad=0):
     """mode 0: y[b,o,t] = sum W x[b,c,s*t+k-p]   (wp = gather layout of the weight)
-    mode 1: y[b,o,s*t+k-p] += W x[b,c,t]        (wp = scatter layout)
+    mode 1: y[b,o,s*t+k-p] += W x[b,c,t]        (wp = scatter layout; wp_pad = the padding it was prepared for)
     x: [B,C,Lin] view, y: [B,O,Lout] view (written in place)."""
     x_bs, x_cs = _bcl(x, 'x')
     y_bs, y_cs = _bcl(y, 'y')
@@ -196,7 +197,7 @@ def conv_engine(x, wp, y, K, stride, pad, mode, bias=None, res=None, lens=None, 
         assert lens.numel() == B and lens.is_contiguous()
     a = _lib.ConvArgs(x.data_ptr(), wp.data_ptr(), _p(bias).value or 0, _p(res).value or 0,
                       y.data_ptr(), _p(lens).value or 0, x_bs, x_cs, y_bs, y_cs, r_bs, r_cs,
-                      B, Cc, Lin, O, Lout, K, stride, pad, mode, act, slope, 1 if accumulate else 0)
+                      B, Cc, Lin, O, Lout, K, stride, pad, mode, act, slope, 1 if accumulate else 0, int(wp_pad))
     check(lib.ag_conv1d_engine(C.byref(a), _stream()), 'ag_conv1d_engine')
 
 

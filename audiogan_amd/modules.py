@@ -157,7 +157,7 @@ class Generator(nn.Module):
         self._trunk = ops.GTrunk(bn, self.dense_res_gen[-1].module.spec)
         for m in self.dense_res_gen[:-1]:
             for layer in (m.module.conv, m.module.deconv):
-                _add(self._trunk.group, layer, 'weight', stride=layer.spec.stride, engine=True)
+                _add(self._trunk.group, layer, 'weight', stride=layer.spec.stride, engine=True, pad=layer.spec.pad)
                 _add(self._trunk.group, layer, 'bias')
         fin = self.dense_res_gen[-1].module
         _add(self._trunk.group, fin, 'weight', stride=1, engine=True)
@@ -226,7 +226,8 @@ class Discriminator(nn.Module):
 
         self._stack = ops.DConvStack([m.module.spec for m in self.cnn])
         for m in self.cnn:
-            _add(self._stack.group, m.module, 'weight', stride=m.module.spec.stride, engine=True)
+            _add(self._stack.group, m.module, 'weight', stride=m.module.spec.stride, engine=True,
+                 pad=m.module.spec.pad)
             _add(self._stack.group, m.module, 'bias')
         self._head = ops.DHead(2)
         for r in self.residual_net.module:

@@ -45,14 +45,14 @@ def conv_fwd(spec, prep, x, y, bias=None, res=None, lens=None, act=ACT_NONE):
     elif spec.kind == 'conv':
         K.conv_engine(x, prep.wpa, y, spec.K, spec.stride, spec.pad, 0, bias, res, lens, act)
     else:
-        K.conv_engine(x, prep.wpb, y, spec.K, spec.stride, spec.pad, 1, bias, res, lens, act)
+        K.conv_engine(x, prep.wpb, y, spec.K, spec.stride, spec.pad, 1, bias, res, lens, act, wp_pad=prep.pad)
 
 
 def conv_bwd_data(spec, prep, dy, dx, accumulate=False):
     if prep.w is not None and _o1(spec):
         K.conv_o1_bwd_data(dy, prep.w, dx, spec.K, spec.pad, accumulate)
     elif spec.kind == 'conv':
-        K.conv_engine(dy, prep.wpb, dx, spec.K, spec.stride, spec.pad, 1, accumulate=accumulate)
+        K.conv_engine(dy, prep.wpb, dx, spec.K, spec.stride, spec.pad, 1, accumulate=accumulate, wp_pad=prep.pad)
     else:
         K.conv_engine(dy, prep.wpa, dx, spec.K, spec.stride, spec.pad, 0, accumulate=accumulate)
 

@@ -59,7 +59,9 @@ typedef struct ag_wn_desc {
   int32_t d1;      /* second dim (1 for 2-D / 1-D tensors)              */
   int32_t K;       /* taps (1 for 2-D / 1-D tensors)                    */
   int32_t stride;  /* conv stride used for the wpb layout               */
-  int32_t pad_;
+  int32_t pad;     /* conv padding the wpb layout is prepared for: when pad % stride != 0 and it costs no tap slot,
+                    * phase r's taps sit ceil(pad/s) - ceil((pad-r)/s) slots later ("aligned" layout, see
+                    * ag_conv_args.wp_pad); 0 = plain layout */
 } ag_wn_desc;
 
 int ag_weight_norm_fwd(const ag_wn_desc* descs_dev, int n, int max_rows, void* stream);
@@ -108,12 +110,15 @@ typedef struct ag_conv_args {
   int32_t act;            /* AG_ACT_*                                  */
   float slope;
   int32_t accumulate;
+  int32_t wp_pad;         /* mode 1: the padding `wp` was prepared for (ag_wn_desc.pad / ag_prep_conv_weight's pad).
+                           * Equal to `pad` with pad % stride != 0: the aligned scatter layout is assumed and all
+                           * phases share one column range (no ragged last column); anything else: plain layout */
 } ag_conv_args;
 
 int ag_conv1d_engine(const ag_conv_args* args, void* stream);
 
 /* plain (non weight-normed) weights -> engine layouts; w is [d0][d1][K] */
-int ag_prep_conv_weight(const float* w, float* wpa, float* wpb, int d0, int d1, int K, int stride,
+int ag_prep_conv_weight(const float* w, float* wpa, float* wpb, int d0, int d1, int K, int stride, int pad,
                         void* stream);
 /* sizes (in floats) of the two layouts, so the host can allocate them */
 int64_t ag_wpa_numel(int d0, int d1, int K);

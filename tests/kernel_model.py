@@ -26,15 +26,36 @@ def wpb_numel(d0, d1, K, stride):
     return _r(d0, 2) * ((K + stride - 1) // stride) * _r(d1 * stride, 32)
 
 
-def _fill_layouts(w, wpa, wpb, stride):
+def _scatter_shift(s, pad, r):
+    qmax = (pad + s - 1) // s
+    qr = (pad - r + s - 1) // s if pad > r else 0
+    return qmax - qr
+
+
+def _scatter_aligned(K, s, pad):
+    """common.h ag_scatter_aligned: the aligned scatter layout applies (pad % s != 0 and no extra tap slot)"""
+    if s <= 1 or pad % s == 0:
+        return False
+    mt = (K + s - 1) // s
+    for r in range(s):
+        taps_r = (K - r + s - 1) // s if r < K else 0
+        if taps_r + _scatter_shift(s, pad, r) > mt:
+            return False
+    return True
+
+
+def _fill_layouts(w, wpa, wpb, stride, pad=0):
     d0, d1, K = w.shape
     if wpa is not None:
         wpa.view(_r(d1, 2), K, _r(d0, 32))[:d1, :, :d0] = w.permute(1, 2, 0)
     if wpb is not None:
         mt, mp = (K + stride - 1) // stride, _r(d1 * stride, 32)
         v = wpb.view(_r(d0, 2), mt, mp)
+        v.zero_()
+        al = _scatter_aligned(K, stride, pad)
         for k in range(K):
-            v[:d0, k // stride, torch.arange(d1) * stride + k % stride] = w[:, :, k]
+            m = k // stride + (_scatter_shift(stride, pad, k % stride) if al else 0)
+            v[:d0, m, torch.arange(d1) * stride + k % stride] = w[:, :, k]
 
 
 def weight_norm_fwd(entries):
@@ -46,7 +67,7 @@ def weight_norm_fwd(entries):
         if e.get('w') is not None:
             e['w'].copy_(w)
         if v.dim() == 3:
-            _fill_layouts(w, e.get('wpa'), e.get('wpb'), int(e.get('stride', 1)))
+            _fill_layouts(w, e.get('wpa'), e.get('wpb'), int(e.get('stride', 1)), int(e.get('pad', 0)))
 
 
 def weight_norm_bwd(entries):
@@ -65,8 +86,8 @@ def weight_norm_bwd(entries):
             e['dv'].copy_(dv_)
 
 
-def prep_conv_weight(w, wpa, wpb, stride):
-    _fill_layouts(w, wpa, wpb, stride)
+def prep_conv_weight(w, wpa, wpb, stride, pad=0):
+    _fill_layouts(w, wpa, wpb, stride, pad)
 
 
 def _act(v, act, slope):
@@ -84,7 +105,7 @@ def _fit(t, n):
 
 
 def conv_engine(x, wp, y, K, stride, pad, mode, bias=None, res=None, lens=None, act=ACT_NONE,
-                slope=LEAKY_SLOPE, accumulate=False):
+                slope=LEAKY_SLOPE, accumulate=False, wp_pad=0):
     B, C, Lin = x.shape
     _, O, Lout = y.shape
     if mode == 0:
@@ -95,7 +116,9 @@ def conv_engine(x, wp, y, K, stride, pad, mode, bias=None, res=None, lens=None, 
         assert wp.numel() == wpb_numel(C, O, K, stride)
         mt, mp = (K + stride - 1) // stride, _r(O * stride, 32)
         v = wp.view(_r(C, 2), mt, mp)
-        w = torch.stack([v[:C, k // stride, torch.arange(O) * stride + k % stride] for k in range(K)], 2)
+        al = wp_pad == pad and _scatter_aligned(K, stride, pad)
+        w = torch.stack([v[:C, k // stride + (_scatter_shift(stride, pad, k % stride) if al else 0),
+                           torch.arange(O) * stride + k % stride] for k in range(K)], 2)
         full = F.conv_transpose1d(x, w, None, stride, 0)                    # w: [C,O,K]; u + pad
         out = _fit(full[:, :, pad:], Lout)
     if bias is not None:

@@ -93,6 +93,22 @@ def test_conv_forward_backward_data(K, layer):
     dx = torch.full((B, cin, lin), float('nan')).cuda()
     K.conv_engine(dev(gy), bwd_wp, dx, k, s, p, 1 - fwd_mode)
     close(dx, xr.grad, msg='backward-data')
+    # the scatter layout prepared FOR this padding (aligned phases, one column range): same results
+    wpb2 = torch.zeros(wpb.numel()).cuda()
+    K.prep_conv_weight(dev(w), None, wpb2, s, pad=p)
+    rb2 = torch.zeros(wpb.numel())
+    KM.prep_conv_weight(w, None, rb2, s, pad=p)
+    close(wpb2, rb2, rtol=0, atol=0)
+    if kind == 'conv':
+        dx2 = dev(torch.randn(B, cin, lin, generator=gen))
+        base = dx2.clone()
+        K.conv_engine(dev(gy), wpb2, dx2, k, s, p, 1, accumulate=True, wp_pad=p)
+        close(dx2 - base, xr.grad, msg='backward-data, aligned layout', rtol=2e-3)
+    else:
+        y3 = torch.full((B, cout, lout), float('nan')).cuda()
+        K.conv_engine(dev(x), wpb2, y3, k, s, p, 1, bias=dev(bias), res=dev(res), lens=dev(lens), act=K.ACT_LEAKY,
+                      wp_pad=p)
+        close(y3, ref, msg='forward, aligned layout')
 
 
 @pytest.mark.parametrize('layer', G_LAYERS + D_LAYERS + EDGE_LAYERS)

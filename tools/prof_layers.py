@@ -45,11 +45,11 @@ for name, kind, cin, cout, k, s, p, lin in LAYERS:
         w = torch.randn((cout, cin, k) if kind == 'conv' else (cin, cout, k), device='cuda') / (cin * k) ** 0.5
         d0, d1, _ = w.shape
         wpa, wpb = torch.zeros(K.wpa_numel(d0, d1, k), device='cuda'), torch.zeros(K.wpb_numel(d0, d1, k, s), device='cuda')
-        K.prep_conv_weight(w, wpa, wpb, s)
+        K.prep_conv_weight(w, wpa, wpb, s, pad=p)        # scatter layout prepared for this padding, as ops.py does
         dx, dw = torch.empty_like(x), torch.zeros_like(w)
         mode = 0 if kind == 'conv' else 1
-        runs = [('fwd', lambda: K.conv_engine(x, wpa if mode == 0 else wpb, y, k, s, p, mode)),
-                ('bwd-x', lambda: K.conv_engine(y, wpb if mode == 0 else wpa, dx, k, s, p, 1 - mode)),
+        runs = [('fwd', lambda: K.conv_engine(x, wpa if mode == 0 else wpb, y, k, s, p, mode, wp_pad=p)),
+                ('bwd-x', lambda: K.conv_engine(y, wpb if mode == 0 else wpa, dx, k, s, p, 1 - mode, wp_pad=p)),
                 ('bwd-w', (lambda: K.conv_wgrad(y, x, dw, k, s, p)) if kind == 'conv' else (lambda: K.conv_wgrad(x, y, dw, k, s, p)))]
     for pname, fn in runs:
         if name == 'D1' and pname == 'bwd-x':
