@@ -151,6 +151,39 @@ def test_stopper_surrogate_trains_only_the_stop_head():
         assert p.requires_grad
 
 
+def test_lstm_layer_with_time_invariant_input_matches_torch_lstm():
+    """LSTMSeqFn's static input (projected once per clip, added inside the step kernel) must equal torch.nn.LSTM on
+    cat([x_t, c]) for the output AND for every gradient: x, c (the conditioning embedding trains through it), weights
+    (both column blocks of weight_ih), biases - ragged lengths included"""
+    from audiogan_amd import ops
+    torch.manual_seed(6)
+    T, B, Fx, Fc, H = 5, 4, 8, 3, 16
+    ref = torch.nn.LSTM(Fx + Fc, H, bidirectional=True)
+    x = torch.randn(T, B, Fx, requires_grad=True)
+    c = torch.randn(B, Fc, requires_grad=True)
+    lens = torch.tensor([5, 3, 5, 2])
+    w = []
+    for sfx in ('', '_reverse'):
+        for n in ('weight_ih', 'weight_hh', 'bias_ih', 'bias_hh'):
+            w.append(getattr(ref, '%s_l0%s' % (n, sfx)).detach().clone().requires_grad_(True))
+    y = ops.LSTMSeqFn.apply(x, lens, 2, c, *w)
+    xin = torch.cat([x.detach(), c.detach().unsqueeze(0).expand(T, B, Fc)], 2).requires_grad_(True)
+    packed = torch.nn.utils.rnn.pack_padded_sequence(xin, lens, enforce_sorted=False)
+    yo, _ = torch.nn.utils.rnn.pad_packed_sequence(ref(packed)[0], total_length=T)
+    np.testing.assert_allclose(y.detach().numpy(), yo.detach().numpy(), rtol=1e-4, atol=1e-5)
+    gy = torch.randn(T, B, 2 * H)
+    (y * gy).sum().backward()
+    (yo * gy).sum().backward()
+    np.testing.assert_allclose(x.grad.numpy(), xin.grad[:, :, :Fx].numpy(), rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(c.grad.numpy(), xin.grad[:, :, Fx:].sum(0).numpy(), rtol=1e-3, atol=1e-5)
+    i = 0
+    for sfx in ('', '_reverse'):
+        for n in ('weight_ih', 'weight_hh', 'bias_ih', 'bias_hh'):
+            np.testing.assert_allclose(w[i].grad.numpy(), getattr(ref, '%s_l0%s' % (n, sfx)).grad.numpy(),
+                                       rtol=1e-3, atol=1e-5, err_msg=n + sfx)
+            i += 1
+
+
 def _tiny_pair():
     torch.manual_seed(11)
     go = O.Generator(16, 6, 5, 24, 1, struct=[[9, 4, 8, 4], [9, 4, 8, 4]])
