@@ -187,12 +187,64 @@ __global__ __launch_bounds__(1024) void skinny_gemm_kernel(const SkinnyP p) {
   }
 }
 
+// 16 x 16 output tiles (v_mfma_f32_16x16x4_f32), both operands k-contiguous, 16 waves splitting K, every load
+// of a wave requested before its first MFMA, direct (bias + activation) epilogue.  For products whose 32-wide
+// tiling leaves most CUs idle and that sit on a sequential critical path: the Generator front's projection
+// x_t = tanh(h_t W_p^T + b) is 64 x 256 x 1024 - 16 workgroups as 32x32 tiles, 64 as 16x16.
+__global__ __launch_bounds__(1024) void skinny16_nt_kernel(const SkinnyP p) {
+  __shared__ float red[16 * 256];
+  const SkinnyOne& Q = p.q[0];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 16;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const int KU = p.K >> 4;
+  const int u0 = KU * wid / 16, u1 = KU * (wid + 1) / 16;
+  const float* ar = Q.A + (int64_t)min(m0 + li, p.M - 1) * p.lda + 4 * g;
+  const float* br = Q.B + (int64_t)min(n0 + li, p.N - 1) * p.ldb + 4 * g;
+  for (int ub = u0; ub < u1; ub += 4) {
+    f32x4 a[4], b[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int u = min(ub + i, u1 - 1);
+      a[i] = *reinterpret_cast<const f32x4*>(ar + 16 * u);
+      b[i] = *reinterpret_cast<const f32x4*>(br + 16 * u);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (ub + i < u1) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][e], b[i][e], acc, 0, 0, 0);
+      }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) red[wid * 256 + (4 * g + e) * 16 + li] = acc[e];     // row 4g+e, col li
+  __syncthreads();
+  if (threadIdx.x >= 256) return;
+  const int m = m0 + (threadIdx.x >> 4), n = n0 + (threadIdx.x & 15);
+  if (m >= p.M || n >= p.N) return;
+  float v = 0.f;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) v += red[w * 256 + threadIdx.x];
+  float* dst = Q.C + (int64_t)m * p.ldc + n;
+  if (p.beta != 0.f) v += p.beta * *dst;
+  if (Q.bias) v += Q.bias[n];
+  *dst = ag_apply_act(v, p.act, p.slope);
+}
+
 static int launch_skinny(SkinnyP& p, int nprob, int accumulate_atomic, hipStream_t st) {
   const int gx = ag_cdiv(p.N, 32);
   const int KU = p.K / 8;
   p.mtiles = ag_cdiv(p.M, 32);
   const int gz = nprob * p.mtiles;
   int nw, gy;
+  // few 32-wide tiles, direct epilogue, both operands k-contiguous: 16x16 tiles put 4x as many CUs on it
+  if (!accumulate_atomic && nprob == 1 && p.tb && p.K % 16 == 0 && p.K >= 256 && gx * gz < 64 &&
+      (int64_t)ag_cdiv(p.N, 16) * ag_cdiv(p.M, 16) <= 1024) {
+    hipLaunchKernelGGL(skinny16_nt_kernel, dim3(ag_cdiv(p.N, 16), ag_cdiv(p.M, 16)), dim3(1024), 0, st, p);
+    AG_CHECK_LAUNCH("ag_skinny_gemm");
+    return AG_OK;
+  }
   if (accumulate_atomic) {
     // C already holds the value to add to; spread K over ~1024 waves on the chip
     nw = 4;

@@ -326,7 +326,7 @@ def test_error_convention(K):
 
 
 @pytest.mark.parametrize('shape', [(64, 2048, 512), (64, 512, 2048), (64, 256, 1024), (64, 1024, 4096), (128, 512, 2048),
-                                   (3, 40, 24), (33, 7, 8), (64, 4096, 256)])
+                                   (3, 40, 24), (33, 7, 8), (64, 4096, 256), (40, 100, 512)])
 @pytest.mark.parametrize('tb', [True, False])
 def test_skinny_gemm(K, shape, tb):
     M, N, Kd = shape
