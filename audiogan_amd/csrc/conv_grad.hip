@@ -482,7 +482,8 @@ __global__ __launch_bounds__(256) void conv_o1_fwd_kernel(const float* __restric
 #pragma unroll
     for (int i = 0; i < 4 + O1_MAXK - 1; ++i) {
       const int g = t0 + i - p;
-      win[i] = (i < 4 + K - 1 && g >= 0 && g < L) ? xc[g] : 0.f;
+      const float v = (i < 4 + K - 1) ? xc[min(max(g, 0), L - 1)] : 0.f;      // unconditional load, then select
+      win[i] = (g >= 0 && g < L) ? v : 0.f;
     }
 #pragma unroll
     for (int k = 0; k < O1_MAXK; ++k) {
@@ -511,7 +512,8 @@ __global__ __launch_bounds__(256) void conv_o1_bwdx_kernel(const float* __restri
 #pragma unroll
   for (int i = 0; i < 4 + O1_MAXK - 1; ++i) {
     const int g = t0 + p - (K - 1) + i;
-    win[i] = (i < 4 + K - 1 && g >= 0 && g < L) ? dyb[g] : 0.f;
+    const float v = (i < 4 + K - 1) ? dyb[min(max(g, 0), L - 1)] : 0.f;        // unconditional load, then select
+    win[i] = (g >= 0 && g < L) ? v : 0.f;
   }
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
