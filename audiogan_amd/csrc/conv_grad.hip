@@ -267,7 +267,10 @@ static int launch_wgrad(WgP& p, hipStream_t st) {
   }
   const int gx = ag_cdiv(p.CK, NT), gy = ag_cdiv(p.A, AT);
   const int total = p.B * p.nchunk;
-  int gz = ag_cdiv(1024, gx * gy);  // ~4 workgroups of 8 waves per CU over the whole grid
+  // ~2 workgroups of 8 waves per CU over the whole grid: every workgroup ends in a full tile of atomics, so more
+  // splits cost more than their shorter chunk loops save (measured over the 15 layers: 256 / 512 / 1024 / 2048
+  // workgroups -> 1510 / 1218 / 1307 / 1522 us in total)
+  int gz = ag_cdiv(512, gx * gy);
   if (gz > total) gz = total;
   if (gz < 1) gz = 1;
   auto kern = conv_wgrad_kernel<TA, TN, WA, WN>;
