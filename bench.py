@@ -161,7 +161,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--force-phases', action='store_true',
-                    help='use the multi-GPU code path (gradient buckets + 4 graphs per step) on one GPU')
+                    help='use the multi-GPU code path (gradient buckets + 5 graphs per step) on one GPU')
     ap.add_argument('--no-overlap', action='store_true',
                     help='keep the G forward of the generator iteration on the main stream (default: on a second '
                          'stream beside the critic iteration; single-GPU graph only)')
@@ -228,7 +228,7 @@ def main():
             disc = K.Profiler.stop()
             dominant = max(disc.items(), key=lambda kv: kv[1]['ms'])[0]
     # ---- hipGraph capture: ~3000 launches per step would otherwise be paced by the Python
-    # interpreter, not by the GPU.  One GPU: the whole G+D step is ONE graph.  N GPUs: four graphs
+    # interpreter, not by the GPU.  One GPU: the whole G+D step is ONE graph.  N GPUs: five graphs
     # (critic fwd+bwd | opt_d | generator fwd+bwd | opt_g) with the two RCCL gradient all-reduces
     # as ordinary stream operations between them.
     graph = None
