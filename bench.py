@@ -227,10 +227,10 @@ def main():
         if prof:
             disc = K.Profiler.stop()
             dominant = max(disc.items(), key=lambda kv: kv[1]['ms'])[0]
-    # ---- hipGraph capture: ~3000 launches per step would otherwise be paced by the Python
+    # ---- hipGraph capture: ~1000 launches per step would otherwise be paced by the Python
     # interpreter, not by the GPU.  One GPU: the whole G+D step is ONE graph.  N GPUs: five graphs
-    # (critic fwd+bwd | opt_d | generator fwd+bwd | opt_g) with the two RCCL gradient all-reduces
-    # as ordinary stream operations between them.
+    # (critic fwd + head/biLSTM bwd | critic conv-stack bwd | opt_d | generator fwd+bwd | opt_g) with the RCCL
+    # gradient all-reduces as ordinary stream operations between them.
     graph = None
     phases = None
     capture_error = None
