@@ -34,6 +34,28 @@ def grad_target(p):
     return g
 
 
+class frozen(object):
+    """context manager: parameters of the given modules (or iterables of parameters) get requires_grad False inside
+    the block and their old flag back afterwards.  A block's ``needs_input_grad`` is fixed when its forward runs, so
+    a forward inside this context computes NO weight gradient in its backward and leaves ``.grad`` untouched
+    (audiogan.py:897-901 freezes the same way around the stopper's REINFORCE backward)."""
+
+    def __init__(self, *modules):
+        self.params = []
+        for m in modules:
+            self.params += list(m.parameters()) if hasattr(m, 'parameters') else list(m)
+
+    def __enter__(self):
+        self.flags = [p.requires_grad for p in self.params]
+        for p in self.params:
+            p.requires_grad_(False)
+        return self
+
+    def __exit__(self, *exc):
+        for p, r in zip(self.params, self.flags):
+            p.requires_grad_(r)
+
+
 class Prepared(object):
     __slots__ = ('w', 'wpa', 'wpb', 'pad')
 

@@ -12,6 +12,7 @@ activation (ag_time_moments_fwd/bwd), their batch means / stds tiny reductions o
 import torch
 
 from . import kernels as K
+from .common import frozen
 from .losses import binary_cross_entropy_with_logits_per_sample, length_mask  # noqa: F401
 
 
@@ -68,9 +69,12 @@ def feature_penalty(dists_d, dists_g, batch_size):
 
 def _input_grad_sign(d, data, data_len, embed_d, target, nframes_hint=None):
     data = data.detach().requires_grad_(True)
-    cls, _, _, nframes = d(data, data_len, embed_d)
-    loss = binary_cross_entropy_with_logits_per_sample(cls, target, nframes=nframes) / nframes.float()
-    grad, = torch.autograd.grad(loss.sum(), data)
+    # only d(loss)/d(input) is wanted: with D's parameters frozen the blocks compute no weight gradient and do not
+    # touch ``.grad`` (which may be the flat all-reduce bucket holding this iteration's gradients)
+    with frozen(d):
+        cls, _, _, nframes = d(data, data_len, embed_d)
+        loss = binary_cross_entropy_with_logits_per_sample(cls, target, nframes=nframes) / nframes.float()
+        grad, = torch.autograd.grad(loss.sum(), data)
     return grad
 
 
@@ -89,12 +93,13 @@ def adversarially_sample_z(g, d, batch_size, nframes, noise_size, maxlen, embed_
     dev = embed_g.device
     z = torch.randn(batch_size, nframes, noise_size, device=dev) if z is None else z
     z = z.detach().requires_grad_(True)
-    fake, _, _, fake_len = g(batch_size=batch_size, length=maxlen, c=embed_g, z=z, stop=stop)
-    if noise is None:
-        noise = torch.randn_like(fake) * noisescale
-    cls_g, _, _, nframes_g = d(fake + noise, fake_len, embed_d)
-    target = 0.5 if g_optim == 'boundary_seeking' else 0.0
-    loss = binary_cross_entropy_with_logits_per_sample(cls_g, target, nframes=nframes_g) / nframes_g.float()
-    grad, = torch.autograd.grad(loss.sum(), z)
+    with frozen(g, d):          # input gradient only: no weight gradients, ``.grad`` of G and D untouched
+        fake, _, _, fake_len = g(batch_size=batch_size, length=maxlen, c=embed_g, z=z, stop=stop)
+        if noise is None:
+            noise = torch.randn_like(fake) * noisescale
+        cls_g, _, _, nframes_g = d(fake + noise, fake_len, embed_d)
+        target = 0.5 if g_optim == 'boundary_seeking' else 0.0
+        loss = binary_cross_entropy_with_logits_per_sample(cls_g, target, nframes=nframes_g) / nframes_g.float()
+        grad, = torch.autograd.grad(loss.sum(), z)
     advers = (grad > 1e-9).float() * scale - (grad < -1e-9).float() * scale
     return (z + advers).detach()

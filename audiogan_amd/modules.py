@@ -166,7 +166,25 @@ class Generator(nn.Module):
     def _front_apply(self, zc):
         return ops.GFrontFn.apply(zc, self._front, *self._front.group.params())
 
-    def forward(self, batch_size=None, length=None, z=None, c=None, stop=None):
+    def prepare_weights(self):
+        """materialise the weight-normed weights of every block NOW, on the current stream (no-op when the
+        parameters have not changed since the last materialisation).  A caller that runs two forwards of this
+        module on two streams calls it before the fork: otherwise the first forward to be ENQUEUED would rewrite
+        the shared weight buffers on its stream while the other stream's forward (which finds the cache key
+        up to date and skips the rewrite) reads them unordered."""
+        self._front.group.prepare()
+        self._trunk.group.prepare()
+
+    def early_params(self):
+        """parameters whose gradients are complete BEFORE the recurrent front's backward runs (the conv trunk,
+        which the backward pass reaches first): their all-reduce can overlap the front's frame loop"""
+        return [p for m in self.dense_res_gen for p in m.parameters()]
+
+    def forward(self, batch_size=None, length=None, z=None, c=None, stop=None, cut=None):
+        """``cut``: optional dict.  When given, the autograd graph is cut between the recurrent front and the conv
+        trunk: the trunk runs on a detached copy of the front's frames (``cut['x_cut']``, a leaf that collects the
+        trunk's input gradient) and ``cut['x']`` keeps the front's output, so that the caller can run the front's
+        backward later with ``cut['x'].backward(cut['x_cut'].grad)`` (train.g_backward_early / _late)."""
         fs, ns, es = self._frame_size, self._noise_size, self._embed_size
         dev = c.device
         if z is None:
@@ -197,6 +215,9 @@ class Generator(nn.Module):
             x, s = x[:, :t_eff * fs], s[:, :t_eff]
         stop_list = ([stops[:, t:t + 1] for t in range(t_eff)] if stops is not None else
                      list(torch.zeros(t_eff, batch_size, 1, dtype=torch.long, device=dev).unbind(0)))
+        if cut is not None:
+            cut['x'] = x
+            x = cut['x_cut'] = x.detach().requires_grad_(True)
         wave = ops.GTrunkFn.apply(x, self._trunk, *self._trunk.group.params())
         return wave, s, stop_list, out_len
 

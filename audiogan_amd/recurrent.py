@@ -256,8 +256,9 @@ class GFrontFn(torch.autograd.Function):
         dha = [torch.zeros(T, B, S, device=dev) for _ in range(nl)]
         if ds is not None:
             ds_tb = ds.t().contiguous().view(T * B, 1)
-            K.gemm(ds_tb, hs[-1].view(T * B, S), dws[4 * nl + 2], ta=True)
-            K.col_sum(ds_tb, dws[4 * nl + 3])
+            if dws is not None:
+                K.gemm(ds_tb, hs[-1].view(T * B, S), dws[4 * nl + 2], ta=True)
+                K.col_sum(ds_tb, dws[4 * nl + 3])
             K.gemm(ds_tb, sw, dha[-1].view(T * B, S))
         dgs = [torch.empty(T, B, 4 * S, device=dev) for _ in range(nl)]
         dxt = torch.empty(T, B, fs, device=dev)      # d(pre-tanh) of the projection, per frame
@@ -288,8 +289,9 @@ class GFrontFn(torch.autograd.Function):
             dacc[:, :, S:].copy_(dx.contiguous().view(B, T, fs).transpose(0, 1))
         if ds is not None:
             ds_tb = ds.t().contiguous().view(T * B, 1)
-            K.gemm(ds_tb, hs.view(T * B, S), dws[4 * nl + 2], ta=True)
-            K.col_sum(ds_tb, dws[4 * nl + 3])
+            if dws is not None:
+                K.gemm(ds_tb, hs.view(T * B, S), dws[4 * nl + 2], ta=True)
+                K.col_sum(ds_tb, dws[4 * nl + 3])
             K.gemm(ds_tb, sw, dacc.view(T * B, S + fs)[:, :S])
         wcat = torch.cat([w_hh, wx], 1)                # [4S, S+fs]
         dgs = torch.empty(T, B, 4 * S, device=dev)
@@ -316,7 +318,10 @@ class GFrontFn(torch.autograd.Function):
         lw = [[p.w for p in prep[4 * l:4 * l + 4]] for l in range(nl)]
         pw, sw = prep[4 * nl].w, prep[4 * nl + 2].w
         wx = lw[0][0][:, :fs]
-        dws = _zeros_like_list([it['v'] for it in front.group.items])
+        # no parameter of the block needs a gradient (FGSM-style input-gradient passes): skip every weight-gradient
+        # product and leave ``.grad`` untouched
+        wg = any(ctx.needs_input_grad[2:])
+        dws = _zeros_like_list([it['v'] for it in front.group.items]) if wg else None
         fused = (nl == 1 and T > 0 and (S + fs) % 4 == 0
                  and K.lstm_front_bwd_ok(B, S, fs, x[:, :fs], x[:, :fs]) and K.skinny_ok(gates[0][0], lw[0][1], False))
         if fused:
@@ -326,9 +331,10 @@ class GFrontFn(torch.autograd.Function):
             dgs, dxt = GFrontFn._bwd_frames(T, B, fs, S, nl, x, dx, ds, gates, cs, lw, wx, pw, sw, hs, dws)
         # parameter gradients, one GEMM per tensor over all frames
         dxt2 = dxt.view(T * B, fs)
-        K.gemm(dxt2, hs[-1].view(T * B, S), dws[4 * nl], ta=True)
-        K.col_sum(dxt2, dws[4 * nl + 1])
-        for l in range(nl):
+        if wg:
+            K.gemm(dxt2, hs[-1].view(T * B, S), dws[4 * nl], ta=True)
+            K.col_sum(dxt2, dws[4 * nl + 1])
+        for l in range(nl if wg else 0):
             dg2 = dgs[l].view(T * B, 4 * S)
             dwih = dws[4 * l]
             if l == 0:
@@ -348,7 +354,7 @@ class GFrontFn(torch.autograd.Function):
             dzc = torch.empty(T * B, Fz, device=dev)
             K.gemm(dgs[0].view(T * B, 4 * S), lw[0][0][:, fs:], dzc)
             dzc = dzc.view(T, B, Fz)
-        grads = front.group.backward(dws)
+        grads = front.group.backward(dws) if wg else [None] * (2 * len(front.group.items))
         return (dzc, None) + tuple(grads)
 
 
@@ -405,13 +411,15 @@ class GRUFrontFn(torch.autograd.Function):
         wx = w_ih[:, :fs]
         zc, x, gi, gh, hs = ctx.saved_tensors
         dev = zc.device
-        dws = _zeros_like_list([it['v'] for it in front.group.items])
+        wg = any(ctx.needs_input_grad[2:])
+        dws = _zeros_like_list([it['v'] for it in front.group.items]) if wg else None
         dxa = dx.contiguous().clone() if dx is not None else torch.zeros(B, T * fs, device=dev)
         dha = torch.zeros(T + 1, B, S, device=dev)     # dha[t+1] accumulates dL/dh_t
         if ds is not None:
             ds_tb = ds.t().contiguous().view(T * B, 1)
-            K.gemm(ds_tb, hs[1:].view(T * B, S), dws[6], ta=True)
-            K.col_sum(ds_tb, dws[7])
+            if wg:
+                K.gemm(ds_tb, hs[1:].view(T * B, S), dws[6], ta=True)
+                K.col_sum(ds_tb, dws[7])
             K.gemm(ds_tb, sw, dha[1:].view(T * B, S))
         dgi = torch.empty(T, B, 3 * S, device=dev)
         dgh = torch.empty(T, B, 3 * S, device=dev)
@@ -427,18 +435,19 @@ class GRUFrontFn(torch.autograd.Function):
             if t > 0:
                 _small_acc(dgi[t], wx, dxa[:, (t - 1) * fs:t * fs])
         dxt2, dgi2, dgh2 = dxt.view(T * B, fs), dgi.view(T * B, 3 * S), dgh.view(T * B, 3 * S)
-        K.gemm(dxt2, hs[1:].view(T * B, S), dws[4], ta=True)
-        K.col_sum(dxt2, dws[5])
-        K.gemm(dgi2, zc.contiguous().view(T * B, Fz), dws[0][:, fs:], ta=True)
-        if T > 1:
-            xprev = x.view(B, T, fs)[:, :T - 1].transpose(0, 1).contiguous().view((T - 1) * B, fs)
-            K.gemm(dgi[1:].view((T - 1) * B, 3 * S), xprev, dws[0][:, :fs], ta=True)
-        K.gemm(dgh2, hs[:T].view(T * B, S), dws[1], ta=True)
-        K.col_sum(dgi2, dws[2])
-        K.col_sum(dgh2, dws[3])
+        if wg:
+            K.gemm(dxt2, hs[1:].view(T * B, S), dws[4], ta=True)
+            K.col_sum(dxt2, dws[5])
+            K.gemm(dgi2, zc.contiguous().view(T * B, Fz), dws[0][:, fs:], ta=True)
+            if T > 1:
+                xprev = x.view(B, T, fs)[:, :T - 1].transpose(0, 1).contiguous().view((T - 1) * B, fs)
+                K.gemm(dgi[1:].view((T - 1) * B, 3 * S), xprev, dws[0][:, :fs], ta=True)
+            K.gemm(dgh2, hs[:T].view(T * B, S), dws[1], ta=True)
+            K.col_sum(dgi2, dws[2])
+            K.col_sum(dgh2, dws[3])
         dzc = None
         if ctx.needs_input_grad[0]:
             dzc = torch.empty(T * B, Fz, device=dev)
             K.gemm(dgi2, w_ih[:, fs:], dzc)
             dzc = dzc.view(T, B, Fz)
-        return (dzc, None) + tuple(front.group.backward(dws))
+        return (dzc, None) + tuple(front.group.backward(dws) if wg else [None] * (2 * len(front.group.items)))

@@ -3,7 +3,37 @@
 numbers can be fed to the CPU oracle."""
 import torch
 
+from .common import frozen
 from .losses import masked_bce_mean
+
+_SIDE = {}
+
+
+def gd_step(g, d, opt_g, opt_d, real, real_len, c, z, noise_real, noise_fake, dgradclip=1.0, ggradclip=0.1,
+            overlap=True, hook_d=None, hook_g=None, check=False):
+    """critic iteration + generator iteration (the canonical step).  ``overlap``: the generator iteration's G forward
+    depends on neither D nor the critic iteration, so it is enqueued on a second stream beside the critic iteration
+    (one fork, one join; a parallel branch when the step is captured into a hipGraph): its latency-bound frame loop
+    then shares the GPU with the critic's equally latency-bound biLSTM chains.  Same work, same results: G's
+    weight-normed weights are materialised on the main stream BEFORE the fork, so neither branch rewrites a buffer
+    the other one reads.  Returns (loss_d, loss_g)."""
+    pre = None
+    if overlap and real.is_cuda:
+        dev = real.device
+        side = _SIDE.get(dev)
+        if side is None:
+            side = _SIDE[dev] = torch.cuda.Stream(device=dev)
+        g.prepare_weights()
+        main = torch.cuda.current_stream()
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            pre = g(z=z, c=c, stop='never')
+    loss_d = d_step(g, d, opt_d, real, real_len, c, z, noise_real, noise_fake, dgradclip, grad_hook=hook_d,
+                    check=check)[0]
+    if pre is not None:
+        torch.cuda.current_stream().wait_stream(side)
+    loss_g = g_step(g, d, opt_g, c, z, noise_fake, ggradclip, grad_hook=hook_g, check=check, pre=pre)[0]
+    return loss_d, loss_g
 
 
 def d_step(g, d, opt_d, real, real_len, c, z, noise_real, noise_fake, dgradclip=1.0, stop='never',
@@ -39,19 +69,13 @@ def g_step(g, d, opt_g, c, z, noise_fake, ggradclip=0.1, g_optim='boundary_seeki
     902-903, 909-921).  ``pre``: the result of ``g(z=z, c=c, stop=stop)`` when the caller has already run the
     generator's forward (it does not involve D, so it may be enqueued on a second stream beside the critic
     iteration - bench.py does that)."""
-    flags = [p.requires_grad for p in d.parameters()]
-    for p in d.parameters():
-        p.requires_grad_(False)
-    try:
+    with frozen(d):
         fake, _, _, fake_len = pre if pre is not None else g(z=z, c=c, stop=stop)
         cls_g, _, _, nf_g = d(fake + noise_fake, fake_len, c)
         tgt = 0.5 if g_optim == 'boundary_seeking' else 0.0
         loss, _ = masked_bce_mean(cls_g, tgt, nf_g)
         opt_g.zero_grad()
         loss.backward()
-    finally:
-        for p, r in zip(d.parameters(), flags):
-            p.requires_grad_(r)
     scale = grad_hook() if grad_hook is not None else 1.0
     opt_g.step(clip_norm=ggradclip, grad_scale=scale, check=check)
     return loss.detach(), fake.detach(), cls_g.detach()
@@ -87,18 +111,12 @@ def d_backward(g, d, opt_d, real, real_len, c, z, noise_real, noise_fake, stop='
 def g_backward(g, d, opt_g, c, z, noise_fake, g_optim='boundary_seeking', stop='never', pre=None):
     """forward + backward of the generator iteration (through D, whose weights get no gradient);
     ``pre``: the generator's forward result when the caller already ran it (see g_step)"""
-    flags = [p.requires_grad for p in d.parameters()]
-    for p in d.parameters():
-        p.requires_grad_(False)
-    try:
+    with frozen(d):
         fake, _, _, fake_len = pre if pre is not None else g(z=z, c=c, stop=stop)
         cls_g, _, _, nf_g = d(fake + noise_fake, fake_len, c)
         loss, _ = masked_bce_mean(cls_g, 0.5 if g_optim == 'boundary_seeking' else 0.0, nf_g)
         opt_g.zero_grad()
         loss.backward()
-    finally:
-        for p, r in zip(d.parameters(), flags):
-            p.requires_grad_(r)
     return loss.detach()
 
 
@@ -128,3 +146,22 @@ def d_backward_early(g, d, opt_d, real, real_len, c, z, noise_real, noise_fake, 
 def d_backward_late(keep):
     """the conv stack's backward (weight gradients of D's cnn) from the cut gradient"""
     keep['acts'][-1].backward(keep['a_cut'].grad)
+
+
+def g_backward_early(g, d, opt_g, c, z, noise_fake, keep, g_optim='boundary_seeking', stop='never', pre=None):
+    """generator iteration, forward + backward DOWN TO the frames the recurrent front produced: afterwards the
+    conv trunk's gradients (``g.early_params()``) are final and their all-reduce can run while ``g_backward_late``
+    runs the front's frame-by-frame backward.  ``pre``: result of ``g(z=z, c=c, stop=stop, cut=keep)`` when the
+    caller already ran the generator's forward (with the same ``keep``)."""
+    with frozen(d):
+        fake, _, _, fake_len = pre if pre is not None else g(z=z, c=c, stop=stop, cut=keep)
+        cls_g, _, _, nf_g = d(fake + noise_fake, fake_len, c)
+        loss, _ = masked_bce_mean(cls_g, 0.5 if g_optim == 'boundary_seeking' else 0.0, nf_g)
+        opt_g.zero_grad()
+        loss.backward()
+    return loss.detach()
+
+
+def g_backward_late(keep):
+    """the recurrent front's backward from the cut gradient (weight gradients of rnn / proj / stopper)"""
+    keep['x'].backward(keep['x_cut'].grad)

@@ -70,22 +70,10 @@ _SIDE = [None]
 
 
 def one_step(train, g, d, opt_g, opt_d, b, hook_d=None, hook_g=None, overlap=False):
-    """the canonical step.  overlap=True: the generator iteration's G forward (which depends on neither D nor the
-    critic iteration) is enqueued on a second stream beside the critic iteration; its latency-bound frame loop
-    then shares the GPU with the critic's equally latency-bound biLSTM chains.  Same work, same results."""
-    pre = None
-    if overlap:
-        if _SIDE[0] is None:
-            _SIDE[0] = torch.cuda.Stream()
-        main = torch.cuda.current_stream()
-        _SIDE[0].wait_stream(main)
-        with torch.cuda.stream(_SIDE[0]):
-            pre = g(z=b['z'], c=b['c'], stop='never')
-    train.d_step(g, d, opt_d, b['real'], b['real_len'], b['c'], b['z'], b['noise_real'], b['noise_fake'],
-                 1.0, grad_hook=hook_d)
-    if overlap:
-        torch.cuda.current_stream().wait_stream(_SIDE[0])
-    train.g_step(g, d, opt_g, b['c'], b['z'], b['noise_fake'], 0.1, grad_hook=hook_g, pre=pre)
+    """the canonical step (train.gd_step).  overlap=True: the generator iteration's G forward runs on a second
+    stream beside the critic iteration (see train.gd_step).  Returns (loss_d, loss_g)."""
+    return train.gd_step(g, d, opt_g, opt_d, b['real'], b['real_len'], b['c'], b['z'], b['noise_real'],
+                         b['noise_fake'], 1.0, 0.1, overlap=overlap, hook_d=hook_d, hook_g=hook_g)
 
 
 def pmc_traffic(kernel):
@@ -100,10 +88,10 @@ def pmc_traffic(kernel):
     return ent['bytes_per_launch'] if ent else None
 
 
-def cpu_baseline(batch, steps, opt_kind, threads=0, budget_s=45.0):
-    """the oracle's canonical step on `batch` clips of the same workload on the host cores.
-    Bounded: after the (timed) warm-up step it keeps timing steps only while the total stays under
-    `budget_s`; a slow host therefore reports from fewer steps instead of stalling the bench."""
+def cpu_baseline(batch, steps, opt_kind, threads=0, budget_s=110.0, warm=2):
+    """the oracle's canonical step on `batch` clips of the same workload on the host cores (the full
+    C2 batch, 2 warm-up + >= 5 timed steps, median).  Bounded: it keeps timing steps only while the total stays
+    under `budget_s`; a slow host therefore reports from fewer steps (and says so) instead of stalling the bench."""
     from oracle import audiogan_oracle as O
     if threads:
         torch.set_num_threads(threads)
@@ -115,22 +103,24 @@ def cpu_baseline(batch, steps, opt_kind, threads=0, budget_s=45.0):
     stop = torch.zeros(batch, L // FRAME, dtype=torch.long)
     cores = torch.get_num_threads()
     times, t_start = [], time.perf_counter()
-    for i in range(steps + 1):
+    for i in range(steps + warm):
         t0 = time.perf_counter()
         O.d_step(g, d, od, b['real'], b['real_len'], b['c'], b['z'], b['noise_real'], b['noise_fake'], 1.0, stop=stop)
         O.g_step(g, d, og, b['c'], b['z'], b['noise_fake'], 0.1, stop=stop)
         times.append(time.perf_counter() - t0)
-        sys.stderr.write('cpu_baseline: step %d of %d took %.1f s\n' % (i, steps, times[-1]))
+        sys.stderr.write('cpu_baseline: step %d of %d took %.1f s\n' % (i, steps + warm, times[-1]))
         sys.stderr.flush()
         if time.perf_counter() - t_start + times[-1] > budget_s:
             break
-    timed = times[1:] if len(times) > 1 else times      # drop the warm-up step when there is another
+    nwarm = min(warm, len(times) - 1)                   # drop the warm-up steps when there are others
+    timed = times[nwarm:]
     t = float(np.median(timed))
+    short = '' if len(timed) >= steps else ' (time budget of %.0f s reached: %d of the %d timed steps asked for)' % (
+        budget_s, len(timed), steps)
     return dict(value=batch * L / t, unit='audio-samples/sec', cores=cores, kind='port',
-                sample='%d of the 64 clips per step, %d timed step(s)%s (median %.2f s/step), torch %s CPU, '
-                       '%d threads, %s' % (batch, len(timed), ' after 1 warm-up' if len(times) > 1 else
-                                           ' (the warm-up itself: time budget)', t, torch.__version__, cores,
-                                           opt_kind))
+                sample='%d of the 64 clips per step, %d timed step(s) after %d warm-up%s (median %.2f s/step), '
+                       'torch %s CPU, %d threads, %s' % (batch, len(timed), nwarm, short, t, torch.__version__,
+                                                         cores, opt_kind))
 
 
 class _StdoutToStderr(object):
@@ -156,8 +146,8 @@ def main():
     ap.add_argument('--batch', type=int, default=64, help='clips per GPU')
     ap.add_argument('--opt', default='adam', choices=['adam', 'rmsprop'],
                     help='adam = north_star; rmsprop = audiogan.py:693-694')
-    ap.add_argument('--cpu-batch', type=int, default=32)
-    ap.add_argument('--cpu-steps', type=int, default=3)
+    ap.add_argument('--cpu-batch', type=int, default=64)
+    ap.add_argument('--cpu-steps', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--force-phases', action='store_true',
@@ -173,10 +163,9 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d '
-                             '--master-addr 127.0.0.1 --master-port 29500 bench.py --gpus %d ...'
-                             % (args.gpus, args.gpus))
+        raise SystemExit('--gpus %d but WORLD_SIZE is %d; launch with: python -m torch.distributed.run --nnodes=1 '
+                         '--nproc-per-node %d --master-addr 127.0.0.1 --master-port 29500 bench.py --gpus %d ...'
+                         % (args.gpus, world, args.gpus, args.gpus))
     assert torch.cuda.is_available(), 'bench.py needs a GPU (no CPU fallback)'
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
@@ -194,6 +183,8 @@ def main():
             t_ = torch.ones(1, device=dev)
             dist.all_reduce(t_)
             torch.cuda.synchronize()
+        assert dist.get_world_size() == (args.gpus if world > 1 else 1), 'process group size != --gpus'
+        assert int(t_.item()) == dist.get_world_size(), 'RCCL all-reduce did not see every rank'
 
     import audiogan_amd as A
     from audiogan_amd import train, ddp, kernels as K
@@ -205,7 +196,7 @@ def main():
         ddp.broadcast_parameters(g)
         ddp.broadcast_parameters(d)
         bd = ddp.GradBucket(list(d.parameters()), early=d.early_params(), force_collective=rehearse)
-        bg = ddp.GradBucket(list(g.parameters()), force_collective=rehearse)
+        bg = ddp.GradBucket(list(g.parameters()), early=g.early_params(), force_collective=rehearse)
         opt_d.bucket, opt_g.bucket = bd, bg
         hook_d, hook_g = bd.all_reduce, bg.all_reduce
     batch = synthetic_batch(args.batch, dev, seed=1000 + rank)
@@ -234,7 +225,7 @@ def main():
     graph = None
     phases = None
     capture_error = None
-    keep = {}
+    keep, gkeep, losses = {}, {}, {}
 
     def capture(fn, warm=True):
         if warm:
@@ -255,35 +246,46 @@ def main():
         try:
             K.reserve_table_arena()
             if not multi:
-                graph = capture(lambda: one_step(train, g, d, opt_g, opt_d, batch, overlap=not args.no_overlap))
+                def whole():
+                    losses['d'], losses['g'] = one_step(train, g, d, opt_g, opt_d, batch, overlap=not args.no_overlap)
+
+                graph = capture(whole)
                 graph.replay()
             else:
                 scale = 1.0 / world
                 # critic: graph 1a ends where the gradients of heads + biLSTM are final; their all-reduce
-                # (93 % of D's bytes) then runs on RCCL's stream WHILE graph 1b does the conv-stack backward
+                # (93 % of D's bytes) then runs on RCCL's stream WHILE graph 1b does the conv-stack backward.
+                # generator: graph 3a ends where the conv trunk's gradients are final; their all-reduce runs
+                # while graph 3b does the recurrent front's frame-by-frame backward.
                 def critic_early():
                     # the G forward of the generator iteration is a parallel branch of this graph (as in the
-                    # single-graph step): fork, run it beside the critic, join before the capture ends
+                    # single-graph step): G's weights are materialised on the main stream, then fork, run it
+                    # beside the critic, join before the capture ends
                     if not args.no_overlap:
                         if _SIDE[0] is None:
                             _SIDE[0] = torch.cuda.Stream()
+                        g.prepare_weights()
                         _SIDE[0].wait_stream(torch.cuda.current_stream())
                         with torch.cuda.stream(_SIDE[0]):
-                            keep['pre'] = g(z=b_['z'], c=b_['c'], stop='never')
-                    train.d_backward_early(g, d, opt_d, b_['real'], b_['real_len'], b_['c'], b_['z'],
-                                           b_['noise_real'], b_['noise_fake'], keep)
+                            keep['pre'] = g(z=b_['z'], c=b_['c'], stop='never', cut=gkeep)
+                    keep['loss_d'] = train.d_backward_early(g, d, opt_d, b_['real'], b_['real_len'], b_['c'], b_['z'],
+                                                            b_['noise_real'], b_['noise_fake'], keep)
                     if not args.no_overlap:
                         torch.cuda.current_stream().wait_stream(_SIDE[0])
+
+                def gen_early():
+                    keep['loss_g'] = train.g_backward_early(g, d, opt_g, b_['c'], b_['z'], b_['noise_fake'], gkeep,
+                                                            pre=keep.get('pre'))
 
                 g1a = capture(critic_early)
                 g1b = capture(lambda: train.d_backward_late(keep), warm=False)
                 bd.all_reduce()
                 g2 = capture(lambda: opt_d.step(clip_norm=1.0, grad_scale=scale))
-                g3 = capture(lambda: train.g_backward(g, d, opt_g, b_['c'], b_['z'], b_['noise_fake'],
-                                                      pre=keep.get('pre')), warm=args.no_overlap)
+                g3a = capture(gen_early, warm=args.no_overlap)
+                g3b = capture(lambda: train.g_backward_late(gkeep), warm=False)
                 bg.all_reduce()
                 g4 = capture(lambda: opt_g.step(clip_norm=0.1, grad_scale=scale))
-                phases = (g1a, g1b, g2, g3, g4)
+                phases = (g1a, g1b, g2, g3a, g3b, g4)
             torch.cuda.synchronize()
         except Exception as e:  # noqa: BLE001
             sys.stderr.write('hipGraph capture failed (%s: %s); running eagerly\n' % (type(e).__name__, e))
@@ -301,11 +303,14 @@ def main():
             bd.wait()
             bd.all_reduce(part='late')
             phases[2].replay()                         # opt_d
-            phases[3].replay()                         # generator fwd + bwd
-            bg.all_reduce()
-            phases[4].replay()                         # opt_g
+            phases[3].replay()                         # generator fwd + bwd down to the front's frames
+            bg.all_reduce(async_op=True, part='early') # conv trunk's gradients; overlaps ...
+            phases[4].replay()                         # ... the recurrent front's backward
+            bg.wait()
+            bg.all_reduce(part='late')
+            phases[5].replay()                         # opt_g
         else:
-            one_step(train, g, d, opt_g, opt_d, batch, hook_d, hook_g)
+            losses['d'], losses['g'] = one_step(train, g, d, opt_g, opt_d, batch, hook_d, hook_g)
 
     graphed = graph is not None or phases is not None
     # ---- timed region: exactly K steps between barrier+synchronize on both sides
@@ -318,6 +323,31 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     rec = K.Profiler.stop() if (dominant is not None and not graphed) else {}
+
+    # ---- replay check (outside the timed region): one more replay of the captured step against one EAGER step from
+    # the same parameters / optimiser state on the same batch; loss_d and loss_g must agree
+    replay = None
+    if graphed:
+        from audiogan_amd import common
+        nets = list(g.parameters()) + list(d.parameters())
+        snap = [p_.detach().clone() for p_ in nets]
+        sog, sod = opt_g.state_dict(), opt_d.state_dict()
+        run_step()
+        torch.cuda.synchronize()
+        src = losses if graph is not None else {'d': keep['loss_d'], 'g': keep['loss_g']}
+        got = (float(src['d']), float(src['g']))
+        with torch.no_grad():
+            for p_, s_ in zip(nets, snap):
+                p_.copy_(s_)
+        common.bump_param_epoch(nets)
+        opt_g.load_state_dict(sog)
+        opt_d.load_state_dict(sod)
+        ld, lg_ = one_step(train, g, d, opt_g, opt_d, batch, hook_d, hook_g)
+        torch.cuda.synchronize()
+        ref = (float(ld), float(lg_))
+        rel = max(abs(a - b) / max(abs(b), 1e-12) for a, b in zip(got, ref))
+        replay = dict(ok=bool(rel <= 2e-4 and all(np.isfinite(got))), max_rel_diff=rel,
+                      loss_d=[got[0], ref[0]], loss_g=[got[1], ref[1]])
     if graphed and dominant is not None:
         # per-kernel HIP-event timing is impossible inside a graph replay: time the dominant
         # kernel class in eager steps right after the timed region (same kernels, same shapes)
@@ -348,10 +378,16 @@ def main():
                        'launch': ('hipGraph replay (1 graph per step%s)' % ('' if args.no_overlap else
                                   '; generator forward of the G iteration on a second stream beside the critic '
                                   'iteration') if graph is not None else
-                                  'hipGraph replay (5 graphs per step; D all-reduce overlaps the conv-stack backward)'
+                                  'hipGraph replay (6 graphs per step; D all-reduce overlaps the conv-stack backward, '
+                                  "G trunk all-reduce overlaps the front's backward)"
                                   if phases is not None
                                   else 'eager' + (' (capture failed: %s)' % capture_error if capture_error else ''))},
         }
+        if replay is not None:
+            out['replay_check'] = 'ok' if replay['ok'] else 'FAILED'
+            out['replay_check_detail'] = {k: v for k, v in replay.items() if k != 'ok'}
+        if world > 1 or rehearse:
+            out['rccl_ranks'] = dist.get_world_size()
         if dominant is not None and dominant in rec:
             r = rec[dominant]
             avg_ms = r['ms'] / r['n']
@@ -397,6 +433,9 @@ def main():
     if world > 1 or rehearse:
         dist.barrier()
         dist.destroy_process_group()
+    if replay is not None and not replay['ok']:
+        sys.stderr.write('replay check FAILED: %r\n' % (replay,))
+        sys.exit(1)
 
 
 if __name__ == '__main__':

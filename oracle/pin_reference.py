@@ -247,6 +247,42 @@ def main():
     emb = e(chars, clen)
     np.savez(os.path.join(OUT, 'ref_embedder.npz'), chars=chars.numpy(), clen=clen.numpy(),
              emb=emb.detach().numpy(), **_pack('sd.', _sd(e)))
+    # ---- C2 widths: the reference's OWN default-struct Generator / Discriminator (audiogan.py:368, :476) ----
+    # frame_size 256 (T = 32, L = 8192), embed 100, noise 100, state 1024, exactly bench.py's models.  The weights
+    # are NOT stored (60 MB): they are the torch default init under manual_seed(SEED), which the test regenerates
+    # (tests/test_oracle_pinned.py::test_c2_width_fixture checks two of them against the checksums kept here).
+    SEED = 1234
+    B2, Tn, fsz = 2, 32, 256
+    torch.manual_seed(SEED)
+    g = R.Generator(frame_size=fsz, embed_size=100, noise_size=100, state_size=1024)
+    d = R.Discriminator(state_size=1024, embed_size=100)
+    gin = torch.Generator().manual_seed(SEED + 1)
+    z = torch.randn(B2, Tn, 100, generator=gin)
+    c = torch.randn(B2, 100, generator=gin)
+    real = torch.rand(B2, Tn * fsz, generator=gin) * 2 - 1
+    rlen = torch.tensor([Tn * fsz, 5000])
+    gy = torch.randn(B2, Tn * fsz, generator=gin)
+    gl = torch.randn(B2, 128, generator=gin)
+    gs_ = torch.randn(B2, Tn, generator=gin)
+    with no_stop_multinomial():
+        xg, s, _, glen = g(z=z, c=c)
+    (xg * gy).sum().add((s * gs_).sum()).backward()
+    logits_f, _, _, nf_f = d(xg.detach(), glen, c)            # D on the generated clips (full length)
+    logits_r, acts_r, _, nf_r = d(real, rlen, c)               # D on ragged "real" clips
+    (logits_r * gl).sum().backward()
+    gn = {k: float(p.grad.norm()) for k, p in g.named_parameters()}
+    dn = {k: float(p.grad.norm()) if p.grad is not None else 0.0 for k, p in d.named_parameters()}
+    np.savez_compressed(
+        os.path.join(OUT, 'ref_c2_width.npz'), seed=SEED,
+        z=z.numpy(), c=c.numpy(), rlen=rlen.numpy(),        # real / gy / gl / gs: re-drawn by the test (same generator)
+        wave=xg.detach().numpy(), s=s.detach().numpy(), length=glen.numpy(),
+        logits_fake=logits_f.detach().numpy(), logits_real=logits_r.detach().numpy(),
+        nframes_real=nf_r.numpy(), act5_real_sum=np.array([float(acts_r[-1].double().sum()),
+                                                           float(acts_r[-1].double().abs().sum())]),
+        g_names=np.array(list(gn.keys())), g_gradnorm=np.array(list(gn.values())),
+        d_names=np.array(list(dn.keys())), d_gradnorm=np.array(list(dn.values())),
+        w_check=np.array([float(g.state_dict()['rnn.0.module.weight_hh_v'].double().sum()),
+                          float(d.state_dict()['cnn.5.module.weight_v'].double().sum())]))
     print('wrote', sorted(f for f in os.listdir(OUT) if f.startswith('ref_')))
 
 

@@ -1,6 +1,8 @@
-"""N>1 path on CPU: 2 processes, gloo backend, kernels replaced by the torch model.  Two ranks that
-each see half of the batch must end up with the same parameters as one process that sees all of it
-(flat gradient bucket -> one sum all-reduce per network -> 1/world folded into the optimiser)."""
+"""N>1 path on CPU: 2 and 4 processes, gloo backend, kernels replaced by the torch model.  N ranks that
+each see 1/N of the batch must end up with the same parameters as one process that sees all of it
+(flat gradient bucket -> sum all-reduce per network -> 1/world folded into the optimiser), also on the
+phase-split path of bench.py (critic: heads/biLSTM early, conv stack late; generator: conv trunk early,
+recurrent front late, each early part all-reduced asynchronously beside the late backward)."""
 import os
 import sys
 
@@ -43,8 +45,8 @@ def _steps(A, g, d, b, buckets=False):
     if buckets:
         ddp.broadcast_parameters(g); ddp.broadcast_parameters(d)
         bd = ddp.GradBucket(list(d.parameters()), early=d.early_params())
-        bg = ddp.GradBucket(list(g.parameters()))
-        assert 0 < bd.n_early < bd.flat.numel()
+        bg = ddp.GradBucket(list(g.parameters()), early=g.early_params())
+        assert 0 < bd.n_early < bd.flat.numel() and 0 < bg.n_early < bg.flat.numel()
         od.bucket, og.bucket = bd, bg
         hd, hg = bd.all_reduce, bg.all_reduce
     for it in range(2):
@@ -58,8 +60,12 @@ def _steps(A, g, d, b, buckets=False):
             bd.wait()
             scale = bd.all_reduce(part='late')
             od.step(clip_norm=1.0, grad_scale=scale)
-            train.g_backward(g, d, og, b['c'], b['z'], b['nf'])
-            og.step(clip_norm=0.1, grad_scale=bg.all_reduce())
+            gkeep = {}
+            train.g_backward_early(g, d, og, b['c'], b['z'], b['nf'], gkeep)
+            bg.all_reduce(async_op=True, part='early')
+            train.g_backward_late(gkeep)
+            bg.wait()
+            og.step(clip_norm=0.1, grad_scale=bg.all_reduce(part='late'))
         else:
             train.d_step(g, d, od, b['real'], b['real_len'], b['c'], b['z'], b['nr'], b['nf'], 1.0, grad_hook=hd)
             train.g_step(g, d, og, b['c'], b['z'], b['nf'], 0.1, grad_hook=hg)
@@ -81,19 +87,26 @@ def _worker(rank, world, port, out):
             for p in list(g.parameters()) + list(d.parameters()):
                 p.add_(0.1)
     full = _batch(4)
-    half = {k: v[rank * 2:(rank + 1) * 2] for k, v in full.items()}
+    per = 4 // world
+    half = {k: v[rank * per:(rank + 1) * per] for k, v in full.items()}
     sd = _steps(A, g, d, half, buckets=True)
     torch.save(sd, os.path.join(out, 'rank%d.pt' % rank))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_ranks_equal_one_process(tmp_path):
-    port = 29500 + (os.getpid() % 2000)
-    mp.start_processes(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True, start_method='spawn')
-    r0, r1 = torch.load(os.path.join(tmp_path, 'rank0.pt')), torch.load(os.path.join(tmp_path, 'rank1.pt'))
-    for k in r0:
-        np.testing.assert_array_equal(r0[k].numpy(), r1[k].numpy(), err_msg='ranks diverged: ' + k)
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize('world', [2, 4])
+def test_ranks_equal_one_process(tmp_path, world):
+    port = 29500 + (os.getpid() % 2000) + world
+    mp.start_processes(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True, start_method='spawn')
+    r0 = torch.load(os.path.join(tmp_path, 'rank0.pt'))
+    for r in range(1, world):
+        rr = torch.load(os.path.join(tmp_path, 'rank%d.pt' % r))
+        for k in r0:
+            np.testing.assert_array_equal(r0[k].numpy(), rr[k].numpy(), err_msg='ranks diverged: ' + k)
     sys.path.insert(0, ROOT)
     _install_model_local = _install_model
     import audiogan_amd.kernels as K

@@ -51,10 +51,13 @@ def _run(dev, A):
     np.testing.assert_array_equal(torch.sign(adv)[strong].numpy(), torch.sign(go_)[strong].numpy())
     assert float(adv.abs().max()) == pytest.approx(1e-3)
     assert not adv[1, 112:].any()         # past the clip's length (+ receptive field) the input is masked out
-    # ---- adversarial z (audiogan.py:99-137)
+    # ---- adversarial z (audiogan.py:99-137); input-gradient passes must leave every parameter's .grad untouched
+    before = [(q, None if q.grad is None else q.grad.clone()) for q in list(g.parameters()) + list(d.parameters())]
     z2 = X.adversarially_sample_z(g, d, B, T, 8, 128, c.to(dev), 0.01, c.to(dev), z=z.to(dev),
                                   noise=torch.zeros(B, 128).to(dev), stop='never')
     assert z2.shape == z.shape and float((z2.cpu() - z).abs().max()) <= 1e-2 + 1e-7
+    for q, b in before:
+        assert q.requires_grad and ((q.grad is None) if b is None else torch.equal(q.grad, b))
 
 
 def test_extras_host_logic(monkeypatch):

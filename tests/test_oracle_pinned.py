@@ -139,3 +139,63 @@ def test_calc_dists_and_fourth_moment(golden_dir):
         np.testing.assert_allclose(s.numpy(), v['s%d' % i], rtol=1e-5, atol=1e-6, err_msg='stat %d' % i)
         np.testing.assert_allclose(d.numpy(), v['d%d' % i], rtol=1e-5, atol=1e-6, err_msg='std %d' % i)
     assert float(O.fourth_moment(torch.randn(5, 3)).min()) == 1.0
+
+
+def c2_width_inputs(v):
+    """the fixture's inputs: z, c, rlen are stored; real / gy / gl / gs are re-drawn from the same generator
+    in the order oracle/pin_reference.py drew them"""
+    seed = int(v['seed'])
+    gin = torch.Generator().manual_seed(seed + 1)
+    B, T, fs = 2, 32, 256
+    z = torch.randn(B, T, 100, generator=gin)
+    c = torch.randn(B, 100, generator=gin)
+    real = torch.rand(B, T * fs, generator=gin) * 2 - 1
+    gy = torch.randn(B, T * fs, generator=gin)
+    gl = torch.randn(B, 128, generator=gin)
+    gs = torch.randn(B, T, generator=gin)
+    np.testing.assert_array_equal(z.numpy(), v['z'])
+    np.testing.assert_array_equal(c.numpy(), v['c'])
+    return dict(z=z, c=c, real=real, rlen=torch.from_numpy(v['rlen']), gy=gy, gl=gl, gs=gs)
+
+
+def c2_width_models(mod, v):
+    """default-struct G / D at bench.py's sizes, torch default init under the fixture's seed (G first, then D)"""
+    torch.manual_seed(int(v['seed']))
+    g = mod.Generator(frame_size=256, embed_size=100, noise_size=100, state_size=1024)
+    d = mod.Discriminator(state_size=1024, embed_size=100)
+    return g, d
+
+
+def test_c2_width_fixture(golden_dir):
+    """the oracle at the FULL C2 widths (default structs, state 1024, 8192-sample clips) against outputs and
+    per-parameter gradient norms of the reference's own classes"""
+    v = _load(golden_dir, 'ref_c2_width.npz')
+    g, d = c2_width_models(O, v)
+    # same seed -> same init as the reference's modules (the weights themselves are not in the fixture)
+    np.testing.assert_allclose(float(g.state_dict()['rnn.0.module.weight_hh_v'].double().sum()), v['w_check'][0],
+                               rtol=1e-12)
+    np.testing.assert_allclose(float(d.state_dict()['cnn.5.module.weight_v'].double().sum()), v['w_check'][1],
+                               rtol=1e-12)
+    i = c2_width_inputs(v)
+    stop = torch.zeros(2, 32, dtype=torch.long)
+    x, s, _, length = g(z=i['z'], c=i['c'], stop=stop)
+    np.testing.assert_allclose(x.detach().numpy(), v['wave'], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(s.detach().numpy(), v['s'], rtol=1e-4, atol=1e-6)
+    np.testing.assert_array_equal(length.numpy(), v['length'])
+    ((x * i['gy']).sum() + (s * i['gs']).sum()).backward()
+    lf, _, _, _ = d(x.detach(), length, i['c'])
+    np.testing.assert_allclose(lf.detach().numpy(), v['logits_fake'], rtol=1e-4, atol=1e-6)
+    lr, acts, _, nf = d(i['real'], i['rlen'], i['c'])
+    np.testing.assert_allclose(lr.detach().numpy(), v['logits_real'], rtol=1e-4, atol=1e-6)
+    np.testing.assert_array_equal(nf.numpy(), v['nframes_real'])
+    np.testing.assert_allclose([float(acts[-1].double().sum()), float(acts[-1].double().abs().sum())],
+                               v['act5_real_sum'], rtol=1e-5)
+    (lr * i['gl']).sum().backward()
+    for names, norms, mod in ((v['g_names'], v['g_gradnorm'], g), (v['d_names'], v['d_gradnorm'], d)):
+        ps = dict(mod.named_parameters())
+        for k, n in zip(names, norms):
+            k = str(k)
+            if k.split('.')[-1].startswith('bias') and k.endswith('_v'):
+                continue
+            got = float(ps[k].grad.norm()) if ps[k].grad is not None else 0.0
+            np.testing.assert_allclose(got, n, rtol=1e-3, atol=1e-7, err_msg=k)
