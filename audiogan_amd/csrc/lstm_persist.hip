@@ -1,0 +1,277 @@
+// lstm_persist.hip -- a whole NN.LSTM layer pass (audiogan.py:498-503, :543; Embedder :315) as ONE persistent launch
+// with the recurrent weights resident in LDS.
+//
+// The per-step launches of lstm_step.hip re-stream W_hh from the fabric on every one of the T steps (L2 is not kept
+// across launches): 8.4 MB per step for the critic's biLSTM, more than the step's own operands.  Here every workgroup
+// keeps ITS slice of W_hh in LDS for the whole sequence and only the hidden state crosses workgroups:
+//
+//   workgroup  = (direction d, batch tile of 32*RT clips, unit tile of 8 hidden units)      1 per CU, all co-resident
+//   LDS        = W_hh rows of its 4 gates x 8 units  [32 gate columns][H]  (128 B * H)  + the K-slice reduction buffer
+//   per step   : wait until the 64 unit tiles of its (d, batch tile) GROUP have published h_{k-1}  (one flag each)
+//                -> A = h_{k-1} rows of the batch tile, straight from L2 into registers (sc1 loads: L1 is never
+//                   refreshed by other CUs' stores, MI355X_MICROARCH.md "inter-workgroup visibility")
+//                -> gates = pre_k + A * W_slice^T on v_mfma_f32_32x32x2_f32 (K split over the waves, LDS reduction)
+//                -> cell non-linearity; c stays in a register for the whole sequence
+//                -> publish h_k: write-through (sc1) stores, every wave drains, barrier, one flag store.
+//
+// Forward exchange buffer layout [parity][group][unit tile q][row][8 units]: a producer writes 1-2 KB contiguous, a
+// consumer lane reads one float4 = 4 consecutive k of its row (k = 8q + 4*(lane>>5) + e, the k-slot order of the MFMA),
+// 64 lanes covering 1 KB contiguous.  Two parities suffice: h_{k+1} is written only after every group member has
+// finished step k, i.e. after it has read h_{k-1}.
+//
+// Synchronisation is placement independent (agent-scope flags + write-through payload, Guideline 16 R1); every spin is
+// bounded by wall clock (s_memrealtime) and reports through a status word instead of hanging.  ONE such launch may be
+// in flight per device (all its workgroups must be co-resident).
+#include "common.h"
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+#define PS_FLAG_OFF 16          // flags start at word 16 of the workspace; word 0 = status
+#define PS_HDR_BYTES 8192       // header (status + flags), zeroed by a memset node in front of every launch
+#define PS_TIMEOUT_TICKS 300000000ull   // 3 s of the 100 MHz realtime counter
+
+struct PersistDir {
+  float* pre;          // [T,B,4H] in: x-projection (+ biases); out: activated gates
+  const float* whh;    // [4H,H]
+  float* c_all;        // [T+1,B,H]  (c_all[0] = 0 on entry)
+  const float* cb;     // optional [B,4H] time-invariant part of the pre-activations
+};
+
+struct PersistFwdP {
+  PersistDir d[2];
+  float* y;            // [T,B,ndir*H]
+  const int64_t* valid;
+  float* xbuf;         // exchange buffer
+  unsigned* hdr;       // status + flags
+  int T, B, H, ndir;
+  int nbt;             // batch tiles
+  int ntile;           // H / 8
+};
+
+__device__ __forceinline__ bool ps_wait_flags(unsigned* hdr, const unsigned* flags, int n, unsigned want, int lane) {
+  // ONE wave polls the group's flags (lane i <-> flags i, i + 64, ...), relaxed agent-scope loads
+  unsigned long long t0 = 0;
+  for (unsigned spins = 0;; ++spins) {
+    bool ok = true;
+    for (int i = lane; i < n; i += 64)
+      ok &= __hip_atomic_load(flags + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want;
+    if (__all(ok)) return true;
+    if ((spins & 63) == 63) {
+      if (__hip_atomic_load(hdr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;   // somebody gave up
+      const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+      if (t0 == 0) t0 = now;
+      else if (now - t0 > PS_TIMEOUT_TICKS) {
+        if (lane == 0) __hip_atomic_store(hdr, 0x80000000u | want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return false;
+      }
+    }
+    __builtin_amdgcn_s_sleep(1);
+  }
+}
+
+template <int RT>      // 32-clip row tiles per workgroup
+__global__ __launch_bounds__(512) void lstm_persist_fwd_kernel(const PersistFwdP p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int NKS = 8 / RT;                 // K slices (waves per row tile)
+  constexpr int ROWS = 32 * RT;
+  const int H = p.H, B = p.B, T = p.T, ntile = p.ntile;
+  float* wl = smem;                           // [ntile][2][32][4]
+  float* red = smem + (size_t)32 * H;         // [8 waves][1024]
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l31 = lane & 31, hh = lane >> 5;
+  const int ngroups = p.ndir * p.nbt;
+  const int grp = blockIdx.x % ngroups, ut = blockIdx.x / ngroups;    // a group's blocks share blockIdx % ngroups
+  const int dir = grp / p.nbt, bt = grp % p.nbt;
+  const PersistDir& D = p.d[dir];
+  const int u0 = ut * 8, row0 = bt * ROWS;
+
+  // ---- W_hh slice -> LDS, once: column j = gate (j>>3), unit u0 + (j&7);  element (q, hslot, j, e) = W[row(j)][8q+4hslot+e]
+  {
+    const int k4n = H >> 2;
+    for (int idx = tid; idx < 32 * k4n; idx += 512) {
+      const int j = idx / k4n, k4 = idx - j * k4n;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(D.whh + (int64_t)((j >> 3) * H + u0 + (j & 7)) * H + 4 * k4);
+      *reinterpret_cast<f32x4*>(wl + ((size_t)((k4 >> 1) * 2 + (k4 & 1)) * 32 + j) * 4) = v;
+    }
+  }
+  __syncthreads();
+
+  unsigned* flags = p.hdr + PS_FLAG_OFF + grp * ntile;
+  const int64_t xg = (int64_t)ntile * ROWS * 8;                       // floats per (parity, group)
+  __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(p.xbuf, 0, (int)(2 * (int64_t)ngroups * xg * 4), 0x00020000);
+
+  // epilogue role: thread <-> (clip row, unit) for the whole sequence; c and h live in registers
+  const int erow = tid >> 3, euu = tid & 7;
+  const bool ethread = tid < ROWS * 8;
+  const int em = row0 + erow, eu = u0 + euu;
+  const bool epi = ethread && em < B;
+  const int64_t vlen = (epi && p.valid) ? p.valid[em] : ((int64_t)1 << 60);
+  float creg = 0.f, hreg = 0.f;
+  // accumulator element of (row i, column j) in a 32x32 tile: lane = j + 32*((i>>2)&1), e = (i&3) + 4*(i>>3)
+  const int ei = erow & 31, ert = erow >> 5;
+  const int ee = (ei & 3) + 4 * (ei >> 3), ehq = (ei >> 2) & 1;
+
+  // MFMA role
+  const int rt = RT == 2 ? (wid & 1) : 0, ks = RT == 2 ? (wid >> 1) : wid;
+  const int QW = ntile / NKS, q0w = ks * QW;
+  bool alive = true;
+
+  for (int k = 0; k < T; ++k) {
+    const int t = dir == 0 ? k : T - 1 - k;
+    // epilogue operands first: their latency overlaps the wait and the product
+    float pre4[4] = {0.f, 0.f, 0.f, 0.f};
+    if (epi) {
+      const float* pr = D.pre + ((int64_t)t * B + em) * 4 * H + eu;
+      pre4[0] = pr[0]; pre4[1] = pr[H]; pre4[2] = pr[2 * H]; pre4[3] = pr[3 * H];
+      if (D.cb) {
+        const float* cb = D.cb + (int64_t)em * 4 * H + eu;
+        pre4[0] += cb[0]; pre4[1] += cb[H]; pre4[2] += cb[2 * H]; pre4[3] += cb[3 * H];
+      }
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    if (k > 0) {
+      if (wid == 0 && alive) alive = ps_wait_flags(p.hdr, flags, ntile, (unsigned)k, lane);
+      __syncthreads();
+      const int par = (k - 1) & 1;
+      // byte offset of (q, row, 4*hh) in the exchange buffer
+      const unsigned abase = (unsigned)((((int64_t)(par * ngroups + grp) * xg) + (int64_t)(rt * 32 + l31) * 8 + 4 * hh) * 4);
+      const float* wrow = wl + ((size_t)hh * 32 + l31) * 4;
+      for (int qb = 0; qb < QW; qb += 8) {
+        u32x4 a[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int q = q0w + min(qb + i, QW - 1);
+          a[i] = __builtin_amdgcn_raw_buffer_load_b128(xr, abase + (unsigned)(q * ROWS * 32), 0, 16 /* sc1 */);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          if (qb + i < QW) {
+            const int q = q0w + qb + i;
+            const f32x4 b = *reinterpret_cast<const f32x4*>(wrow + (size_t)q * 256);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a[i][e]), b[e], acc, 0, 0, 0);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) red[wid * 1024 + e * 64 + lane] = acc[e];
+    __syncthreads();
+    if (epi) {
+      float g4[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float s = pre4[g];
+        if (k > 0) {
+#pragma unroll
+          for (int s_ = 0; s_ < NKS; ++s_) {
+            const int w = RT == 2 ? (ert + 2 * s_) : s_;
+            s += red[w * 1024 + ee * 64 + 32 * ehq + 8 * g + euu];
+          }
+        }
+        g4[g] = s;
+      }
+      const bool padded = t >= vlen;
+      float yv = 0.f;
+      if (!padded) {
+        const float ig = ag_sigmoid(g4[0]), fg = ag_sigmoid(g4[1]), gg = tanhf(g4[2]), og = ag_sigmoid(g4[3]);
+        creg = fg * creg + ig * gg;
+        hreg = og * tanhf(creg);
+        yv = hreg;
+        float* pr = D.pre + ((int64_t)t * B + em) * 4 * H + eu;
+        pr[0] = ig; pr[H] = fg; pr[2 * H] = gg; pr[3 * H] = og;
+      }
+      // publish h_k first (write-through), then the rest
+      if (k + 1 < T)
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(hreg), xr,
+            (unsigned)(((int64_t)((k & 1) * ngroups + grp) * xg + ((int64_t)ut * ROWS + erow) * 8 + euu) * 4), 0, 16 /* sc1 */);
+      D.c_all[((int64_t)(k + 1) * B + em) * H + eu] = creg;
+      p.y[((int64_t)t * B + em) * p.ndir * H + (int64_t)dir * H + eu] = yv;
+    } else if (ethread && k + 1 < T) {
+      // rows past the batch: keep the exchange buffer defined (the consumers' MFMA rows that read it are never stored)
+      __builtin_amdgcn_raw_buffer_store_b32(0u, xr,
+          (unsigned)(((int64_t)((k & 1) * ngroups + grp) * xg + ((int64_t)ut * ROWS + erow) * 8 + euu) * 4), 0, 16);
+    }
+    if (k + 1 < T) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // EVERY storing wave drains its write-through stores
+      __syncthreads();
+      if (tid == 0) __hip_atomic_store(flags + ut, (unsigned)(k + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+static bool persist_shape_ok(int B, int H, int ndir, int n_cu, int* rt_out, int* nbt_out) {
+  if (H % 64 != 0 || H < 64 || H > 768 || B < 1) return false;
+  if (n_cu > 256) n_cu = 256;
+  const int ntile = H / 8;
+  // one workgroup per CU, all co-resident: take 64-clip tiles when 32-clip tiles would not fit the chip
+  for (int rt = 1; rt <= 2; ++rt) {
+    const int nbt = ag_cdiv(B, 32 * rt);
+    if ((int64_t)ndir * nbt * ntile <= n_cu && ndir * nbt * ntile <= (PS_HDR_BYTES / 4 - PS_FLAG_OFF)) {
+      *rt_out = rt;
+      *nbt_out = nbt;
+      return true;
+    }
+  }
+  return false;
+}
+
+extern "C" int ag_lstm_persist_ok(int B, int H, int ndir, int n_cu) {
+  int rt, nbt;
+  return persist_shape_ok(B, H, ndir, n_cu, &rt, &nbt) ? 1 : 0;
+}
+
+extern "C" int64_t ag_lstm_persist_ws_bytes(int B, int H, int ndir) {
+  // header + 2 parities of the padded hidden state, both directions (64-clip padding covers both tilings)
+  return PS_HDR_BYTES + (int64_t)2 * ndir * ag_roundup(B, 64) * H * 4;
+}
+
+// Whole (bi)directional layer forward in ONE launch.  Same tensors as ag_lstm_seq_fwd (lstm_step.hip) minus the
+// hidden-state scratch; `ws` = ag_lstm_persist_ws_bytes() bytes of device memory, 16-byte aligned, used by no other
+// launch in flight.  `n_cu`: compute units of the device (the grid must be co-resident).
+extern "C" int ag_lstm_seq_fwd_persist(float* const* pre, const float* const* whh, float* const* c_all, float* y,
+                                       const int64_t* valid_i64, const float* const* static_pre, void* ws,
+                                       int64_t ws_bytes, int T, int B, int H, int ndir, int n_cu, void* stream) {
+  AG_REQUIRE(pre && whh && c_all && y && ws, "ag_lstm_seq_fwd_persist: null tensor");
+  AG_REQUIRE(ndir == 1 || ndir == 2, "ag_lstm_seq_fwd_persist: ndir must be 1 or 2");
+  AG_REQUIRE(T > 0, "ag_lstm_seq_fwd_persist: T must be positive");
+  int rt = 0, nbt = 0;
+  if (!persist_shape_ok(B, H, ndir, n_cu, &rt, &nbt)) {
+    ag_set_error("ag_lstm_seq_fwd_persist: shape B=%d H=%d ndir=%d does not fit %d CUs", B, H, ndir, n_cu);
+    return AG_ERR_UNSUPPORTED;
+  }
+  AG_REQUIRE(ws_bytes >= ag_lstm_persist_ws_bytes(B, H, ndir) && ((uintptr_t)ws & 15) == 0,
+             "ag_lstm_seq_fwd_persist: workspace too small or misaligned");
+  for (int d = 0; d < ndir; ++d) AG_REQUIRE(((uintptr_t)whh[d] & 15) == 0, "ag_lstm_seq_fwd_persist: W_hh must be 16-B aligned");
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(ws, 0, PS_HDR_BYTES, st) != hipSuccess) {
+    ag_set_error("ag_lstm_seq_fwd_persist: memset failed");
+    return AG_ERR_LAUNCH;
+  }
+  PersistFwdP p;
+  for (int d = 0; d < 2; ++d) {
+    const int s = d < ndir ? d : 0;
+    p.d[d].pre = pre[s]; p.d[d].whh = whh[s]; p.d[d].c_all = c_all[s];
+    p.d[d].cb = static_pre ? static_pre[s] : nullptr;
+  }
+  p.y = y; p.valid = valid_i64;
+  p.hdr = (unsigned*)ws;
+  p.xbuf = (float*)((char*)ws + PS_HDR_BYTES);
+  p.T = T; p.B = B; p.H = H; p.ndir = ndir; p.nbt = nbt; p.ntile = H / 8;
+  const size_t lds = ((size_t)32 * H + 8 * 1024) * sizeof(float);
+  const int grid = ndir * nbt * p.ntile;
+  if (rt == 1) {
+    auto kern = lstm_persist_fwd_kernel<1>;
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, p);
+  } else {
+    auto kern = lstm_persist_fwd_kernel<2>;
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, p);
+  }
+  AG_CHECK_LAUNCH("ag_lstm_seq_fwd_persist");
+  return AG_OK;
+}

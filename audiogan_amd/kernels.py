@@ -565,13 +565,81 @@ def _ptr_table(tensors):
     return arr
 
 
+# ---- persistent (weights-resident) layer pass: workspace per device, status word, switch -------------------------
+import os as _os
+
+PERSIST = [_os.environ.get('AG_LSTM_PERSIST', '1') != '0']
+_persist_ws = {}
+_ncu = {}
+
+
+def _n_cu(dev):
+    n = _ncu.get(dev)
+    if n is None:
+        n = _ncu[dev] = torch.cuda.get_device_properties(dev).multi_processor_count
+    return n
+
+
+def lstm_persist_ok(B, H, ndir, dev):
+    return bool(PERSIST[0] and lib.ag_lstm_persist_ok(B, H, ndir, _n_cu(dev)))
+
+
+def _persist_workspace(dev, nbytes):
+    ws = _persist_ws.get(dev)
+    if ws is None or ws.numel() < nbytes:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError('audiogan_amd: the persistent LSTM workspace must exist before hipGraph capture '
+                               '(run one eager step first)')
+        ws = _persist_ws[dev] = torch.zeros(int(nbytes), dtype=torch.uint8, device=dev)
+    return ws
+
+
+def lstm_persist_status(dev=None):
+    """status word of the last persistent launch(es) on `dev` (0 = ok; host sync).  Non-zero: a bounded wait timed
+    out, i.e. the launch's workgroups were not all co-resident (another persistent launch in flight?)."""
+    dev = torch.device('cuda', torch.cuda.current_device()) if dev is None else torch.device(dev)
+    ws = _persist_ws.get(dev)
+    return 0 if ws is None else int(ws[:4].view(torch.int32).item())
+
+
+def lstm_seq_fwd_persist(pre, whh, c_all, y, valid, static=None):
+    """ONE persistent launch for the whole layer pass (ag_lstm_seq_fwd_persist)"""
+    ndir = len(pre)
+    T, B, H4 = pre[0].shape
+    H = H4 // 4
+    for d in range(ndir):
+        for t_, shp in ((pre[d], (T, B, 4 * H)), (whh[d], (4 * H, H)), (c_all[d], (T + 1, B, H))):
+            _chk(t_, 'lstm_seq tensor')
+            assert t_.is_contiguous() and tuple(t_.shape) == shp, (tuple(t_.shape), shp)
+    _chk(y, 'y'); _chk(valid, 'valid', torch.int64)
+    assert y.is_contiguous() and tuple(y.shape) == (T, B, ndir * H)
+    if static is not None:
+        assert len(static) == ndir
+        for t_ in static:
+            _chk(t_, 'static')
+            assert t_.is_contiguous() and tuple(t_.shape) == (B, 4 * H)
+    nb = int(lib.ag_lstm_persist_ws_bytes(B, H, ndir))
+    ws = _persist_workspace(y.device, nb)
+    check(lib.ag_lstm_seq_fwd_persist(_ptr_table(pre), _ptr_table(whh), _ptr_table(c_all), _p(y), _p(valid),
+                                      _ptr_table(static) if static is not None else None, _p(ws), ws.numel(),
+                                      T, B, H, ndir, _n_cu(y.device), _stream()), 'ag_lstm_seq_fwd_persist')
+
+
 def lstm_seq_fwd(pre, whh, c_all, hbuf, y, valid, static=None):
     """pre/whh/c_all/hbuf: lists (one per direction) of contiguous tensors; static: optional list of [B,4H]
-    tensors added to every step's pre-activations; see ag_lstm_seq_fwd"""
+    tensors added to every step's pre-activations; see ag_lstm_seq_fwd.  Shapes that fit the chip take the
+    persistent weights-resident launch (AG_LSTM_PERSIST=0 forces one launch per step)."""
     T = pre[0].size(0)
+    if lstm_persist_ok(pre[0].size(1), pre[0].size(2) // 4, len(pre), y.device):
+        _lstm_seq_fwd_persist_call(pre, whh, c_all, y, valid, static)
+        return
     # (the profiler times the whole chain of T back-to-back launches with one pair of events and divides by T:
     # events around every single launch add ~3 us to a 10 us kernel)
     _lstm_seq_fwd_range(pre, whh, c_all, hbuf, y, valid, 0, T, static)
+
+
+def _lstm_seq_fwd_persist_call(pre, whh, c_all, y, valid, static=None):
+    lstm_seq_fwd_persist(pre, whh, c_all, y, valid, static)
 
 
 def _lstm_seq_fwd_range(pre, whh, c_all, hbuf, y, valid, k0, k1, static=None):
@@ -656,6 +724,15 @@ def _work_seq_fwd(pre, whh, c_all, hbuf, y, valid, k0, k1, *a_, **kw):
     return 'lstm_step_fwd_kernel', n * 2.0 * nd * B * H4 * (H4 // 4), n * 4.0 * nd * (H4 * (H4 // 4) + 3 * B * H4), n
 
 
+def _work_seq_fwd_persist(pre, whh, c_all, y, valid, static=None):
+    T, B, H4 = pre[0].shape
+    nd = len(pre)
+    # one launch = the whole layer pass: T steps of 2*B*4H*H flops per direction; algorithmic bytes: W_hh ONCE
+    # + gates in/out, cells, outputs per step
+    return 'lstm_persist_fwd_kernel', T * 2.0 * nd * B * H4 * (H4 // 4), \
+        4.0 * nd * (H4 * (H4 // 4) + T * 3 * B * H4), 1
+
+
 def _work_seq_bwd_prod(gates, whh, *a_, **kw):
     T, B, H4 = gates[0].shape
     nd = len(gates)
@@ -674,7 +751,8 @@ def _work_seq_bwd_cell(gates, whh, *a_, **kw):
 
 
 for _n, _w in (('skinny_gemm', _work_skinny), ('lstm_step_fwd', _work_step),
-               ('_lstm_seq_fwd_range', _work_seq_fwd), ('_lstm_seq_bwd_prod', _work_seq_bwd_prod),
+               ('_lstm_seq_fwd_range', _work_seq_fwd), ('_lstm_seq_fwd_persist_call', _work_seq_fwd_persist),
+               ('_lstm_seq_bwd_prod', _work_seq_bwd_prod),
                ('_lstm_seq_bwd_cell', _work_seq_bwd_cell), ('_lstm_seq_bwd_step', _work_seq_bwd_step)):
     _instrument(_n, _w)
 

@@ -245,6 +245,21 @@ int ag_lstm_seq_bwd(const float* const* gates, const float* const* whh, const fl
                     const int64_t* valid_i64, int T, int B, int H, int ndir, int k_begin, int k_end,
                     int phases, void* stream);
 
+/* The same layer forward as ONE persistent launch with W_hh resident in LDS (csrc/lstm_persist.hip): each
+ * workgroup owns 8 hidden units x 32 or 64 clips of one direction for the whole sequence; only the hidden state
+ * crosses workgroups (write-through stores + one agent-scope flag per workgroup and step).  Replaces T launches
+ * that re-stream W_hh from the fabric each.  Needs every workgroup co-resident: ag_lstm_persist_ok() says whether
+ * (B, H, ndir) fits `n_cu` compute units (H % 64 == 0, H <= 768, ndir * ceil(B/32 or 64) * H/8 <= n_cu); `ws` is
+ * ag_lstm_persist_ws_bytes() bytes of 16-byte aligned device memory owned by this launch while it is in flight (its
+ * first 8 KiB - status word + flags - are zeroed by a memset node enqueued in front of the kernel; word 0 != 0
+ * afterwards = a bounded spin timed out).  ONE persistent launch per device at a time.
+ * Tensors as for ag_lstm_seq_fwd (no hbuf: the state stays in registers). */
+int ag_lstm_persist_ok(int B, int H, int ndir, int n_cu);
+int64_t ag_lstm_persist_ws_bytes(int B, int H, int ndir);
+int ag_lstm_seq_fwd_persist(float* const* pre, const float* const* whh, float* const* c_all, float* y,
+                            const int64_t* valid_i64, const float* const* static_pre, void* ws, int64_t ws_bytes,
+                            int T, int B, int H, int ndir, int n_cu, void* stream);
+
 /* One fused backward step of the Generator front (audiogan.py:428-460: LSTMCell -> tanh(Linear) fed back), frame t:
  *   gx     = dxa * (1 - x_t^2)                        d(pre-tanh) of the projection, stored to gx_out [B,Kp]
  *   dh     = dh_acc + gx * w_proj                      w_proj [Kp = frame size, H]; dh_acc [B,H] rows, pitch lddh

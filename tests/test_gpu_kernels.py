@@ -372,9 +372,27 @@ def test_lstm_step_fwd(K, B, H, Kx):
         close(g_d, rg, rtol=1e-4); close(c_d, rc, rtol=1e-4); close(h_d, rh, rtol=1e-4)
 
 
+@pytest.mark.parametrize('persist', [True, False])
 @pytest.mark.parametrize('T,B,H,ndir,ragged', [(128, 64, 512, 2, True), (16, 128, 64, 2, True), (5, 3, 8, 2, True), (7, 33, 24, 1, False),
-                                               (1, 4, 16, 2, True), (6, 40, 96, 1, True), (9, 70, 32, 2, True), (3, 150, 512, 2, True)])
-def test_lstm_seq_fwd_bwd(K, T, B, H, ndir, ragged):
+                                               (1, 4, 16, 2, True), (6, 40, 96, 1, True), (9, 70, 32, 2, True), (3, 150, 512, 2, True),
+                                               (33, 128, 512, 2, True), (5, 70, 192, 1, True), (4, 33, 64, 2, False),
+                                               (3, 256, 256, 2, True)])
+def test_lstm_seq_fwd_bwd(K, T, B, H, ndir, ragged, persist):
+    """persist=True: shapes that fit the chip take the persistent weights-resident launch (lstm_persist.hip), the
+    others one launch per step; persist=False forces the per-step kernels for every shape"""
+    fits = K.lib.ag_lstm_persist_ok(B, H, ndir, 256)
+    if persist and not fits:
+        pytest.skip('shape does not take the persistent kernel')
+    old = K.PERSIST[0]
+    K.PERSIST[0] = persist
+    try:
+        _lstm_seq_case(K, T, B, H, ndir, ragged)
+        assert K.lstm_persist_status() == 0, 'a bounded wait of the persistent launch timed out'
+    finally:
+        K.PERSIST[0] = old
+
+
+def _lstm_seq_case(K, T, B, H, ndir, ragged):
     gen = torch.Generator().manual_seed(15)
     pre = [torch.randn(T, B, 4 * H, generator=gen) for _ in range(ndir)]
     whh = [torch.randn(4 * H, H, generator=gen) / H ** 0.5 for _ in range(ndir)]
