@@ -77,6 +77,10 @@ SIGNATURES = {
                                    C.c_int, C.c_int, vp]),
     'ag_lstm_seq_fwd': (C.c_int, [vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     'ag_lstm_seq_bwd': (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    'ag_bind_workspace': (C.c_int, [vp, i64]),
+    'ag_conv1d_wgrad_ws_numel': (i64, [C.c_int] * 5),
+    'ag_gemm_ws_numel': (i64, [C.c_int] * 4),
+    'ag_skinny_ws_numel': (i64, [C.c_int] * 3),
     'ag_lstm_persist_ok': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     'ag_lstm_persist_ws_bytes': (i64, [C.c_int, C.c_int, C.c_int]),
     'ag_lstm_seq_fwd_persist': (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),

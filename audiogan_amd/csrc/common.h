@@ -14,6 +14,21 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // last-error text (host side, one per process; the library is driven by one thread per GPU)
 void ag_set_error(const char* fmt, ...);
 
+// Two-stage reductions (deterministic: no float atomics).  A caller binds a workspace with ag_bind_workspace() right
+// before a reducing entry point; that entry point takes it (the binding is consumed) and sums partial results in a
+// fixed order with ag_slab_reduce().  Without a bound workspace the legacy float-atomic path runs.
+struct AgWs {
+  float* p;
+  int64_t numel;
+};
+AgWs ag_ws_take();
+// dst[i] (+)= sum_{z=0}^{Z-1} ws[z*n + i], z ascending
+int ag_slab_reduce(const float* ws, int Z, int64_t n, float* dst, int accumulate, hipStream_t st);
+
+// C[row*ldc+col] = beta*C + sum_{z<Z} part[(z*M+row)*N+col] + bias[col] + res[row*ldres+col]   (gemm.hip)
+int ag_splitk_reduce(const float* part, int Z, int M, int N, float* C, int ldc, float beta, const float* bias,
+                     const float* res, int ldres, hipStream_t st);
+
 #define AG_REQUIRE(cond, ...)     \
   do {                            \
     if (!(cond)) {                \

@@ -22,6 +22,7 @@ struct WgP {
   int lgp;      // LDS pitch of one lg channel row (odd)
   int maxch;    // channel rows staged per tile
   int vec;      // sh rows may be read with 16-byte loads
+  float* part;  // two-stage reduction: slab z = blockIdx.z of [A][CK] partial sums (plain stores); NULL -> atomics
 };
 
 // 8 waves: waves 0-3 multiply chunk i out of LDS buffer i&1 while waves 4-7 stage chunk i+1.
@@ -245,13 +246,27 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgP p) {
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         const int ck = ck0 + wn * 32 * TN + 32 * j + l31;
-        if (ck < p.CK) atomicAdd(p.dw + (int64_t)a * p.CK + ck, acc[i][j][e]);
+        if (ck >= p.CK) continue;
+        if (p.part) p.part[((int64_t)blockIdx.z * p.A + a) * p.CK + ck] = acc[i][j][e];
+        else atomicAdd(p.dw + (int64_t)a * p.CK + ck, acc[i][j][e]);
       }
     }
 }
 
+// reduction slices (grid.z) of the MFMA kernel for an [A x CK] gradient tiled AT x NT
+static int wgrad_slices(int A, int CK, int AT, int NT, int total) {
+  const int gx = ag_cdiv(CK, NT), gy = ag_cdiv(A, AT);
+  // ~2 workgroups of 8 waves per CU over the whole grid: every workgroup ends in a full tile of partial sums, so more
+  // splits cost more than their shorter chunk loops save (measured over the 15 layers: 256 / 512 / 1024 / 2048
+  // workgroups -> 1510 / 1218 / 1307 / 1522 us in total)
+  int gz = ag_cdiv(512, gx * gy);
+  if (gz > total) gz = total;
+  if (gz < 1) gz = 1;
+  return gz;
+}
+
 template <int TA, int TN, int WA, int WN>
-static int launch_wgrad(WgP& p, hipStream_t st) {
+static int launch_wgrad(WgP& p, hipStream_t st, AgWs ws) {
   constexpr int AT = 32 * TA * WA, NT = 32 * TN * WN;
   p.TC = AT >= 128 ? 32 : 64;   // keeps two LDS buffers of the 128x128 tile under 48 KiB (>= 2 workgroups per CU)
   if (p.Lsh < p.TC) p.TC = ag_roundup(p.Lsh, 4);
@@ -267,18 +282,20 @@ static int launch_wgrad(WgP& p, hipStream_t st) {
   }
   const int gx = ag_cdiv(p.CK, NT), gy = ag_cdiv(p.A, AT);
   const int total = p.B * p.nchunk;
-  // ~2 workgroups of 8 waves per CU over the whole grid: every workgroup ends in a full tile of atomics, so more
-  // splits cost more than their shorter chunk loops save (measured over the 15 layers: 256 / 512 / 1024 / 2048
-  // workgroups -> 1510 / 1218 / 1307 / 1522 us in total)
-  int gz = ag_cdiv(512, gx * gy);
-  if (gz > total) gz = total;
-  if (gz < 1) gz = 1;
+  int gz = wgrad_slices(p.A, p.CK, AT, NT, total);
+  const int64_t n_out = (int64_t)p.A * p.CK;
+  p.part = nullptr;
+  if (ws.p && ws.numel >= n_out) {         // two-stage, fixed-order reduction
+    if ((int64_t)gz * n_out > ws.numel) gz = (int)(ws.numel / n_out);
+    p.part = ws.p;
+  }
   auto kern = conv_wgrad_kernel<TA, TN, WA, WN>;
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds);
   hipLaunchKernelGGL(kern, dim3(gx, gy, gz), dim3(512), lds, st, p);
   AG_CHECK_LAUNCH("ag_conv1d_wgrad");
+  if (p.part) return ag_slab_reduce(p.part, gz, n_out, p.dw, 1, st);
   return AG_OK;
 }
 
@@ -288,7 +305,7 @@ template <int KMAX, int AG>
 __global__ __launch_bounds__(256) void conv_c1_wgrad_kernel(const float* __restrict__ sh, int64_t sh_bs, int64_t sh_cs,
                                                             const float* __restrict__ lg, int64_t lg_bs,
                                                             float* __restrict__ dw, int B, int A, int Lsh, int Llg,
-                                                            int K, int s, int p, int bper) {
+                                                            int K, int s, int p, int bper, float* __restrict__ part) {
   // a thread owns ONE time step (consecutive threads = consecutive steps: dy loads coalesce, x loads are s floats
   // apart) and AG output channels: the K-wide x window is loaded once per clip and reused by the AG channels
   __shared__ float red[4][AG * KMAX];
@@ -331,8 +348,11 @@ __global__ __launch_bounds__(256) void conv_c1_wgrad_kernel(const float* __restr
   __syncthreads();
   if (threadIdx.x < AG * KMAX) {
     const int i = threadIdx.x / KMAX, k = threadIdx.x % KMAX;
-    if (k < K && a0 + i < A)
-      atomicAdd(dw + (a0 + i) * K + k, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (k < K && a0 + i < A) {
+      const float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+      if (part) part[((int64_t)(blockIdx.z * gridDim.x + blockIdx.x) * A + a0 + i) * K + k] = v;
+      else atomicAdd(dw + (a0 + i) * K + k, v);
+    }
   }
 }
 
@@ -349,22 +369,49 @@ extern "C" int ag_conv1d_wgrad(const float* sh, int64_t sh_bs, int64_t sh_cs, co
   p.CK = C * K;
   p.vec = (((uintptr_t)sh & 15) == 0) && (sh_bs % 4 == 0) && (sh_cs % 4 == 0);
   hipStream_t st = (hipStream_t)stream;
+  const AgWs ws = ag_ws_take();
   if (C == 1 && K <= 8) {       // (K = 17, A = 128 - G1.conv - measured faster on the MFMA path: 43 vs 88 us)
     const int ag = 8;
     const int gx = ag_cdiv(Lsh, 256), gy = ag_cdiv(A, ag);
-    int gz = ag_cdiv(512, gx * gy);     // ~2 workgroups per CU: each ends in AG*K atomics on a handful of lines
+    int gz = ag_cdiv(512, gx * gy);     // ~2 workgroups per CU: each ends in AG*K partial sums
     if (gz > B) gz = B;
     if (gz < 1) gz = 1;
+    float* part = nullptr;
+    if (ws.p && ws.numel >= (int64_t)gx * A * K) {
+      if ((int64_t)gz * gx * A * K > ws.numel) gz = (int)(ws.numel / ((int64_t)gx * A * K));
+      part = ws.p;
+    }
     const int bper = ag_cdiv(B, gz);
     gz = ag_cdiv(B, bper);
     hipLaunchKernelGGL((conv_c1_wgrad_kernel<8, 8>), dim3(gx, gy, gz), dim3(256), 0, st, sh, sh_bs, sh_cs, lg, lg_bs,
-                       dw, B, A, Lsh, Llg, K, stride, pad, bper);
+                       dw, B, A, Lsh, Llg, K, stride, pad, bper, part);
     AG_CHECK_LAUNCH("ag_conv1d_wgrad");
+    if (part) return ag_slab_reduce(part, gx * gz, (int64_t)A * K, dw, 1, st);
     return AG_OK;
   }
-  if (A <= 32) return launch_wgrad<1, 1, 1, 4>(p, st);             // 32 x 128
-  if (A <= 64 || p.CK <= 64) return launch_wgrad<1, 1, 2, 2>(p, st);  // 64 x 64
-  return launch_wgrad<2, 2, 2, 2>(p, st);                           // 128 x 128
+  if (A <= 32) return launch_wgrad<1, 1, 1, 4>(p, st, ws);             // 32 x 128
+  if (A <= 64 || p.CK <= 64) return launch_wgrad<1, 1, 2, 2>(p, st, ws);  // 64 x 64
+  return launch_wgrad<2, 2, 2, 2>(p, st, ws);                           // 128 x 128
+}
+
+// floats of workspace ag_conv1d_wgrad wants bound (ag_bind_workspace) for its two-stage reduction
+extern "C" int64_t ag_conv1d_wgrad_ws_numel(int B, int A, int Lsh, int C, int K) {
+  if (C == 1 && K <= 8) {
+    const int gx = ag_cdiv(Lsh, 256), gy = ag_cdiv(A, 8);
+    int gz = ag_cdiv(512, gx * gy);
+    if (gz > B) gz = B;
+    if (gz < 1) gz = 1;
+    return (int64_t)gz * gx * A * K;
+  }
+  const int CK = C * K;
+  int AT, NT;
+  if (A <= 32) { AT = 32; NT = 128; }
+  else if (A <= 64 || CK <= 64) { AT = 64; NT = 64; }
+  else { AT = 128; NT = 128; }
+  int TC = AT >= 128 ? 32 : 64;
+  if (Lsh < TC) TC = ag_roundup(Lsh, 4);
+  const int total = B * ag_cdiv(Lsh, TC);
+  return (int64_t)wgrad_slices(A, CK, AT, NT, total) * A * CK;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -372,7 +419,7 @@ extern "C" int ag_conv1d_wgrad(const float* sh, int64_t sh_bs, int64_t sh_cs, co
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restrict__ dy, int64_t bs,
                                                           int64_t cs, float* __restrict__ db, int B,
-                                                          int C, int L, int nsplit) {
+                                                          int C, int L, int nsplit, float* __restrict__ part) {
   __shared__ float red[17];
   const int c = blockIdx.x;
   const int64_t total = (int64_t)B * L;
@@ -383,7 +430,10 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restric
     s += dy[(int64_t)b * bs + (int64_t)c * cs + t];
   }
   s = ag_block_sum(s, red);
-  if (threadIdx.x == 0) atomicAdd(db + c, s);
+  if (threadIdx.x == 0) {
+    if (part) part[(int64_t)blockIdx.y * C + c] = s;
+    else atomicAdd(db + c, s);
+  }
 }
 
 extern "C" int ag_channel_sum(const float* dy, int64_t bs, int64_t cs, float* db, int B, int C, int L,
@@ -393,9 +443,16 @@ extern "C" int ag_channel_sum(const float* dy, int64_t bs, int64_t cs, float* db
   const int cap = ag_cdiv(2048, C);
   if (nsplit > cap) nsplit = cap;
   if (nsplit < 1) nsplit = 1;
+  const AgWs ws = ag_ws_take();
+  float* part = nullptr;
+  if (ws.p && ws.numel >= C) {
+    if ((int64_t)nsplit * C > ws.numel) nsplit = (int)(ws.numel / C);
+    part = ws.p;
+  }
   hipLaunchKernelGGL(channel_sum_kernel, dim3(C, nsplit), dim3(256), 0, (hipStream_t)stream, dy, bs,
-                     cs, db, B, C, L, nsplit);
+                     cs, db, B, C, L, nsplit, part);
   AG_CHECK_LAUNCH("ag_channel_sum");
+  if (part) return ag_slab_reduce(part, nsplit, C, db, 1, (hipStream_t)stream);
   return AG_OK;
 }
 
@@ -410,7 +467,7 @@ __global__ __launch_bounds__(256) void leaky_bwd_kernel(const float* __restrict_
                                                         int64_t ad_bs, int64_t ad_cs,
                                                         const int64_t* __restrict__ lens,
                                                         float* __restrict__ bias_grad, int B, int C,
-                                                        int L, int bper, float slope) {
+                                                        int L, int bper, float slope, float* __restrict__ part) {
   const int c = blockIdx.y;
   float bsum = 0.f;
   // bper clips per workgroup: with a bias gradient every workgroup ends in ONE atomic, and all channels of a
@@ -435,7 +492,11 @@ __global__ __launch_bounds__(256) void leaky_bwd_kernel(const float* __restrict_
     bsum = ag_wave_sum(bsum);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = bsum;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(bias_grad + c, red[0] + red[1] + red[2] + red[3]);
+    if (threadIdx.x == 0) {
+      const float v = red[0] + red[1] + red[2] + red[3];
+      if (part) part[(int64_t)(blockIdx.z * gridDim.x + blockIdx.x) * C + c] = v;
+      else atomicAdd(bias_grad + c, v);
+    }
   }
 }
 
@@ -448,15 +509,24 @@ extern "C" int ag_leaky_bwd(const float* dy, int64_t dy_bs, int64_t dy_cs, const
   int gx = ag_cdiv(L, 256 * 4);
   if (gx < 1) gx = 1;
   int bper = 1;
+  const AgWs ws = ag_ws_take();
+  float* part = nullptr;
   if (bias_grad) {
     bper = (int)(((int64_t)gx * C * B) / 2048);
     if (bper < 8) bper = 8;
     if (bper > B) bper = B;
+    if (ws.p && ws.numel >= (int64_t)gx * C) {      // partial sums per (x, z) block, fixed-order second stage
+      const int64_t zmax = ws.numel / ((int64_t)gx * C);
+      if (ag_cdiv(B, bper) > zmax) bper = ag_cdiv(B, (int)zmax);
+      part = ws.p;
+    }
   }
-  hipLaunchKernelGGL(leaky_bwd_kernel, dim3(gx, C, ag_cdiv(B, bper)), dim3(256), 0, (hipStream_t)stream, dy, dy_bs,
+  const int gz = ag_cdiv(B, bper);
+  hipLaunchKernelGGL(leaky_bwd_kernel, dim3(gx, C, gz), dim3(256), 0, (hipStream_t)stream, dy, dy_bs,
                      dy_cs, y, y_bs, y_cs, dpre, dp_bs, dp_cs, add_into, ad_bs, ad_cs, lens_i64, bias_grad, B, C, L,
-                     bper, slope);
+                     bper, slope, part);
   AG_CHECK_LAUNCH("ag_leaky_bwd");
+  if (part) return ag_slab_reduce(part, gx * gz, C, bias_grad, 1, (hipStream_t)stream);
   return AG_OK;
 }
 
@@ -537,7 +607,7 @@ __global__ __launch_bounds__(256) void conv_o1_bwdx_kernel(const float* __restri
 __global__ __launch_bounds__(256) void conv_o1_wgrad_kernel(const float* __restrict__ dy, int64_t dy_bs,
                                                             const float* __restrict__ x, int64_t x_bs, int64_t x_cs,
                                                             float* __restrict__ dw, int B, int C, int L, int K, int p,
-                                                            int bper) {
+                                                            int bper, float* __restrict__ part) {
   __shared__ float red[17];
   const int c = blockIdx.y;
   const int t0 = (blockIdx.x * 256 + threadIdx.x) * 4;
@@ -575,7 +645,10 @@ __global__ __launch_bounds__(256) void conv_o1_wgrad_kernel(const float* __restr
   for (int k = 0; k < O1_MAXK; ++k) {
     if (k < K) {      // uniform
       const float s = ag_block_sum(acc[k], red);
-      if (threadIdx.x == 0) atomicAdd(dw + c * K + k, s);
+      if (threadIdx.x == 0) {
+        if (part) part[((int64_t)(blockIdx.z * gridDim.x + blockIdx.x) * C + c) * K + k] = s;
+        else atomicAdd(dw + c * K + k, s);
+      }
     }
   }
 }
@@ -612,10 +685,17 @@ extern "C" int ag_conv1d_o1_wgrad(const float* dy, int64_t dy_bs, const float* x
   int gz = ag_cdiv(2048, gx * C);
   if (gz > B) gz = B;
   if (gz < 1) gz = 1;
+  const AgWs ws = ag_ws_take();
+  float* part = nullptr;
+  if (ws.p && ws.numel >= (int64_t)gx * C * K) {
+    if ((int64_t)gz * gx * C * K > ws.numel) gz = (int)(ws.numel / ((int64_t)gx * C * K));
+    part = ws.p;
+  }
   const int bper = ag_cdiv(B, gz);
   gz = ag_cdiv(B, bper);
   hipLaunchKernelGGL(conv_o1_wgrad_kernel, dim3(gx, C, gz), dim3(256), 0, (hipStream_t)stream, dy, dy_bs, x, x_bs,
-                     x_cs, dw, B, C, L, K, pad, bper);
+                     x_cs, dw, B, C, L, K, pad, bper, part);
   AG_CHECK_LAUNCH("ag_conv1d_o1_wgrad");
+  if (part) return ag_slab_reduce(part, gx * gz, (int64_t)C * K, dw, 1, (hipStream_t)stream);
   return AG_OK;
 }

@@ -27,8 +27,10 @@ struct GemmP {
   float alpha, beta, slope;
   int act;
   int vecA, vecB;  // 16-B vector loads allowed for A / B
-  int ksplit;      // > 1: grid.z K slices, fp32 atomic epilogue into a pre-initialised C
+  int ksplit;      // > 1: grid.z K slices; partial tiles go to `part` (two-stage, fixed-order reduction) or, when
+                   // part == NULL, are added with fp32 atomics into a pre-initialised C
   int kchunk;      // K per slice (multiple of GBK)
+  float* part;     // [ksplit][M][N] partial products (alpha applied), or NULL
 };
 
 // Tile loaders, split into "global -> registers" and "registers -> LDS" so that the loads of
@@ -270,6 +272,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
         float v = p.alpha * acc[i][j][e];
         float* dst = p.C + (int64_t)row * p.ldc + col;
         if (p.ksplit > 1) {
+          if (p.part) {
+            p.part[((int64_t)blockIdx.z * p.M + row) * p.N + col] = v;
+            continue;
+          }
           if (blockIdx.z == 0) {
             if (p.bias) v += p.bias[col];
             if (p.res) v += p.res[(int64_t)row * p.ldres + col];
@@ -432,6 +438,10 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmP p) {
         float v = p.alpha * acc[i][j][e];
         float* dst = p.C + (int64_t)row * p.ldc + col;
         if (p.ksplit > 1) {
+          if (p.part) {
+            p.part[((int64_t)blockIdx.z * p.M + row) * p.N + col] = v;
+            continue;
+          }
           if (blockIdx.z == 0) {
             if (p.bias) v += p.bias[col];
             if (p.res) v += p.res[(int64_t)row * p.ldres + col];
@@ -445,6 +455,34 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmP p) {
         *dst = ag_apply_act(v, p.act, p.slope);
       }
     }
+}
+
+// second stage of a split-K product: C = beta*C + sum_z part[z] + bias + res  (z ascending)
+__global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float* __restrict__ part, int Z, int M, int N,
+                                                                 float* __restrict__ C, int ldc, float beta,
+                                                                 const float* __restrict__ bias,
+                                                                 const float* __restrict__ res, int ldres) {
+  const int64_t mn = (int64_t)M * N;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < mn; i += (int64_t)gridDim.x * 256) {
+    const int row = (int)(i / N), col = (int)(i - (int64_t)row * N);
+    float s = part[i];
+    for (int z = 1; z < Z; ++z) s += part[(int64_t)z * mn + i];
+    float* dst = C + (int64_t)row * ldc + col;
+    if (beta != 0.f) s += beta * *dst;
+    if (bias) s += bias[col];
+    if (res) s += res[(int64_t)row * ldres + col];
+    *dst = s;
+  }
+}
+
+int ag_splitk_reduce(const float* part, int Z, int M, int N, float* C, int ldc, float beta, const float* bias,
+                     const float* res, int ldres, hipStream_t st) {
+  const int64_t mn = (int64_t)M * N;
+  int g = (int)ag_cdiv64(mn, 256);
+  if (g > 2048) g = 2048;
+  hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(g), dim3(256), 0, st, part, Z, M, N, C, ldc, beta, bias, res, ldres);
+  AG_CHECK_LAUNCH("ag_splitk_reduce");
+  return AG_OK;
 }
 
 static int launch_gemm_dma(const GemmP& p, int ta, int tb, hipStream_t st) {
@@ -492,17 +530,25 @@ extern "C" int ag_gemm(const float* A, int lda, int ta, const float* B, int ldb,
   const int64_t big = (int64_t)ag_cdiv(M, 128) * ag_cdiv(N, 128);
   const bool use128 = M > 64 && N > 64 && (big >= 192 || K >= 2048);
   const int64_t tiles = use128 ? big : (int64_t)ag_cdiv(M, 64) * ag_cdiv(N, 64);
-  // few output tiles but a long reduction (weight gradients over all frames): slice K over
-  // grid.z and combine with atomics.  Needs a linear epilogue on a C that already holds beta*C.
-  if (tiles < 192 && K >= 1024 && act == AG_ACT_NONE && (beta == 0.f || beta == 1.f)) {
+  // few output tiles but a long reduction (weight gradients over all frames): slice K over grid.z.  With a bound
+  // workspace the slices' partial tiles are summed in a fixed order by a second kernel (deterministic); without one
+  // they are combined with atomics.  Needs a linear epilogue.
+  p.part = nullptr;
+  const AgWs ws = ag_ws_take();
+  if (tiles < 192 && K >= 1024 && act == AG_ACT_NONE) {
     int ks = (int)(512 / tiles);
     if (ks > K / 256) ks = K / 256;
     if (ks > 32) ks = 32;
-    if (ks >= 2) {
+    const int64_t mn = (int64_t)M * N;
+    const bool slabs = ws.p && ws.numel >= 2 * mn;
+    if (slabs && (int64_t)ks * mn > ws.numel) ks = (int)(ws.numel / mn);
+    if (ks >= 2 && (slabs || beta == 0.f || beta == 1.f)) {
       p.ksplit = ks;
       p.kchunk = ag_roundup(ag_cdiv(K, ks), GBK);
       p.ksplit = ag_cdiv(K, p.kchunk);
-      if (beta == 0.f) {
+      if (slabs) {
+        p.part = ws.p;
+      } else if (beta == 0.f) {
         if (ldc == N) {
           if (hipMemsetAsync(C, 0, sizeof(float) * (size_t)M * N, st) != hipSuccess) {
             ag_set_error("ag_gemm: memset failed");
@@ -516,21 +562,38 @@ extern "C" int ag_gemm(const float* A, int lda, int ta, const float* B, int ldb,
       }
     }
   }
+  int rc;
   if (use128) {
     // LDS-DMA variant: whole 16-k tiles only, 16-byte aligned rows, row-contiguous operands with rows % 4 == 0
     // (AG_GEMM_NODMA=1 in the environment forces the register-staged kernel: A/B switch for tools/prof_gemm.py)
     const bool dma = p.vecA && p.vecB && K % 16 == 0 && p.kchunk % 16 == 0 && (ta == 0 || M % 4 == 0) &&
                      (tb == 1 || N % 4 == 0) && M >= 4 && N >= 4 && getenv("AG_GEMM_NODMA") == nullptr;
-    if (dma) return launch_gemm_dma(p, ta, tb, st);
-    return launch_gemm<2, 2, 2, 2>(p, ta, tb, st);  // 128x128
+    rc = dma ? launch_gemm_dma(p, ta, tb, st) : launch_gemm<2, 2, 2, 2>(p, ta, tb, st);  // 128x128
+  } else {
+    rc = launch_gemm<1, 1, 2, 2>(p, ta, tb, st);              // 64x64
   }
-  return launch_gemm<1, 1, 2, 2>(p, ta, tb, st);              // 64x64
+  if (rc != AG_OK || !p.part) return rc;
+  return ag_splitk_reduce(p.part, p.ksplit, M, N, C, ldc, beta, bias, res, ldres, st);
+}
+
+// floats of workspace ag_gemm wants bound (ag_bind_workspace) so that a split-K product is reduced in two stages
+extern "C" int64_t ag_gemm_ws_numel(int M, int N, int K, int act) {
+  const int64_t big = (int64_t)ag_cdiv(M, 128) * ag_cdiv(N, 128);
+  const bool use128 = M > 64 && N > 64 && (big >= 192 || K >= 2048);
+  const int64_t tiles = use128 ? big : (int64_t)ag_cdiv(M, 64) * ag_cdiv(N, 64);
+  if (!(tiles < 192 && K >= 1024 && act == AG_ACT_NONE)) return 0;
+  int ks = (int)(512 / tiles);
+  if (ks > K / 256) ks = K / 256;
+  if (ks > 32) ks = 32;
+  // cap the slab traffic (2 * ks * M * N * 4 B): beyond ~8 slices of a large output it costs more than it buys
+  while (ks > 2 && (int64_t)ks * M * N > ((int64_t)8 << 20)) --ks;
+  return ks >= 2 ? (int64_t)ks * M * N : 0;
 }
 
 // out[n] += sum_m X[m, n]
 __global__ __launch_bounds__(256) void col_sum_kernel(const float* __restrict__ X, int ldx,
                                                       float* __restrict__ out, int M, int N,
-                                                      int rows_per) {
+                                                      int rows_per, float* __restrict__ part) {
   const int n = blockIdx.x * 64 + (threadIdx.x & 63);
   const int sub = threadIdx.x >> 6;  // 4 row-phases per block
   const int mbeg = blockIdx.y * rows_per;
@@ -544,7 +607,8 @@ __global__ __launch_bounds__(256) void col_sum_kernel(const float* __restrict__ 
   __syncthreads();
   if (sub == 0 && n < N) {
     s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-    atomicAdd(out + n, s);
+    if (part) part[(int64_t)blockIdx.y * N + n] = s;
+    else atomicAdd(out + n, s);
   }
 }
 
@@ -554,9 +618,17 @@ extern "C" int ag_col_sum(const float* X, int ldx, float* out, int M, int N, voi
   int gy = ag_cdiv(1024, gx);
   if (gy > ag_cdiv(M, 16)) gy = ag_cdiv(M, 16);
   if (gy < 1) gy = 1;
+  const AgWs ws = ag_ws_take();
+  float* part = nullptr;
+  if (gy > 1 && ws.p && ws.numel >= 2 * (int64_t)N) {   // (one row block: a single writer per column, nothing to order)
+    if ((int64_t)gy * N > ws.numel) gy = (int)(ws.numel / N);
+    part = ws.p;
+  }
   const int rows_per = ag_cdiv(M, gy);
+  gy = ag_cdiv(M, rows_per);
   hipLaunchKernelGGL(col_sum_kernel, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, X, ldx, out, M,
-                     N, rows_per);
+                     N, rows_per, part);
   AG_CHECK_LAUNCH("ag_col_sum");
+  if (part) return ag_slab_reduce(part, gy, N, out, 1, (hipStream_t)stream);
   return AG_OK;
 }

@@ -131,6 +131,8 @@ __global__ __launch_bounds__(512) void lstm_persist_fwd_kernel(const PersistFwdP
     f32x16 acc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    bool sv_pad = false;
+    float sv_ig = 0.f, sv_fg = 0.f, sv_gg = 0.f, sv_og = 0.f, sv_y = 0.f;
     if (k > 0) {
       if (wid == 0 && alive) alive = ps_wait_flags(p.hdr, flags, ntile, (unsigned)k, lane);
       __syncthreads();
@@ -175,30 +177,37 @@ __global__ __launch_bounds__(512) void lstm_persist_fwd_kernel(const PersistFwdP
         g4[g] = s;
       }
       const bool padded = t >= vlen;
-      float yv = 0.f;
+      float yv = 0.f, ig = 0.f, fg = 0.f, gg = 0.f, og = 0.f;
       if (!padded) {
-        const float ig = ag_sigmoid(g4[0]), fg = ag_sigmoid(g4[1]), gg = tanhf(g4[2]), og = ag_sigmoid(g4[3]);
+        ig = ag_sigmoid(g4[0]); fg = ag_sigmoid(g4[1]); gg = tanhf(g4[2]); og = ag_sigmoid(g4[3]);
         creg = fg * creg + ig * gg;
         hreg = og * tanhf(creg);
         yv = hreg;
-        float* pr = D.pre + ((int64_t)t * B + em) * 4 * H + eu;
-        pr[0] = ig; pr[H] = fg; pr[2 * H] = gg; pr[3 * H] = og;
       }
-      // publish h_k first (write-through), then the rest
-      if (k + 1 < T)
+      // publish h_k FIRST (write-through); the stores nobody waits for (gates, cell, output) go out after the flag
+      if (k + 1 < T) {
         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(hreg), xr,
             (unsigned)(((int64_t)((k & 1) * ngroups + grp) * xg + ((int64_t)ut * ROWS + erow) * 8 + euu) * 4), 0, 16 /* sc1 */);
-      D.c_all[((int64_t)(k + 1) * B + em) * H + eu] = creg;
-      p.y[((int64_t)t * B + em) * p.ndir * H + (int64_t)dir * H + eu] = yv;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // EVERY storing wave drains its write-through stores
+      }
+      sv_pad = padded; sv_ig = ig; sv_fg = fg; sv_gg = gg; sv_og = og; sv_y = yv;
     } else if (ethread && k + 1 < T) {
       // rows past the batch: keep the exchange buffer defined (the consumers' MFMA rows that read it are never stored)
       __builtin_amdgcn_raw_buffer_store_b32(0u, xr,
           (unsigned)(((int64_t)((k & 1) * ngroups + grp) * xg + ((int64_t)ut * ROWS + erow) * 8 + euu) * 4), 0, 16);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     if (k + 1 < T) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // EVERY storing wave drains its write-through stores
       __syncthreads();
       if (tid == 0) __hip_atomic_store(flags + ut, (unsigned)(k + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (epi) {
+      if (!sv_pad) {
+        float* pr = D.pre + ((int64_t)t * B + em) * 4 * H + eu;
+        pr[0] = sv_ig; pr[H] = sv_fg; pr[2 * H] = sv_gg; pr[3 * H] = sv_og;
+      }
+      D.c_all[((int64_t)(k + 1) * B + em) * H + eu] = creg;
+      p.y[((int64_t)t * B + em) * p.ndir * H + (int64_t)dir * H + eu] = sv_y;
     }
   }
 }

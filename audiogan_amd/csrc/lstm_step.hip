@@ -36,6 +36,8 @@ struct SkinnyP {
   int act;
   float slope, beta;
   int mtiles;    // grid.z = nprob * mtiles
+  float* part;   // K split over workgroups (gridDim.y > 1): partial [gridDim.y][nprob][M][N] (two-stage reduction)
+                 // or NULL -> fp32 atomics into C
 };
 
 // A rows m0..m0+31 (k contiguous) x B rows (k contiguous), K range [k0,k1) (multiples of 8).
@@ -180,6 +182,9 @@ __global__ __launch_bounds__(1024) void skinny_gemm_kernel(const SkinnyP p) {
       if (p.beta != 0.f) v += p.beta * *dst;
       if (Q.bias) v += Q.bias[n];
       *dst = ag_apply_act(v, p.act, p.slope);
+    } else if (p.part) {
+      const int prob = blockIdx.z / p.mtiles, nprob = gridDim.z / p.mtiles;
+      p.part[(((int64_t)blockIdx.y * nprob + prob) * p.M + m) * p.N + n] = v;
     } else {
       if (Q.bias && blockIdx.y == 0) v += Q.bias[n];
       atomicAdd(dst, v);
@@ -232,7 +237,31 @@ __global__ __launch_bounds__(1024) void skinny16_nt_kernel(const SkinnyP p) {
   *dst = ag_apply_act(v, p.act, p.slope);
 }
 
-static int launch_skinny(SkinnyP& p, int nprob, int accumulate_atomic, hipStream_t st) {
+// C[m*ldc+n] += sum_{z<Z} part[z*pitch + m*N + n] (+ bias[n]), z ascending
+__global__ __launch_bounds__(256) void skinny_reduce_kernel(const float* __restrict__ part, int Z, int64_t pitch, int M,
+                                                            int N, float* __restrict__ C, int ldc,
+                                                            const float* __restrict__ bias) {
+  const int64_t mn = (int64_t)M * N;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < mn; i += (int64_t)gridDim.x * 256) {
+    const int m = (int)(i / N), n = (int)(i - (int64_t)m * N);
+    float s = part[i];
+    for (int z = 1; z < Z; ++z) s += part[(int64_t)z * pitch + i];
+    if (bias) s += bias[n];
+    C[(int64_t)m * ldc + n] += s;
+  }
+}
+
+static int ag_splitk_reduce_strided(const float* part, int Z, int64_t pitch, int M, int N, float* C, int ldc,
+                                    const float* bias, hipStream_t st) {
+  int g = (int)ag_cdiv64((int64_t)M * N, 256);
+  if (g > 1024) g = 1024;
+  hipLaunchKernelGGL(skinny_reduce_kernel, dim3(g), dim3(256), 0, st, part, Z, pitch, M, N, C, ldc, bias);
+  AG_CHECK_LAUNCH("ag_skinny_gemm(reduce)");
+  return AG_OK;
+}
+
+static int launch_skinny(SkinnyP& p, int nprob, int accumulate_atomic, hipStream_t st, AgWs ws = AgWs{nullptr, 0}) {
+  p.part = nullptr;
   const int gx = ag_cdiv(p.N, 32);
   const int KU = p.K / 8;
   p.mtiles = ag_cdiv(p.M, 32);
@@ -251,7 +280,12 @@ static int launch_skinny(SkinnyP& p, int nprob, int accumulate_atomic, hipStream
     nw = 4;
     gy = ag_cdiv(4096, gx * gz * nw);
     if (gy * nw > KU) gy = ag_cdiv(KU, nw);
-    if (gy < 2) gy = 2;  // keep the atomic epilogue (C holds the addend)
+    if (gy < 2) gy = 2;  // keep the split epilogue (C holds the addend)
+    const int64_t slab = (int64_t)nprob * p.M * p.N;
+    if (ws.p && ws.numel >= 2 * slab) {     // two-stage: partial products, then a fixed-order sum into C
+      if ((int64_t)gy * slab > ws.numel) gy = (int)(ws.numel / slab);
+      p.part = ws.p;
+    }
   } else {
     gy = 1;
     nw = ag_cdiv(2048, gx * gz);
@@ -262,7 +296,24 @@ static int launch_skinny(SkinnyP& p, int nprob, int accumulate_atomic, hipStream
   const size_t lds = (size_t)nw * 1024 * sizeof(float);
   hipLaunchKernelGGL(skinny_gemm_kernel, dim3(gx, gy, gz), dim3(64 * nw), lds, st, p);
   AG_CHECK_LAUNCH("ag_skinny_gemm");
+  if (p.part) {
+    for (int q = 0; q < nprob; ++q) {
+      // slab z of problem q starts at part + (z*nprob + q)*M*N: present it as Z slabs of pitch nprob*M*N
+      const int rc = ag_splitk_reduce_strided(p.part + (int64_t)q * p.M * p.N, gy, (int64_t)nprob * p.M * p.N, p.M, p.N,
+                                              p.q[q].C, p.ldc, p.q[q].bias, st);
+      if (rc != AG_OK) return rc;
+    }
+  }
   return AG_OK;
+}
+
+// floats of workspace ag_skinny_gemm (accumulate mode) wants bound for its two-stage reduction
+extern "C" int64_t ag_skinny_ws_numel(int M, int N, int K) {
+  const int gx = ag_cdiv(N, 32), gz = ag_cdiv(M, 32), KU = K / 8;
+  int gy = ag_cdiv(4096, gx * gz * 4);
+  if (gy * 4 > KU) gy = ag_cdiv(KU, 4);
+  if (gy < 2) gy = 2;
+  return (int64_t)gy * M * N;
 }
 
 extern "C" int ag_skinny_gemm(const float* A, int lda, const float* B, int ldb, int tb, float* C, int ldc,
@@ -278,7 +329,7 @@ extern "C" int ag_skinny_gemm(const float* A, int lda, const float* B, int ldb, 
   p.q[1] = p.q[0];
   p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.M = M; p.N = N; p.K = K; p.tb = tb; p.act = act;
   p.slope = slope; p.beta = beta;
-  return launch_skinny(p, 1, accumulate_atomic, (hipStream_t)stream);
+  return launch_skinny(p, 1, accumulate_atomic, (hipStream_t)stream, ag_ws_take());
 }
 
 // ------------------------------------------------------------------------------------------
@@ -769,6 +820,7 @@ extern "C" int ag_lstm_seq_bwd(const float* const* gates, const float* const* wh
   AG_REQUIRE(T > 0 && B > 0 && B <= 256 && (4 * H) % 8 == 0, "ag_lstm_seq_bwd: bad shape");
   AG_REQUIRE(0 <= k_begin && k_begin <= k_end && k_end <= T, "ag_lstm_seq_bwd: bad step range");
   hipStream_t st = (hipStream_t)stream;
+  const AgWs ws = ag_ws_take();     // (only the unfused fallback below reduces across workgroups)
   const int64_t BH = (int64_t)B * H, BG = (int64_t)B * 4 * H;
   if (phases == 3 && H % 16 == 0) {
     // fused path: launch k = product of step k+1 + cell backward of step k
@@ -829,7 +881,7 @@ extern "C" int ag_lstm_seq_bwd(const float* const* gates, const float* const* wh
       AG_CHECK_LAUNCH("ag_lstm_seq_bwd(cell)");
     }
     if (k > 0 && (phases & 2)) {
-      int rc = launch_skinny(s, ndir, 1, st);
+      int rc = launch_skinny(s, ndir, 1, st, ws);
       if (rc != AG_OK) return rc;
     }
   }

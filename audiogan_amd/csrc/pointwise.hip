@@ -206,19 +206,30 @@ __global__ __launch_bounds__(256) void bce_fwd_kernel(const float* __restrict__ 
     s += v - v * target + m + logf(expf(-m) + expf(-v - m));
   }
   s = ag_wave_sum(s);
-  if (lane == 0) {
-    if (per) per[b] = s;
-    if (loss) atomicAdd(loss, scale * s / (float)n);
-  }
+  if (lane == 0) per[b] = s;
+}
+
+// loss[0] += scale * sum_b per[b] / n[b], in a fixed order (one wave)
+__global__ __launch_bounds__(64) void bce_finish_kernel(const float* __restrict__ per, const int64_t* __restrict__ nfr,
+                                                        float* __restrict__ loss, float scale, int B, int T) {
+  float s = 0.f;
+  for (int b = threadIdx.x; b < B; b += 64) s += per[b] / (float)(nfr ? nfr[b] : (int64_t)T);
+  s = ag_wave_sum(s);
+  if (threadIdx.x == 0) loss[0] += scale * s;
 }
 
 extern "C" int ag_bce_logits_fwd(const float* x, int ldx, float target, const int64_t* nframes_i64,
                                  float* per_sample, float* loss, float scale, int B, int T,
                                  void* stream) {
-  AG_REQUIRE(x && (per_sample || loss) && B > 0 && T > 0 && ldx >= T, "ag_bce_logits_fwd: bad args");
+  AG_REQUIRE(x && per_sample && B > 0 && T > 0 && ldx >= T, "ag_bce_logits_fwd: bad args (per_sample is required)");
   hipLaunchKernelGGL(bce_fwd_kernel, dim3(ag_cdiv(B, 4)), dim3(256), 0, (hipStream_t)stream, x, ldx,
                      target, nframes_i64, per_sample, loss, scale, B, T);
   AG_CHECK_LAUNCH("ag_bce_logits_fwd");
+  if (loss) {
+    hipLaunchKernelGGL(bce_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, per_sample, nframes_i64, loss,
+                       scale, B, T);
+    AG_CHECK_LAUNCH("ag_bce_logits_fwd(finish)");
+  }
   return AG_OK;
 }
 
@@ -310,7 +321,7 @@ extern "C" int ag_axpby(const float* x, float* y, int64_t n, float a, float b, v
 
 __global__ __launch_bounds__(256) void grad_norms_kernel(const ag_opt_desc* __restrict__ descs,
                                                          float* __restrict__ sq, int32_t* __restrict__ flags,
-                                                         float gscale) {
+                                                         float gscale, float* __restrict__ part) {
   __shared__ float red[17];
   const ag_opt_desc d = descs[blockIdx.y];
   float s = 0.f;
@@ -321,19 +332,30 @@ __global__ __launch_bounds__(256) void grad_norms_kernel(const ag_opt_desc* __re
     if (g != g) f |= AG_FLAG_NAN;
     if (fabsf(g) > 1e5f) f |= AG_FLAG_BIG;
   }
-  if ((int64_t)blockIdx.x * 256 >= d.n) return;  // uniform per block
+  if ((int64_t)blockIdx.x * 256 >= d.n) {  // uniform per block
+    if (part && threadIdx.x == 0) part[(int64_t)blockIdx.y * OPT_CHUNKS + blockIdx.x] = 0.f;
+    return;
+  }
   s = ag_block_sum(s, red);
-  if (threadIdx.x == 0) atomicAdd(sq + blockIdx.y, s);
+  if (threadIdx.x == 0) {
+    if (part) part[(int64_t)blockIdx.y * OPT_CHUNKS + blockIdx.x] = s;
+    else atomicAdd(sq + blockIdx.y, s);
+  }
   if (f && flags) atomicOr(flags, f);
 }
 
 __global__ void grad_norms_finish_kernel(float* __restrict__ sq_to_norm, float* __restrict__ norm_sum,
-                                         int n, int32_t* __restrict__ step_dev) {
+                                         int n, int32_t* __restrict__ step_dev, const float* __restrict__ part) {
   if (threadIdx.x == 0 && step_dev) step_dev[0] += 1;
   // single block: norms[i] = sqrt(sq[i]); norm_sum = sum_i norms[i] (deterministic order)
   __shared__ float red[17];
   float s = 0.f;
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    if (part) {          // sum of squares of tensor i = its per-chunk partials in chunk order
+      float q = 0.f;
+      for (int c = 0; c < OPT_CHUNKS; ++c) q += part[(int64_t)i * OPT_CHUNKS + c];
+      sq_to_norm[i] = q;
+    }
     const float nr = sqrtf(sq_to_norm[i]);
     sq_to_norm[i] = nr;
     s += nr;
@@ -346,15 +368,17 @@ extern "C" int ag_grad_norms(const ag_opt_desc* descs_dev, int n, float* norms, 
                              int32_t* flags, float grad_scale, int32_t* step_dev, void* stream) {
   AG_REQUIRE(descs_dev && norms && n > 0 && n <= 65535, "ag_grad_norms: bad args");
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(norms, 0, sizeof(float) * n, st) != hipSuccess) {
+  const AgWs ws = ag_ws_take();
+  float* part = (ws.p && ws.numel >= (int64_t)n * OPT_CHUNKS) ? ws.p : nullptr;    // two-stage sum of squares
+  if (!part && hipMemsetAsync(norms, 0, sizeof(float) * n, st) != hipSuccess) {
     ag_set_error("ag_grad_norms: memset failed");
     return AG_ERR_LAUNCH;
   }
   if (flags) (void)hipMemsetAsync(flags, 0, sizeof(int32_t), st);
   hipLaunchKernelGGL(grad_norms_kernel, dim3(OPT_CHUNKS, n), dim3(256), 0, st, descs_dev, norms, flags,
-                     grad_scale);
+                     grad_scale, part);
   AG_CHECK_LAUNCH("ag_grad_norms");
-  hipLaunchKernelGGL(grad_norms_finish_kernel, dim3(1), dim3(256), 0, st, norms, norm_sum, n, step_dev);
+  hipLaunchKernelGGL(grad_norms_finish_kernel, dim3(1), dim3(256), 0, st, norms, norm_sum, n, step_dev, part);
   AG_CHECK_LAUNCH("ag_grad_norms(finish)");
   return AG_OK;
 }

@@ -47,6 +47,25 @@ def _mat(t, name):
     return t.stride(0) if t.size(0) > 1 else max(t.stride(0), t.size(1))
 
 
+# ------------------------------------------------------------------------------------
+# two-stage (deterministic) reductions: a per-call workspace bound right before the C call
+# ------------------------------------------------------------------------------------
+import os as _os0
+
+DETERMINISTIC = [_os0.environ.get('AG_DETERMINISTIC', '1') != '0']
+_SMALL_WS = 1 << 17        # floats; enough for the bias / channel / column sums at every BASELINE size
+
+
+def _bind_ws(numel, dev):
+    """bind `numel` floats of scratch for the NEXT reducing call (ag_bind_workspace); the tensor comes from torch's
+    stream-ordered caching allocator, so it is safe to drop it as soon as the call has been enqueued"""
+    if not DETERMINISTIC[0] or numel <= 0:
+        return None
+    ws = torch.empty(int(numel), dtype=torch.float32, device=dev)
+    check(lib.ag_bind_workspace(_p(ws), int(numel)), 'ag_bind_workspace')
+    return ws
+
+
 def wpa_numel(d0, d1, K):
     return int(lib.ag_wpa_numel(d0, d1, K))
 
@@ -209,6 +228,7 @@ def conv_wgrad(sh, lg, dw, K, stride, pad):
     B, A, Lsh = sh.shape
     B2, Cc, Llg = lg.shape
     assert B == B2 and dw.is_contiguous() and dw.numel() == A * Cc * K
+    _ws = _bind_ws(lib.ag_conv1d_wgrad_ws_numel(B, A, Lsh, Cc, K), dw.device)  # noqa: F841
     check(lib.ag_conv1d_wgrad(_p(sh), sh_bs, sh_cs, _p(lg), lg_bs, lg_cs, _p(dw), B, A, Lsh, Cc, Llg,
                               K, stride, pad, _stream()), 'ag_conv1d_wgrad')
 
@@ -219,6 +239,7 @@ def channel_sum(dy, db):
     _chk(db, 'db')
     B, Cc, L = dy.shape
     assert db.numel() == Cc and db.is_contiguous()
+    _ws = _bind_ws(_SMALL_WS, db.device)  # noqa: F841
     check(lib.ag_channel_sum(_p(dy), bs, cs, _p(db), B, Cc, L, _stream()), 'ag_channel_sum')
 
 
@@ -235,6 +256,7 @@ def leaky_bwd(dy, y, dpre, lens=None, slope=LEAKY_SLOPE, add_into=None, bias_gra
     if bias_grad is not None:
         _chk(bias_grad, 'bias_grad')
         assert bias_grad.is_contiguous() and bias_grad.numel() == Cc
+        _ws = _bind_ws(_SMALL_WS, bias_grad.device)  # noqa: F841
     check(lib.ag_leaky_bwd(_p(dy), a[0], a[1], _p(y), b[0], b[1], _p(dpre), c[0], c[1], _p(add_into),
                            d[0], d[1], _p(lens), _p(bias_grad), B, Cc, L, slope, _stream()), 'ag_leaky_bwd')
 
@@ -258,6 +280,7 @@ def gemm(A, B, Cm, ta=False, tb=False, alpha=1.0, beta=0.0, bias=None, res=None,
     if bias is not None:
         _chk(bias, 'bias')
         assert bias.numel() == N and bias.is_contiguous()
+    _ws = _bind_ws(lib.ag_gemm_ws_numel(M, N, K, act), Cm.device)  # noqa: F841
     check(lib.ag_gemm(_p(A), lda, int(ta), _p(B), ldb, int(tb), _p(Cm), ldc, M, N, K, alpha, beta,
                       _p(bias), _p(res), ldres, act, slope, _stream()), 'ag_gemm')
 
@@ -268,6 +291,7 @@ def col_sum(X, out):
     _chk(out, 'out')
     M, N = X.shape
     assert out.numel() == N and out.is_contiguous()
+    _ws = _bind_ws(min(_SMALL_WS, 64 * N) if M > 16 else 0, out.device)  # noqa: F841
     check(lib.ag_col_sum(_p(X), ldx, _p(out), M, N, _stream()), 'ag_col_sum')
 
 
@@ -365,6 +389,7 @@ def grad_norms(params, grads, s1, s2, norms, norm_sum, flags, grad_scale=1.0, st
     _chk(norms, 'norms'); _chk(norm_sum, 'norm_sum'); _chk(flags, 'flags', torch.int32)
     assert norms.numel() >= len(params)
     _chk(step_dev, 'step_dev', torch.int32)
+    _ws = _bind_ws(256 * len(params), norms.device)  # noqa: F841
     check(lib.ag_grad_norms(_p(tab), len(params), _p(norms), _p(norm_sum), _p(flags), grad_scale,
                             _p(step_dev), _stream()), 'ag_grad_norms')
 
@@ -508,6 +533,7 @@ def skinny_gemm(A, B, Cm, tb=False, beta=0.0, bias=None, act=ACT_NONE, slope=LEA
     if bias is not None:
         _chk(bias, 'bias')
         assert bias.numel() == N and bias.is_contiguous()
+    _ws = _bind_ws(lib.ag_skinny_ws_numel(M, N, Kd), Cm.device) if atomic else None  # noqa: F841
     check(lib.ag_skinny_gemm(_p(A), lda, _p(B), ldb, int(tb), _p(Cm), ldc, M, N, Kd, beta, _p(bias), act,
                              slope, int(atomic), _stream()), 'ag_skinny_gemm')
 
@@ -701,6 +727,7 @@ def _lstm_seq_bwd_range(gates, whh, c_all, dy, dgates, dhbuf, dcbuf, valid, k0, 
             assert t_.is_contiguous() and tuple(t_.shape) == shp, (tuple(t_.shape), shp)
     _chk(dy, 'dy'); _chk(valid, 'valid', torch.int64)
     assert dy.is_contiguous() and tuple(dy.shape) == (T, B, ndir * H)
+    _ws = _bind_ws(ndir * lib.ag_skinny_ws_numel(B, H, 4 * H), dy.device) if H % 16 else None  # noqa: F841
     check(lib.ag_lstm_seq_bwd(_ptr_table(gates), _ptr_table(whh), _ptr_table(c_all), _p(dy),
                               _ptr_table(dgates), _ptr_table(dhbuf), _ptr_table(dcbuf), _p(valid), T, B, H,
                               ndir, k0, k1, phases, _stream()), 'ag_lstm_seq_bwd')
@@ -830,6 +857,7 @@ def conv_o1_wgrad(dy, x, dw, K_, pad):
     x_bs, x_cs = _bcl(x, 'x')
     B, Cc, L = x.shape
     assert dw.is_contiguous() and dw.numel() == Cc * K_ and tuple(dy.shape) == (B, 1, L)
+    _ws = _bind_ws(_SMALL_WS, dw.device)  # noqa: F841
     check(lib.ag_conv1d_o1_wgrad(_p(dy), dy_bs, _p(x), x_bs, x_cs, _p(dw), B, Cc, L, K_, pad, _stream()),
           'ag_conv1d_o1_wgrad')
 

@@ -206,6 +206,19 @@ int ag_gru_cell_bwd(const float* gates_act, const float* gh, const float* h_prev
                     const float* dh, int lddh, float* dgi, float* dgh, float* dh_prev, int lddhp, int B,
                     int H, void* stream);
 
+/* Deterministic cross-workgroup reductions.  Entry points that sum over workgroups (ag_conv1d_wgrad,
+ * ag_conv1d_o1_wgrad, ag_channel_sum, ag_leaky_bwd's bias gradient, ag_gemm's split-K products, ag_col_sum,
+ * ag_skinny_gemm in accumulate mode, ag_lstm_seq_bwd's unfused fallback, ag_grad_norms) do so in TWO STAGES when a
+ * workspace is bound: partial results with plain stores, then a sum in a fixed order - bitwise reproducible, and no
+ * float atomics (which execute at the memory side at ~1.3 TB/s).  ag_bind_workspace() binds `numel` floats (16-byte
+ * aligned device memory on the launch stream's device) for the NEXT such call of this host thread; the call consumes
+ * the binding.  The ag_*_ws_numel() functions return the size a call wants (0: none needed); a smaller workspace
+ * reduces the number of partial slabs, a missing one selects the float-atomic path (order-dependent last bits). */
+int ag_bind_workspace(float* ws, int64_t numel);
+int64_t ag_conv1d_wgrad_ws_numel(int B, int A, int Lsh, int C, int K);
+int64_t ag_gemm_ws_numel(int M, int N, int K, int act);
+int64_t ag_skinny_ws_numel(int M, int N, int K);
+
 /* Skinny product for the sequential part of the recurrent layers (M = clips per call <= 256):
  *   C[M,N] = act(A[M,K] * op(B) + beta*C + bias)         (accumulate_atomic == 0)
  *   C[M,N] += A[M,K] * op(B) (+ bias)   K split over workgroups, fp32 atomics  (== 1)
