@@ -34,35 +34,53 @@ AgWs ag_ws_take() {
   return w;
 }
 
+// One output (a float4, or a float in the scalar form) is summed by 8 threads: thread zq takes slabs z = zq, zq + 8, ...
+// (ascending, 4 independent loads in flight), then the 8 partial sums are added in the order zq = 0..7.  The order is
+// fixed by (Z, thread layout) alone, so the result is bitwise reproducible; the loads of a slab row are coalesced.
+template <typename V>
+__device__ __forceinline__ V slab_sum(const V* __restrict__ ws, int Z, int64_t n, int64_t i, int zq, bool ok, V* sh) {
+  V s = V{};
+  if (ok) {
+    int z = zq;
+    for (; z + 24 < Z; z += 32) {
+      const V a = ws[(int64_t)z * n + i], b = ws[(int64_t)(z + 8) * n + i], c = ws[(int64_t)(z + 16) * n + i],
+              d = ws[(int64_t)(z + 24) * n + i];
+      s += a; s += b; s += c; s += d;
+    }
+    for (; z < Z; z += 8) s += ws[(int64_t)z * n + i];
+  }
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  V t = sh[threadIdx.x & 31];
+#pragma unroll
+  for (int q = 1; q < 8; ++q) t += sh[q * 32 + (threadIdx.x & 31)];
+  return t;
+}
+
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ ws, int Z, int64_t n,
                                                           float* __restrict__ dst, int accumulate) {
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    float s = ws[i];
-    for (int z = 1; z < Z; ++z) s += ws[(int64_t)z * n + i];
-    dst[i] = accumulate ? dst[i] + s : s;
-  }
+  __shared__ float sh[256];
+  const int64_t i = (int64_t)blockIdx.x * 32 + (threadIdx.x & 31);
+  const float t = slab_sum<float>(ws, Z, n, i, threadIdx.x >> 5, i < n, sh);
+  if (threadIdx.x < 32 && i < n) dst[i] = accumulate ? dst[i] + t : t;
 }
 
 __global__ __launch_bounds__(256) void slab_reduce4_kernel(const f32x4* __restrict__ ws, int Z, int64_t n4,
                                                            f32x4* __restrict__ dst, int accumulate) {
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-    f32x4 s = ws[i];
-    for (int z = 1; z < Z; ++z) s += ws[(int64_t)z * n4 + i];
-    dst[i] = accumulate ? dst[i] + s : s;
-  }
+  __shared__ f32x4 sh[256];
+  const int64_t i = (int64_t)blockIdx.x * 32 + (threadIdx.x & 31);
+  const f32x4 t = slab_sum<f32x4>(ws, Z, n4, i, threadIdx.x >> 5, i < n4, sh);
+  if (threadIdx.x < 32 && i < n4) dst[i] = accumulate ? dst[i] + t : t;
 }
 
 int ag_slab_reduce(const float* ws, int Z, int64_t n, float* dst, int accumulate, hipStream_t st) {
   if (n <= 0 || Z <= 0) return AG_OK;
   if ((n & 3) == 0 && (((uintptr_t)ws | (uintptr_t)dst) & 15) == 0) {
     const int64_t n4 = n >> 2;
-    int g = (int)ag_cdiv64(n4, 256);
-    if (g > 2048) g = 2048;
-    hipLaunchKernelGGL(slab_reduce4_kernel, dim3(g), dim3(256), 0, st, (const f32x4*)ws, Z, n4, (f32x4*)dst, accumulate);
+    hipLaunchKernelGGL(slab_reduce4_kernel, dim3((unsigned)ag_cdiv64(n4, 32)), dim3(256), 0, st, (const f32x4*)ws, Z, n4,
+                       (f32x4*)dst, accumulate);
   } else {
-    int g = (int)ag_cdiv64(n, 256);
-    if (g > 2048) g = 2048;
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(g), dim3(256), 0, st, ws, Z, n, dst, accumulate);
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)ag_cdiv64(n, 32)), dim3(256), 0, st, ws, Z, n, dst, accumulate);
   }
   AG_CHECK_LAUNCH("ag_slab_reduce");
   return AG_OK;

@@ -25,9 +25,9 @@ AgWs ag_ws_take();
 // dst[i] (+)= sum_{z=0}^{Z-1} ws[z*n + i], z ascending
 int ag_slab_reduce(const float* ws, int Z, int64_t n, float* dst, int accumulate, hipStream_t st);
 
-// C[row*ldc+col] = beta*C + sum_{z<Z} part[(z*M+row)*N+col] + bias[col] + res[row*ldres+col]   (gemm.hip)
-int ag_splitk_reduce(const float* part, int Z, int M, int N, float* C, int ldc, float beta, const float* bias,
-                     const float* res, int ldres, hipStream_t st);
+// C[row*ldc+col] = beta*C + sum_{z<Z} part[z*pitch + row*N+col] + bias[col] + res[row*ldres+col]   (gemm.hip)
+int ag_splitk_reduce(const float* part, int Z, int64_t pitch, int M, int N, float* C, int ldc, float beta,
+                     const float* bias, const float* res, int ldres, hipStream_t st);
 
 #define AG_REQUIRE(cond, ...)     \
   do {                            \

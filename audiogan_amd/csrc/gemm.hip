@@ -457,30 +457,37 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmP p) {
     }
 }
 
-// second stage of a split-K product: C = beta*C + sum_z part[z] + bias + res  (z ascending)
-__global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float* __restrict__ part, int Z, int M, int N,
-                                                                 float* __restrict__ C, int ldc, float beta,
-                                                                 const float* __restrict__ bias,
+// second stage of a split-K product: C = beta*C + sum_z part[z] + bias + res.  8 threads per output element: thread zq
+// sums slabs z = zq, zq + 8, ... ascending, then the 8 partial sums are added in the order zq = 0..7 (fixed order).
+__global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float* __restrict__ part, int Z, int64_t pitch,
+                                                                 int M, int N, float* __restrict__ C, int ldc,
+                                                                 float beta, const float* __restrict__ bias,
                                                                  const float* __restrict__ res, int ldres) {
+  __shared__ float sh[256];
   const int64_t mn = (int64_t)M * N;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < mn; i += (int64_t)gridDim.x * 256) {
-    const int row = (int)(i / N), col = (int)(i - (int64_t)row * N);
-    float s = part[i];
-    for (int z = 1; z < Z; ++z) s += part[(int64_t)z * mn + i];
-    float* dst = C + (int64_t)row * ldc + col;
-    if (beta != 0.f) s += beta * *dst;
-    if (bias) s += bias[col];
-    if (res) s += res[(int64_t)row * ldres + col];
-    *dst = s;
-  }
+  const int64_t i = (int64_t)blockIdx.x * 32 + (threadIdx.x & 31);
+  float s = 0.f;
+  if (i < mn)
+    for (int z = threadIdx.x >> 5; z < Z; z += 8) s += part[(int64_t)z * pitch + i];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x >= 32 || i >= mn) return;
+  s = sh[threadIdx.x];
+#pragma unroll
+  for (int q = 1; q < 8; ++q) s += sh[q * 32 + threadIdx.x];
+  const int row = (int)(i / N), col = (int)(i - (int64_t)row * N);
+  float* dst = C + (int64_t)row * ldc + col;
+  if (beta != 0.f) s += beta * *dst;
+  if (bias) s += bias[col];
+  if (res) s += res[(int64_t)row * ldres + col];
+  *dst = s;
 }
 
-int ag_splitk_reduce(const float* part, int Z, int M, int N, float* C, int ldc, float beta, const float* bias,
-                     const float* res, int ldres, hipStream_t st) {
+int ag_splitk_reduce(const float* part, int Z, int64_t pitch, int M, int N, float* C, int ldc, float beta,
+                     const float* bias, const float* res, int ldres, hipStream_t st) {
   const int64_t mn = (int64_t)M * N;
-  int g = (int)ag_cdiv64(mn, 256);
-  if (g > 2048) g = 2048;
-  hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(g), dim3(256), 0, st, part, Z, M, N, C, ldc, beta, bias, res, ldres);
+  hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)ag_cdiv64(mn, 32)), dim3(256), 0, st, part, Z, pitch, M, N,
+                     C, ldc, beta, bias, res, ldres);
   AG_CHECK_LAUNCH("ag_splitk_reduce");
   return AG_OK;
 }
@@ -573,7 +580,7 @@ extern "C" int ag_gemm(const float* A, int lda, int ta, const float* B, int ldb,
     rc = launch_gemm<1, 1, 2, 2>(p, ta, tb, st);              // 64x64
   }
   if (rc != AG_OK || !p.part) return rc;
-  return ag_splitk_reduce(p.part, p.ksplit, M, N, C, ldc, beta, bias, res, ldres, st);
+  return ag_splitk_reduce(p.part, p.ksplit, (int64_t)M * N, M, N, C, ldc, beta, bias, res, ldres, st);
 }
 
 // floats of workspace ag_gemm wants bound (ag_bind_workspace) so that a split-K product is reduced in two stages

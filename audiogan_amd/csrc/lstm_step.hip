@@ -237,29 +237,6 @@ __global__ __launch_bounds__(1024) void skinny16_nt_kernel(const SkinnyP p) {
   *dst = ag_apply_act(v, p.act, p.slope);
 }
 
-// C[m*ldc+n] += sum_{z<Z} part[z*pitch + m*N + n] (+ bias[n]), z ascending
-__global__ __launch_bounds__(256) void skinny_reduce_kernel(const float* __restrict__ part, int Z, int64_t pitch, int M,
-                                                            int N, float* __restrict__ C, int ldc,
-                                                            const float* __restrict__ bias) {
-  const int64_t mn = (int64_t)M * N;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < mn; i += (int64_t)gridDim.x * 256) {
-    const int m = (int)(i / N), n = (int)(i - (int64_t)m * N);
-    float s = part[i];
-    for (int z = 1; z < Z; ++z) s += part[(int64_t)z * pitch + i];
-    if (bias) s += bias[n];
-    C[(int64_t)m * ldc + n] += s;
-  }
-}
-
-static int ag_splitk_reduce_strided(const float* part, int Z, int64_t pitch, int M, int N, float* C, int ldc,
-                                    const float* bias, hipStream_t st) {
-  int g = (int)ag_cdiv64((int64_t)M * N, 256);
-  if (g > 1024) g = 1024;
-  hipLaunchKernelGGL(skinny_reduce_kernel, dim3(g), dim3(256), 0, st, part, Z, pitch, M, N, C, ldc, bias);
-  AG_CHECK_LAUNCH("ag_skinny_gemm(reduce)");
-  return AG_OK;
-}
-
 static int launch_skinny(SkinnyP& p, int nprob, int accumulate_atomic, hipStream_t st, AgWs ws = AgWs{nullptr, 0}) {
   p.part = nullptr;
   const int gx = ag_cdiv(p.N, 32);
@@ -299,8 +276,8 @@ static int launch_skinny(SkinnyP& p, int nprob, int accumulate_atomic, hipStream
   if (p.part) {
     for (int q = 0; q < nprob; ++q) {
       // slab z of problem q starts at part + (z*nprob + q)*M*N: present it as Z slabs of pitch nprob*M*N
-      const int rc = ag_splitk_reduce_strided(p.part + (int64_t)q * p.M * p.N, gy, (int64_t)nprob * p.M * p.N, p.M, p.N,
-                                              p.q[q].C, p.ldc, p.q[q].bias, st);
+      const int rc = ag_splitk_reduce(p.part + (int64_t)q * p.M * p.N, gy, (int64_t)nprob * p.M * p.N, p.M, p.N, p.q[q].C,
+                                      p.ldc, 1.f, p.q[q].bias, nullptr, 0, st);
       if (rc != AG_OK) return rc;
     }
   }
