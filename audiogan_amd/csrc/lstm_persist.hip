@@ -284,3 +284,193 @@ extern "C" int ag_lstm_seq_fwd_persist(float* const* pre, const float* const* wh
   AG_CHECK_LAUNCH("ag_lstm_seq_fwd_persist");
   return AG_OK;
 }
+
+// ------------------------------------------------------------------------------------------
+// Backward through time as ONE persistent launch.
+//
+//   dh_k[m,u] = sum_kk dgates_{k+1}[m,kk] * W_hh[kk,u]  (+ pass-through of padded rows),   K = 4H
+//   (dgates_k, dc, pass-through) = cell backward of step k
+//
+// The contraction runs over ALL 4H gate columns, so a workgroup that owns 32 hidden units needs the W_hh slice
+// [4H x 32] = 256 KB at H = 512: more than LDS, but not more than the REGISTER FILE (512 KB per CU).  Each of the
+// 8 waves keeps its K slice of that panel in VGPRs for the whole sequence (4H/8 k-values x 32 units = 128 registers
+// per lane at H = 512) as ready-made MFMA B operands; nothing but dgates is read per step.
+//
+//   workgroup = (direction, 16-clip tile, 32-unit tile); group = the H/32 unit tiles of one (direction, clip tile)
+//   per step  : wait for the group's flags -> A = dgates_{k+1}[16 clips, K slice] (sc1 loads, straight from L2)
+//               -> v_mfma_f32_16x16x4_f32 against the resident panel -> LDS sum of the 8 K slices
+//               -> cell backward for its (clip, unit) pairs; dc and the pass-through stay in registers
+//               -> dgates_k written THROUGH (sc1) into the output tensor itself, which is also the exchange
+//                  buffer (one slot per step: no parity), every wave drains, barrier, flag.
+// ------------------------------------------------------------------------------------------
+struct PersistBwdDir {
+  const float* ga;      // [T,B,4H] activated gates
+  const float* whh;     // [4H,H]
+  const float* c_all;   // [T+1,B,H]
+  float* dgates;        // [T,B,4H] out (and exchange)
+};
+
+struct PersistBwdP {
+  PersistBwdDir d[2];
+  const float* dy;      // [T,B,ndir*H]
+  const int64_t* valid;
+  unsigned* hdr;
+  int T, B, H, ndir;
+  int nbt;              // 16-clip tiles
+  int ntile;            // H / 32
+};
+
+template <int NU>       // 16-k units per wave: 4H = 8 waves * NU * 16
+__global__ __launch_bounds__(512) void lstm_persist_bwd_kernel(const PersistBwdP p) {
+  __shared__ float red[8 * 512];
+  const int H = p.H, B = p.B, T = p.T, ntile = p.ntile;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  const int ngroups = p.ndir * p.nbt;
+  const int grp = blockIdx.x % ngroups, ut = blockIdx.x / ngroups;
+  const int dir = grp / p.nbt, bt = grp % p.nbt;
+  const PersistBwdDir& D = p.d[dir];
+  const int n0 = ut * 32, m0 = bt * 16;
+  const int64_t BG = (int64_t)B * 4 * H, BH = (int64_t)B * H;
+
+  // ---- resident weight panel: wreg[u][e][c] = W_hh[(wid*NU + u)*16 + 4g + e][n0 + 16c + li]
+  float wreg[NU][4][2];
+#pragma unroll
+  for (int u = 0; u < NU; ++u)
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+        wreg[u][e][c] = D.whh[(int64_t)((wid * NU + u) * 16 + 4 * g + e) * H + n0 + 16 * c + li];
+
+  unsigned* flags = p.hdr + PS_FLAG_OFF + grp * ntile;
+  // epilogue role: thread <-> (clip row, unit)
+  const int erow = tid >> 5, eun = tid & 31;
+  const int em = m0 + erow, eu = n0 + eun;
+  const bool epi = em < B;
+  const int64_t vlen = (epi && p.valid) ? p.valid[em] : ((int64_t)1 << 60);
+  float dcn = 0.f, dpass = 0.f;
+  // A operand row of this lane (clamped: rows past the batch only feed their own, unwritten outputs)
+  const int arow = min(m0 + li, B - 1);
+  const unsigned aoff = (unsigned)(((int64_t)arow * 4 * H + (wid * NU) * 16 + 4 * g) * 4);
+  bool alive = true;
+
+  for (int k = T - 1; k >= 0; --k) {
+    const int t = dir == 0 ? k : T - 1 - k;
+    float ig = 0.f, fg = 0.f, gg = 0.f, og = 0.f, cp = 0.f, cn = 0.f, dyv = 0.f;
+    if (epi) {
+      const float* gr = D.ga + (int64_t)t * BG + (int64_t)em * 4 * H + eu;
+      ig = gr[0]; fg = gr[H]; gg = gr[2 * H]; og = gr[3 * H];
+      cp = D.c_all[(int64_t)k * BH + (int64_t)em * H + eu];
+      cn = D.c_all[(int64_t)(k + 1) * BH + (int64_t)em * H + eu];
+      dyv = p.dy[((int64_t)t * B + em) * p.ndir * H + (int64_t)dir * H + eu];
+    }
+    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    if (k < T - 1) {
+      if (wid == 0 && alive) alive = ps_wait_flags(p.hdr, flags, ntile, (unsigned)(T - 1 - k), lane);
+      __syncthreads();
+      const int tn = dir == 0 ? k + 1 : T - 2 - k;
+      __amdgpu_buffer_rsrc_t ar = __builtin_amdgcn_make_buffer_rsrc(D.dgates + (int64_t)tn * BG, 0, (int)(BG * 4), 0x00020000);
+      constexpr int UB = NU < 8 ? NU : 8;
+#pragma unroll
+      for (int ub = 0; ub < NU; ub += UB) {
+        u32x4 a[UB];
+#pragma unroll
+        for (int i = 0; i < UB; ++i) a[i] = __builtin_amdgcn_raw_buffer_load_b128(ar, aoff + (unsigned)((ub + i) * 64), 0, 16);
+#pragma unroll
+        for (int i = 0; i < UB; ++i)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+              acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[i][e]), wreg[ub + i][e][c], acc[c], 0, 0, 0);
+      }
+    }
+    // C layout of a 16x16 tile: col = lane & 15, row = 4 * (lane >> 4) + e
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) red[wid * 512 + (4 * g + e) * 32 + 16 * c + li] = acc[c][e];
+    __syncthreads();
+    if (epi) {
+      float dhf = dpass;
+      if (k < T - 1) {
+#pragma unroll
+        for (int w = 0; w < 8; ++w) dhf += red[w * 512 + tid];
+      }
+      float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
+      if (t >= vlen) {
+        dpass = dhf;          // padded step: gradient passes through h and c unchanged
+      } else {
+        const float dhv = dhf + dyv;
+        const float tc = tanhf(cn);
+        const float dc = dcn + dhv * og * (1.f - tc * tc);
+        d0 = dc * gg * ig * (1.f - ig);
+        d1 = dc * cp * fg * (1.f - fg);
+        d2 = dc * ig * (1.f - gg * gg);
+        d3 = dhv * tc * og * (1.f - og);
+        dcn = dc * fg;
+        dpass = 0.f;
+      }
+      __amdgpu_buffer_rsrc_t orr = __builtin_amdgcn_make_buffer_rsrc(D.dgates + (int64_t)t * BG, 0, (int)(BG * 4), 0x00020000);
+      const unsigned o = (unsigned)(((int64_t)em * 4 * H + eu) * 4);
+      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(d0), orr, o, 0, 16);
+      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(d1), orr, o + (unsigned)(H * 4), 0, 16);
+      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(d2), orr, o + (unsigned)(2 * H * 4), 0, 16);
+      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(d3), orr, o + (unsigned)(3 * H * 4), 0, 16);
+    }
+    if (k > 0) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // EVERY storing wave drains its write-through stores
+      __syncthreads();
+      if (tid == 0) __hip_atomic_store(flags + ut, (unsigned)(T - k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+static bool persist_bwd_shape_ok(int B, int H, int ndir, int n_cu) {
+  if (!(H == 64 || H == 128 || H == 256 || H == 512) || B < 1) return false;
+  if (n_cu > 256) n_cu = 256;
+  const int64_t grid = (int64_t)ndir * ag_cdiv(B, 16) * (H / 32);
+  return grid <= n_cu && grid <= (PS_HDR_BYTES / 4 - PS_FLAG_OFF);
+}
+
+extern "C" int ag_lstm_persist_bwd_ok(int B, int H, int ndir, int n_cu) {
+  return persist_bwd_shape_ok(B, H, ndir, n_cu) ? 1 : 0;
+}
+
+// Whole layer backward through time in ONE launch; tensors as for ag_lstm_seq_bwd (no scratch state: dc and the
+// pass-through term stay in registers).  `ws`: >= 8 KiB (status + flags), zeroed by a memset node in front.
+extern "C" int ag_lstm_seq_bwd_persist(const float* const* gates, const float* const* whh, const float* const* c_all,
+                                       const float* dy, float* const* dgates, const int64_t* valid_i64, void* ws,
+                                       int64_t ws_bytes, int T, int B, int H, int ndir, int n_cu, void* stream) {
+  AG_REQUIRE(gates && whh && c_all && dy && dgates && ws, "ag_lstm_seq_bwd_persist: null tensor");
+  AG_REQUIRE(ndir == 1 || ndir == 2, "ag_lstm_seq_bwd_persist: ndir must be 1 or 2");
+  AG_REQUIRE(T > 0, "ag_lstm_seq_bwd_persist: T must be positive");
+  if (!persist_bwd_shape_ok(B, H, ndir, n_cu)) {
+    ag_set_error("ag_lstm_seq_bwd_persist: shape B=%d H=%d ndir=%d does not fit %d CUs", B, H, ndir, n_cu);
+    return AG_ERR_UNSUPPORTED;
+  }
+  AG_REQUIRE(ws_bytes >= PS_HDR_BYTES && ((uintptr_t)ws & 15) == 0, "ag_lstm_seq_bwd_persist: workspace too small");
+  AG_REQUIRE((int64_t)B * 4 * H * 4 < ((int64_t)1 << 31), "ag_lstm_seq_bwd_persist: step slab too large");
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(ws, 0, PS_HDR_BYTES, st) != hipSuccess) {
+    ag_set_error("ag_lstm_seq_bwd_persist: memset failed");
+    return AG_ERR_LAUNCH;
+  }
+  PersistBwdP p;
+  for (int d = 0; d < 2; ++d) {
+    const int s = d < ndir ? d : 0;
+    p.d[d].ga = gates[s]; p.d[d].whh = whh[s]; p.d[d].c_all = c_all[s]; p.d[d].dgates = dgates[s];
+  }
+  p.dy = dy; p.valid = valid_i64; p.hdr = (unsigned*)ws;
+  p.T = T; p.B = B; p.H = H; p.ndir = ndir; p.nbt = ag_cdiv(B, 16); p.ntile = H / 32;
+  const int grid = ndir * p.nbt * p.ntile;
+  switch (H) {
+    case 512: hipLaunchKernelGGL(lstm_persist_bwd_kernel<16>, dim3(grid), dim3(512), 0, st, p); break;
+    case 256: hipLaunchKernelGGL(lstm_persist_bwd_kernel<8>, dim3(grid), dim3(512), 0, st, p); break;
+    case 128: hipLaunchKernelGGL(lstm_persist_bwd_kernel<4>, dim3(grid), dim3(512), 0, st, p); break;
+    default:  hipLaunchKernelGGL(lstm_persist_bwd_kernel<2>, dim3(grid), dim3(512), 0, st, p); break;
+  }
+  AG_CHECK_LAUNCH("ag_lstm_seq_bwd_persist");
+  return AG_OK;
+}

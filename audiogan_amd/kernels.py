@@ -689,8 +689,40 @@ def _lstm_seq_fwd_range(pre, whh, c_all, hbuf, y, valid, k0, k1, static=None):
                               _stream()), 'ag_lstm_seq_fwd')
 
 
+def lstm_persist_bwd_ok(B, H, ndir, dev):
+    return bool(PERSIST[0] and lib.ag_lstm_persist_bwd_ok(B, H, ndir, _n_cu(dev)))
+
+
+def _lstm_seq_bwd_persist_call(gates, whh, c_all, dy, dgates, valid):
+    """ONE persistent launch for the whole backward through time (ag_lstm_seq_bwd_persist)"""
+    ndir = len(gates)
+    T, B, H4 = gates[0].shape
+    H = H4 // 4
+    for d in range(ndir):
+        for t_, shp in ((gates[d], (T, B, 4 * H)), (whh[d], (4 * H, H)), (c_all[d], (T + 1, B, H)),
+                        (dgates[d], (T, B, 4 * H))):
+            _chk(t_, 'lstm_seq tensor')
+            assert t_.is_contiguous() and tuple(t_.shape) == shp, (tuple(t_.shape), shp)
+    _chk(dy, 'dy'); _chk(valid, 'valid', torch.int64)
+    assert dy.is_contiguous() and tuple(dy.shape) == (T, B, ndir * H)
+    ws = _persist_workspace(dy.device, 8192)
+    check(lib.ag_lstm_seq_bwd_persist(_ptr_table(gates), _ptr_table(whh), _ptr_table(c_all), _p(dy),
+                                      _ptr_table(dgates), _p(valid), _p(ws), ws.numel(), T, B, H, ndir,
+                                      _n_cu(dy.device), _stream()), 'ag_lstm_seq_bwd_persist')
+
+
+def _work_seq_bwd_persist(gates, whh, c_all, dy, dgates, valid):
+    T, B, H4 = gates[0].shape
+    nd = len(gates)
+    return 'lstm_persist_bwd_kernel', T * 2.0 * nd * B * H4 * (H4 // 4), \
+        4.0 * nd * (H4 * (H4 // 4) + T * 5.5 * B * H4), 1
+
+
 def lstm_seq_bwd(gates, whh, c_all, dy, dgates, dhbuf, dcbuf, valid):
     T = gates[0].size(0)
+    if lstm_persist_bwd_ok(gates[0].size(1), gates[0].size(2) // 4, len(gates), dy.device):
+        _lstm_seq_bwd_persist_call(gates, whh, c_all, dy, dgates, valid)
+        return
     if Profiler.enabled:
         H = gates[0].size(2) // 4
         if H % 16 == 0:         # the fused step kernel: the whole chain between one pair of events
@@ -779,7 +811,7 @@ def _work_seq_bwd_cell(gates, whh, *a_, **kw):
 
 for _n, _w in (('skinny_gemm', _work_skinny), ('lstm_step_fwd', _work_step),
                ('_lstm_seq_fwd_range', _work_seq_fwd), ('_lstm_seq_fwd_persist_call', _work_seq_fwd_persist),
-               ('_lstm_seq_bwd_prod', _work_seq_bwd_prod),
+               ('_lstm_seq_bwd_persist_call', _work_seq_bwd_persist), ('_lstm_seq_bwd_prod', _work_seq_bwd_prod),
                ('_lstm_seq_bwd_cell', _work_seq_bwd_cell), ('_lstm_seq_bwd_step', _work_seq_bwd_step)):
     _instrument(_n, _w)
 

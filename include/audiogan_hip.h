@@ -273,6 +273,16 @@ int ag_lstm_seq_fwd_persist(float* const* pre, const float* const* whh, float* c
                             const int64_t* valid_i64, const float* const* static_pre, void* ws, int64_t ws_bytes,
                             int T, int B, int H, int ndir, int n_cu, void* stream);
 
+/* The layer's backward through time as ONE persistent launch: each workgroup (16 clips x 32 hidden units of one
+ * direction) keeps its [4H x 32] panel of W_hh in REGISTERS for the whole sequence; dgates_k is written through
+ * into the output tensor, which doubles as the exchange buffer.  H in {64,128,256,512} and
+ * ndir * ceil(B/16) * H/32 <= n_cu (ag_lstm_persist_bwd_ok); `ws` >= 8 KiB as above.  Tensors as for
+ * ag_lstm_seq_bwd (no dhbuf/dcbuf: the state stays in registers). */
+int ag_lstm_persist_bwd_ok(int B, int H, int ndir, int n_cu);
+int ag_lstm_seq_bwd_persist(const float* const* gates, const float* const* whh, const float* const* c_all,
+                            const float* dy, float* const* dgates, const int64_t* valid_i64, void* ws,
+                            int64_t ws_bytes, int T, int B, int H, int ndir, int n_cu, void* stream);
+
 /* One fused backward step of the Generator front (audiogan.py:428-460: LSTMCell -> tanh(Linear) fed back), frame t:
  *   gx     = dxa * (1 - x_t^2)                        d(pre-tanh) of the projection, stored to gx_out [B,Kp]
  *   dh     = dh_acc + gx * w_proj                      w_proj [Kp = frame size, H]; dh_acc [B,H] rows, pitch lddh

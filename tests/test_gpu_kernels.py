@@ -376,11 +376,11 @@ def test_lstm_step_fwd(K, B, H, Kx):
 @pytest.mark.parametrize('T,B,H,ndir,ragged', [(128, 64, 512, 2, True), (16, 128, 64, 2, True), (5, 3, 8, 2, True), (7, 33, 24, 1, False),
                                                (1, 4, 16, 2, True), (6, 40, 96, 1, True), (9, 70, 32, 2, True), (3, 150, 512, 2, True),
                                                (33, 128, 512, 2, True), (5, 70, 192, 1, True), (4, 33, 64, 2, False),
-                                               (3, 256, 256, 2, True)])
+                                               (3, 256, 256, 2, True), (6, 20, 128, 2, True), (9, 17, 256, 1, True)])
 def test_lstm_seq_fwd_bwd(K, T, B, H, ndir, ragged, persist):
     """persist=True: shapes that fit the chip take the persistent weights-resident launch (lstm_persist.hip), the
     others one launch per step; persist=False forces the per-step kernels for every shape"""
-    fits = K.lib.ag_lstm_persist_ok(B, H, ndir, 256)
+    fits = K.lib.ag_lstm_persist_ok(B, H, ndir, 256) or K.lib.ag_lstm_persist_bwd_ok(B, H, ndir, 256)
     if persist and not fits:
         pytest.skip('shape does not take the persistent kernel')
     old = K.PERSIST[0]
