@@ -77,6 +77,8 @@ SIGNATURES = {
                                    C.c_int, C.c_int, vp]),
     'ag_lstm_seq_fwd': (C.c_int, [vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     'ag_lstm_seq_bwd': (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    'ag_set_precision': (C.c_int, [C.c_int]),
+    'ag_get_precision': (C.c_int, []),
     'ag_bind_workspace': (C.c_int, [vp, i64]),
     'ag_conv1d_wgrad_ws_numel': (i64, [C.c_int] * 5),
     'ag_gemm_ws_numel': (i64, [C.c_int] * 4),

@@ -29,6 +29,33 @@ int ag_slab_reduce(const float* ws, int Z, int64_t n, float* dst, int accumulate
 int ag_splitk_reduce(const float* part, int Z, int64_t pitch, int M, int N, float* C, int ldc, float beta,
                      const float* bias, const float* res, int ldres, hipStream_t st);
 
+// Precision mode of the contractions (api.hip, thread-local, set by ag_set_precision):
+//   AG_PREC_F32   operands as stored (exact fp32 MFMA / FMA chains)
+//   AG_PREC_BF16  EVERY contraction (conv, transposed conv, linear, recurrent products; forward, backward-data and
+//                 backward-weight forms) rounds BOTH operands to bf16 (round-to-nearest-even) and accumulates in fp32.
+//                 The GEMM and the persistent recurrent kernels then run v_mfma_f32_32x32x16_bf16; kernels that still
+//                 issue fp32 MFMA / FMA round their operands in registers (ag_rbf) - products of bf16 values are exact
+//                 in fp32, so both forms compute the same sums up to the order of the fp32 additions.
+int ag_precision();
+#define AG_PREC_F32 0
+#define AG_PREC_BF16 1
+
+// round-to-nearest-even to bf16 precision, result kept in an fp32 register (NaN payloads are not preserved)
+__device__ __forceinline__ float ag_rbf(float x) {
+  unsigned u = __float_as_uint(x);
+  u = (u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u;
+  return __uint_as_float(u);
+}
+__device__ __forceinline__ float ag_rbf_if(float x, int rb) { return rb ? ag_rbf(x) : x; }
+__device__ __forceinline__ f32x4 ag_rbf4_if(f32x4 v, int rb) {
+  if (rb) { v[0] = ag_rbf(v[0]); v[1] = ag_rbf(v[1]); v[2] = ag_rbf(v[2]); v[3] = ag_rbf(v[3]); }
+  return v;
+}
+// two floats -> packed bf16x2 (lo = a, hi = b), RNE
+__device__ __forceinline__ unsigned ag_pack_bf16(float a, float b) {
+  return (__float_as_uint(ag_rbf(a)) >> 16) | (__float_as_uint(ag_rbf(b)) & 0xFFFF0000u);
+}
+
 #define AG_REQUIRE(cond, ...)     \
   do {                            \
     if (!(cond)) {                \

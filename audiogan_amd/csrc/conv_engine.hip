@@ -37,6 +37,7 @@ struct ConvP {
   int n_cnt;      // number of columns
   int xvec;       // input rows may be read with aligned 16-byte loads
   int aligned;    // mode 1: aligned scatter layout (common.h) - phase r's outputs are shifted by -s * shift_r
+  int rb;         // AG_PREC_BF16: both operands rounded to bf16 while staging (fp32 MFMA on rounded values)
   int tapoff[MAX_TAPS];
 };
 
@@ -148,7 +149,7 @@ __global__ __launch_bounds__(512) void conv_engine_kernel(const ConvP p) {
               qq = rem / p.sp;
               r = rem - qq * p.sp;
             }
-            xs[cc * chs + r * rowlen + qq] = xv[u][q];
+            xs[cc * chs + r * rowlen + qq] = ag_rbf_if(xv[u][q], p.rb);
           }
         }
       }
@@ -157,7 +158,7 @@ __global__ __launch_bounds__(512) void conv_engine_kernel(const ConvP p) {
         const int idx = we + u * step;
         if (idx < wtot) {
           const int r4 = idx % (OT / 4), ct = idx / (OT / 4);
-          *reinterpret_cast<f32x4*>(ws + (size_t)ct * OT + r4 * 4) = wv[u];
+          *reinterpret_cast<f32x4*>(ws + (size_t)ct * OT + r4 * 4) = ag_rbf4_if(wv[u], p.rb);
         }
       }
       xe += UX * step;
@@ -261,10 +262,10 @@ __global__ __launch_bounds__(512) void conv_engine_kernel(const ConvP p) {
       for (int u = 0; u < FX; ++u)
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-          if (xl[u][q] >= 0) xs[xl[u][q]] = xsrc[u] < 0 ? 0.f : xv[u][q];
+          if (xl[u][q] >= 0) xs[xl[u][q]] = xsrc[u] < 0 ? 0.f : ag_rbf_if(xv[u][q], p.rb);
 #pragma unroll
       for (int u = 0; u < FW; ++u)
-        if (wl[u] >= 0) *reinterpret_cast<f32x4*>(ws + wl[u]) = wv[u];
+        if (wl[u] >= 0) *reinterpret_cast<f32x4*>(ws + wl[u]) = ag_rbf4_if(wv[u], p.rb);
       __syncthreads();
     }
     for (; ci < nchunk; ++ci) {
@@ -537,6 +538,7 @@ extern "C" int ag_conv1d_engine(const ag_conv_args* args, void* stream) {
   p.a = *args;
   const ag_conv_args& a = p.a;
   p.aligned = 0;
+  p.rb = ag_precision() == AG_PREC_BF16;
   AG_REQUIRE(a.x && a.wp && a.y, "ag_conv1d_engine: null tensor");
   AG_REQUIRE(a.B > 0 && a.C > 0 && a.O > 0 && a.Lin > 0 && a.Lout > 0, "ag_conv1d_engine: bad shape");
   AG_REQUIRE(a.K > 0 && a.stride > 0 && a.pad >= 0, "ag_conv1d_engine: bad conv params");

@@ -23,6 +23,7 @@ struct WgP {
   int maxch;    // channel rows staged per tile
   int vec;      // sh rows may be read with 16-byte loads
   float* part;  // two-stage reduction: slab z = blockIdx.z of [A][CK] partial sums (plain stores); NULL -> atomics
+  int rb;       // AG_PREC_BF16: both operands rounded to bf16 while staging
 };
 
 // 8 waves: waves 0-3 multiply chunk i out of LDS buffer i&1 while waves 4-7 stage chunk i+1.
@@ -98,7 +99,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgP p) {
         if (e < stot) {
           const int r = e / q4, q = e - r * q4;
 #pragma unroll
-          for (int x = 0; x < 4; ++x) shs[(4 * q + x) * SP + r] = sv[u][x];
+          for (int x = 0; x < 4; ++x) shs[(4 * q + x) * SP + r] = ag_rbf_if(sv[u][x], p.rb);
         }
       }
 #pragma unroll
@@ -106,7 +107,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgP p) {
         const int e = le + u * step;
         if (e < ltot) {
           const int r = e / span, i = e - r * span;
-          lgs[r * p.lgp + i] = lv[u];
+          lgs[r * p.lgp + i] = ag_rbf_if(lv[u], p.rb);
         }
       }
       se += US * step;
@@ -179,14 +180,14 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgP p) {
           for (int u = 0; u < FS; ++u)
             if (sl[u] >= 0) {
 #pragma unroll
-              for (int x = 0; x < 4; ++x) shs[sl[u] + x * SP] = ssrc[u] < 0 ? 0.f : sv[u][x];
+              for (int x = 0; x < 4; ++x) shs[sl[u] + x * SP] = ssrc[u] < 0 ? 0.f : ag_rbf_if(sv[u][x], p.rb);
             }
 #pragma unroll
           for (int u = 0; u < FL; ++u)
 #pragma unroll
             for (int x = 0; x < 4; ++x) {
               const int i = li0[u] + x;
-              if (i >= 0 && i < span) lgs[lrow[u] + i] = lok[u] ? lv[u][x] : 0.f;
+              if (i >= 0 && i < span) lgs[lrow[u] + i] = lok[u] ? ag_rbf_if(lv[u][x], p.rb) : 0.f;
             }
         }
         __syncthreads();
@@ -305,7 +306,8 @@ template <int KMAX, int AG>
 __global__ __launch_bounds__(256) void conv_c1_wgrad_kernel(const float* __restrict__ sh, int64_t sh_bs, int64_t sh_cs,
                                                             const float* __restrict__ lg, int64_t lg_bs,
                                                             float* __restrict__ dw, int B, int A, int Lsh, int Llg,
-                                                            int K, int s, int p, int bper, float* __restrict__ part) {
+                                                            int K, int s, int p, int bper, float* __restrict__ part,
+                                                            int rb) {
   // a thread owns ONE time step (consecutive threads = consecutive steps: dy loads coalesce, x loads are s floats
   // apart) and AG output channels: the K-wide x window is loaded once per clip and reused by the AG channels
   __shared__ float red[4][AG * KMAX];
@@ -326,12 +328,12 @@ __global__ __launch_bounds__(256) void conv_c1_wgrad_kernel(const float* __restr
       for (int k = 0; k < KMAX; ++k) {
         const int q = q0 + k;
         const float xv = xr[min(max(q, 0), Llg - 1)];          // unconditional load, then select
-        win[k] = (k < K && q >= 0 && q < Llg) ? xv : 0.f;
+        win[k] = (k < K && q >= 0 && q < Llg) ? ag_rbf_if(xv, rb) : 0.f;
       }
       const float* dyr = sh + (int64_t)b * sh_bs + t;
 #pragma unroll
       for (int i = 0; i < AG; ++i) {
-        const float g = dyr[(int64_t)min(a0 + i, A - 1) * sh_cs];
+        const float g = ag_rbf_if(dyr[(int64_t)min(a0 + i, A - 1) * sh_cs], rb);
 #pragma unroll
         for (int k = 0; k < KMAX; ++k) acc[i][k] += g * win[k];
       }
@@ -367,6 +369,7 @@ extern "C" int ag_conv1d_wgrad(const float* sh, int64_t sh_bs, int64_t sh_cs, co
   p.sh_bs = sh_bs; p.sh_cs = sh_cs; p.lg_bs = lg_bs; p.lg_cs = lg_cs;
   p.B = B; p.A = A; p.Lsh = Lsh; p.C = C; p.Llg = Llg; p.K = K; p.s = stride; p.p = pad;
   p.CK = C * K;
+  p.rb = ag_precision() == AG_PREC_BF16;
   p.vec = (((uintptr_t)sh & 15) == 0) && (sh_bs % 4 == 0) && (sh_cs % 4 == 0);
   hipStream_t st = (hipStream_t)stream;
   const AgWs ws = ag_ws_take();
@@ -384,7 +387,7 @@ extern "C" int ag_conv1d_wgrad(const float* sh, int64_t sh_bs, int64_t sh_cs, co
     const int bper = ag_cdiv(B, gz);
     gz = ag_cdiv(B, bper);
     hipLaunchKernelGGL((conv_c1_wgrad_kernel<8, 8>), dim3(gx, gy, gz), dim3(256), 0, st, sh, sh_bs, sh_cs, lg, lg_bs,
-                       dw, B, A, Lsh, Llg, K, stride, pad, bper, part);
+                       dw, B, A, Lsh, Llg, K, stride, pad, bper, part, p.rb);
     AG_CHECK_LAUNCH("ag_conv1d_wgrad");
     if (part) return ag_slab_reduce(part, gx * gz, (int64_t)A * K, dw, 1, st);
     return AG_OK;
@@ -543,7 +546,7 @@ extern "C" int ag_leaky_bwd(const float* dy, int64_t dy_bs, int64_t dy_cs, const
 __global__ __launch_bounds__(256) void conv_o1_fwd_kernel(const float* __restrict__ x, int64_t x_bs, int64_t x_cs,
                                                           const float* __restrict__ w, const float* __restrict__ bias,
                                                           float* __restrict__ y, int64_t y_bs, int C, int L, int K,
-                                                          int p, int act, float slope) {
+                                                          int p, int act, float slope, int rb) {
   const int b = blockIdx.y;
   const int t0 = (blockIdx.x * 256 + threadIdx.x) * 4;
   if (t0 >= L) return;
@@ -556,12 +559,12 @@ __global__ __launch_bounds__(256) void conv_o1_fwd_kernel(const float* __restric
     for (int i = 0; i < 4 + O1_MAXK - 1; ++i) {
       const int g = t0 + i - p;
       const float v = (i < 4 + K - 1) ? xc[min(max(g, 0), L - 1)] : 0.f;      // unconditional load, then select
-      win[i] = (g >= 0 && g < L) ? v : 0.f;
+      win[i] = (g >= 0 && g < L) ? ag_rbf_if(v, rb) : 0.f;
     }
 #pragma unroll
     for (int k = 0; k < O1_MAXK; ++k) {
       if (k >= K) break;
-      const float wk = w[c * K + k];
+      const float wk = ag_rbf_if(w[c * K + k], rb);
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[j] += wk * win[j + k];
     }
@@ -575,7 +578,7 @@ __global__ __launch_bounds__(256) void conv_o1_fwd_kernel(const float* __restric
 __global__ __launch_bounds__(256) void conv_o1_bwdx_kernel(const float* __restrict__ dy, int64_t dy_bs,
                                                            const float* __restrict__ w, float* __restrict__ dx,
                                                            int64_t dx_bs, int64_t dx_cs, int C, int L, int K, int p,
-                                                           int accumulate) {
+                                                           int accumulate, int rb) {
   const int b = blockIdx.z, c = blockIdx.y;
   const int t0 = (blockIdx.x * 256 + threadIdx.x) * 4;
   if (t0 >= L) return;
@@ -586,13 +589,13 @@ __global__ __launch_bounds__(256) void conv_o1_bwdx_kernel(const float* __restri
   for (int i = 0; i < 4 + O1_MAXK - 1; ++i) {
     const int g = t0 + p - (K - 1) + i;
     const float v = (i < 4 + K - 1) ? dyb[min(max(g, 0), L - 1)] : 0.f;        // unconditional load, then select
-    win[i] = (g >= 0 && g < L) ? v : 0.f;
+    win[i] = (g >= 0 && g < L) ? ag_rbf_if(v, rb) : 0.f;
   }
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int k = 0; k < O1_MAXK; ++k) {
     if (k >= K) break;
-    const float wk = w[c * K + k];
+    const float wk = ag_rbf_if(w[c * K + k], rb);
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[j] += wk * win[j + (K - 1) - k];
   }
@@ -607,7 +610,7 @@ __global__ __launch_bounds__(256) void conv_o1_bwdx_kernel(const float* __restri
 __global__ __launch_bounds__(256) void conv_o1_wgrad_kernel(const float* __restrict__ dy, int64_t dy_bs,
                                                             const float* __restrict__ x, int64_t x_bs, int64_t x_cs,
                                                             float* __restrict__ dw, int B, int C, int L, int K, int p,
-                                                            int bper, float* __restrict__ part) {
+                                                            int bper, float* __restrict__ part, int rb) {
   __shared__ float red[17];
   const int c = blockIdx.y;
   const int t0 = (blockIdx.x * 256 + threadIdx.x) * 4;
@@ -624,13 +627,13 @@ __global__ __launch_bounds__(256) void conv_o1_wgrad_kernel(const float* __restr
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float v = dyb[min(t0 + j, L - 1)];      // unconditional load, then select
-        g[j] = (t0 + j < L) ? v : 0.f;
+        g[j] = (t0 + j < L) ? ag_rbf_if(v, rb) : 0.f;
       }
 #pragma unroll
       for (int i = 0; i < 4 + O1_MAXK - 1; ++i) {
         const int q = t0 + i - p;
         const float v = (i < 4 + K - 1) ? xc[min(max(q, 0), L - 1)] : 0.f;
-        win[i] = (q >= 0 && q < L) ? v : 0.f;
+        win[i] = (q >= 0 && q < L) ? ag_rbf_if(v, rb) : 0.f;
       }
 #pragma unroll
       for (int k = 0; k < O1_MAXK; ++k) {
@@ -660,7 +663,7 @@ extern "C" int ag_conv1d_o1_fwd(const float* x, int64_t x_bs, int64_t x_cs, cons
              "ag_conv1d_o1_fwd: bad args (needs stride 1, K <= 9)");
   AG_REQUIRE(L + 2 * pad - K + 1 == L, "ag_conv1d_o1_fwd: needs a length-preserving ('same') conv");
   hipLaunchKernelGGL(conv_o1_fwd_kernel, dim3(ag_cdiv(L, 1024), B), dim3(256), 0, (hipStream_t)stream, x, x_bs, x_cs,
-                     w, bias, y, y_bs, C, L, K, pad, act, slope);
+                     w, bias, y, y_bs, C, L, K, pad, act, slope, (int)(ag_precision() == AG_PREC_BF16));
   AG_CHECK_LAUNCH("ag_conv1d_o1_fwd");
   return AG_OK;
 }
@@ -671,7 +674,7 @@ extern "C" int ag_conv1d_o1_bwd_data(const float* dy, int64_t dy_bs, const float
   AG_REQUIRE(dy && w && dx && B > 0 && C > 0 && L > 0 && K > 0 && K <= O1_MAXK && B <= 65535 && C <= 65535,
              "ag_conv1d_o1_bwd_data: bad args");
   hipLaunchKernelGGL(conv_o1_bwdx_kernel, dim3(ag_cdiv(L, 1024), C, B), dim3(256), 0, (hipStream_t)stream, dy, dy_bs,
-                     w, dx, dx_bs, dx_cs, C, L, K, pad, accumulate);
+                     w, dx, dx_bs, dx_cs, C, L, K, pad, accumulate, (int)(ag_precision() == AG_PREC_BF16));
   AG_CHECK_LAUNCH("ag_conv1d_o1_bwd_data");
   return AG_OK;
 }
@@ -694,7 +697,7 @@ extern "C" int ag_conv1d_o1_wgrad(const float* dy, int64_t dy_bs, const float* x
   const int bper = ag_cdiv(B, gz);
   gz = ag_cdiv(B, bper);
   hipLaunchKernelGGL(conv_o1_wgrad_kernel, dim3(gx, C, gz), dim3(256), 0, (hipStream_t)stream, dy, dy_bs, x, x_bs,
-                     x_cs, dw, B, C, L, K, pad, bper, part);
+                     x_cs, dw, B, C, L, K, pad, bper, part, (int)(ag_precision() == AG_PREC_BF16));
   AG_CHECK_LAUNCH("ag_conv1d_o1_wgrad");
   if (part) return ag_slab_reduce(part, gx * gz, (int64_t)C * K, dw, 1, (hipStream_t)stream);
   return AG_OK;

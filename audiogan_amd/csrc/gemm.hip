@@ -27,6 +27,7 @@ struct GemmP {
   float alpha, beta, slope;
   int act;
   int vecA, vecB;  // 16-B vector loads allowed for A / B
+  int rb;          // AG_PREC_BF16: operands are rounded to bf16 on the way into LDS (fp32 MFMA on rounded values)
   int ksplit;      // > 1: grid.z K slices; partial tiles go to `part` (two-stage, fixed-order reduction) or, when
                    // part == NULL, are added with fp32 atomics into a pre-initialised C
   int kchunk;      // K per slice (multiple of GBK)
@@ -90,13 +91,13 @@ struct KContig {
     for (int it = 0; it < ITER; ++it) v[it] = *reinterpret_cast<const f32x4*>(base[it] + k0);
   }
   template <int PITCH>
-  __device__ __forceinline__ void store(float* S, int tid) const {
+  __device__ __forceinline__ void store(float* S, int tid, int rb = 0) const {
 #pragma unroll
     for (int it = 0; it < ITER; ++it) {
       const int idx = tid + it * 256;
       const int r = idx / GKQ, kq = idx % GKQ;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) S[(kq * 4 + e) * PITCH + r] = v[it][e];
+      for (int e = 0; e < 4; ++e) S[(kq * 4 + e) * PITCH + r] = ag_rbf_if(v[it][e], rb);
     }
   }
 };
@@ -155,12 +156,12 @@ struct RContig {
     for (int it = 0; it < ITER; ++it) v[it] = *reinterpret_cast<const f32x4*>(base[it] + koff);
   }
   template <int PITCH>
-  __device__ __forceinline__ void store(float* S, int tid) const {
+  __device__ __forceinline__ void store(float* S, int tid, int rb = 0) const {
 #pragma unroll
     for (int it = 0; it < ITER; ++it) {
       const int idx = tid + it * 256;
       const int k = idx / R4, r = (idx % R4) * 4;
-      *reinterpret_cast<f32x4*>(S + k * PITCH + r) = v[it];
+      *reinterpret_cast<f32x4*>(S + k * PITCH + r) = ag_rbf4_if(v[it], rb);
     }
   }
 };
@@ -198,8 +199,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
   }
   la.load(p.A, p.lda, m0, p.M, kbeg, p.K, p.vecA, tid);
   lb.load(p.B, p.ldb, n0, p.N, kbeg, p.K, p.vecB, tid);
-  la.template store<PA>(As[0], tid);
-  lb.template store<PB>(Bs[0], tid);
+  la.template store<PA>(As[0], tid, p.rb);
+  lb.template store<PB>(Bs[0], tid, p.rb);
   __syncthreads();
   int buf = 0;
   for (int k0 = kbeg; k0 < kend; k0 += GBK) {
@@ -229,8 +230,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
     }
     if (more) {
-      la.template store<PA>(As[buf ^ 1], tid);
-      lb.template store<PB>(Bs[buf ^ 1], tid);
+      la.template store<PA>(As[buf ^ 1], tid, p.rb);
+      lb.template store<PB>(Bs[buf ^ 1], tid, p.rb);
     }
     __syncthreads();
     buf ^= 1;
@@ -457,6 +458,168 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmP p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// AG_PREC_BF16: 128x128 tile on v_mfma_f32_32x32x16_bf16.  Operands are fp32 in memory; the loaders round them to bf16
+// (RNE) on the way into LDS, so a k-tile of 32 costs half the LDS bytes and 1/8 of the MFMA instructions of the fp32
+// kernels.  LDS image per operand: [128 rows][32 k] bf16 (64-byte rows); the 16-byte chunk c of row r sits in slot
+// c ^ ((r >> 2) & 3) so that the ds_read_b128 of a 16-lane group (16 consecutive rows, one chunk) is conflict free.
+// MFMA operand of lane (row l & 31, half h = l >> 5) for k-step s: chunk 2s + h = k 8h .. 8h+7 of that step.
+//   k-contiguous operands ([rows][K]): a lane loads one float4 (4 k) -> 8 bytes of bf16 -> ds_write_b64
+//   row-contiguous operands ([K][rows]): a lane loads a 4 k x 4 rows micro-tile (4 float4, each coalesced along the
+//   rows), transposes it in registers and writes 4 x 8 bytes
+// Needs K % 4 == 0, 16-byte aligned rows and (row-contiguous operands) rows % 4 == 0; other shapes take gemm_kernel with
+// operands rounded in registers (same sums).
+// ------------------------------------------------------------------------------------------
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x2g __attribute__((ext_vector_type(2)));
+
+template <int T_>      // 0: stored [rows][K] (k contiguous)   1: stored [K][rows]
+struct Bf16Loader {
+  f32x4 v[4];
+  // k-contiguous: 128 rows x 8 float4 per tile = 4 per thread;  row-contiguous: one 4x4 micro-tile per thread
+  __device__ __forceinline__ void load(const float* __restrict__ G, int ld, int r0, int nrows, int k0, int K, int tid) {
+    if (T_ == 0) {
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int idx = tid + 256 * it;
+        const int r = idx >> 3, q = idx & 7;
+        const int k = k0 + 4 * q;
+        const float* src = G + (int64_t)min(r0 + r, nrows - 1) * ld + min(k, K - 4);
+        const f32x4 x = *reinterpret_cast<const f32x4*>(src);
+        v[it] = k < K ? x : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    } else {
+      const int kq = tid >> 5, r4 = tid & 31;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int k = k0 + 4 * kq + i;
+        const f32x4 x = *reinterpret_cast<const f32x4*>(G + (int64_t)min(k, K - 1) * ld + min(r0 + 4 * r4, nrows - 4));
+        v[i] = k < K ? x : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+  }
+  __device__ __forceinline__ void store(char* S, int tid) const {
+    if (T_ == 0) {
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int idx = tid + 256 * it;
+        const int r = idx >> 3, q = idx & 7;
+        u32x2g w = {ag_pack_bf16(v[it][0], v[it][1]), ag_pack_bf16(v[it][2], v[it][3])};
+        *reinterpret_cast<u32x2g*>(S + r * 64 + (((q >> 1) ^ ((r >> 2) & 3)) << 4) + ((q & 1) << 3)) = w;
+      }
+    } else {
+      const int kq = tid >> 5, r4 = tid & 31;
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int r = 4 * r4 + rr;
+        u32x2g w = {ag_pack_bf16(v[0][rr], v[1][rr]), ag_pack_bf16(v[2][rr], v[3][rr])};
+        *reinterpret_cast<u32x2g*>(S + r * 64 + (((kq >> 1) ^ ((r >> 2) & 3)) << 4) + ((kq & 1) << 3)) = w;
+      }
+    }
+  }
+};
+
+template <int TA, int TB>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmP p) {
+  constexpr int BM = 128, BN = 128, TILEB = 128 * 64;      // bytes per operand tile
+  __shared__ __attribute__((aligned(16))) char sm[2 * 2 * TILEB];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int wm0 = (wid >> 1) * 64, wn0 = (wid & 1) * 64;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  Bf16Loader<TA> la;
+  Bf16Loader<(TB == 1 ? 0 : 1)> lb;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  const int kbeg = blockIdx.z * p.kchunk;
+  const int kend = (kbeg + p.kchunk < p.K) ? kbeg + p.kchunk : p.K;
+  la.load(p.A, p.lda, m0, p.M, kbeg, kend, tid);
+  lb.load(p.B, p.ldb, n0, p.N, kbeg, kend, tid);
+  la.store(sm, tid);
+  lb.store(sm + TILEB, tid);
+  __syncthreads();
+  int buf = 0;
+  for (int k0 = kbeg; k0 < kend; k0 += 32) {
+    const bool more = k0 + 32 < kend;
+    if (more) {
+      la.load(p.A, p.lda, m0, p.M, k0 + 32, kend, tid);
+      lb.load(p.B, p.ldb, n0, p.N, k0 + 32, kend, tid);
+    }
+    const char* As = sm + buf * 2 * TILEB;
+    const char* Bs = As + TILEB;
+#pragma unroll
+    for (int s_ = 0; s_ < 2; ++s_) {
+      bf16x8 av[2], bv[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int m = wm0 + 32 * i + l31;
+        av[i] = *reinterpret_cast<const bf16x8*>(As + m * 64 + (((2 * s_ + h) ^ ((m >> 2) & 3)) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int n = wn0 + 32 * j + l31;
+        bv[j] = *reinterpret_cast<const bf16x8*>(Bs + n * 64 + (((2 * s_ + h) ^ ((n >> 2) & 3)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) {
+      la.store(sm + (buf ^ 1) * 2 * TILEB, tid);
+      lb.store(sm + (buf ^ 1) * 2 * TILEB + TILEB, tid);
+    }
+    __syncthreads();
+    buf ^= 1;
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = m0 + wm0 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
+      if (row >= p.M) continue;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int col = n0 + wn0 + 32 * j + l31;
+        if (col >= p.N) continue;
+        float v = p.alpha * acc[i][j][e];
+        float* dst = p.C + (int64_t)row * p.ldc + col;
+        if (p.ksplit > 1) {
+          if (p.part) {
+            p.part[((int64_t)blockIdx.z * p.M + row) * p.N + col] = v;
+            continue;
+          }
+          if (blockIdx.z == 0) {
+            if (p.bias) v += p.bias[col];
+            if (p.res) v += p.res[(int64_t)row * p.ldres + col];
+          }
+          atomicAdd(dst, v);
+          continue;
+        }
+        if (p.beta != 0.f) v += p.beta * *dst;
+        if (p.bias) v += p.bias[col];
+        if (p.res) v += p.res[(int64_t)row * p.ldres + col];
+        *dst = ag_apply_act(v, p.act, p.slope);
+      }
+    }
+}
+
+static int launch_gemm_bf16(const GemmP& p, int ta, int tb, hipStream_t st) {
+  dim3 grid(ag_cdiv(p.N, 128), ag_cdiv(p.M, 128), p.ksplit);
+  if (ta == 0 && tb == 0) hipLaunchKernelGGL((gemm_bf16_kernel<0, 0>), grid, dim3(256), 0, st, p);
+  if (ta == 0 && tb == 1) hipLaunchKernelGGL((gemm_bf16_kernel<0, 1>), grid, dim3(256), 0, st, p);
+  if (ta == 1 && tb == 0) hipLaunchKernelGGL((gemm_bf16_kernel<1, 0>), grid, dim3(256), 0, st, p);
+  if (ta == 1 && tb == 1) hipLaunchKernelGGL((gemm_bf16_kernel<1, 1>), grid, dim3(256), 0, st, p);
+  AG_CHECK_LAUNCH("ag_gemm(bf16)");
+  return AG_OK;
+}
+
 // second stage of a split-K product: C = beta*C + sum_z part[z] + bias + res.  8 threads per output element: thread zq
 // sums slabs z = zq, zq + 8, ... ascending, then the 8 partial sums are added in the order zq = 0..7 (fixed order).
 __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float* __restrict__ part, int Z, int64_t pitch,
@@ -531,9 +694,10 @@ extern "C" int ag_gemm(const float* A, int lda, int ta, const float* B, int ldb,
   p.alpha = alpha; p.beta = beta; p.slope = slope; p.act = act;
   p.vecA = aligned16(A) && (lda % 4 == 0);
   p.vecB = aligned16(B) && (ldb % 4 == 0);
+  p.rb = ag_precision() == AG_PREC_BF16;
   hipStream_t st = (hipStream_t)stream;
   p.ksplit = 1;
-  p.kchunk = ag_roundup(K, GBK);
+  p.kchunk = ag_roundup(K, 32);
   const int64_t big = (int64_t)ag_cdiv(M, 128) * ag_cdiv(N, 128);
   const bool use128 = M > 64 && N > 64 && (big >= 192 || K >= 2048);
   const int64_t tiles = use128 ? big : (int64_t)ag_cdiv(M, 64) * ag_cdiv(N, 64);
@@ -551,7 +715,7 @@ extern "C" int ag_gemm(const float* A, int lda, int ta, const float* B, int ldb,
     if (slabs && (int64_t)ks * mn > ws.numel) ks = (int)(ws.numel / mn);
     if (ks >= 2 && (slabs || beta == 0.f || beta == 1.f)) {
       p.ksplit = ks;
-      p.kchunk = ag_roundup(ag_cdiv(K, ks), GBK);
+      p.kchunk = ag_roundup(ag_cdiv(K, ks), 32);
       p.ksplit = ag_cdiv(K, p.kchunk);
       if (slabs) {
         p.part = ws.p;
@@ -570,11 +734,17 @@ extern "C" int ag_gemm(const float* A, int lda, int ta, const float* B, int ldb,
     }
   }
   int rc;
-  if (use128) {
+  // bf16 mode: the bf16-MFMA kernel takes every shape with more than one row tile's worth of work whose operands
+  // can be read 16 bytes at a time; the rest runs the fp32 kernels on operands rounded in registers
+  const bool bf16k = p.rb && M > 32 && N > 32 && p.vecA && p.vecB && K % 4 == 0 && p.kchunk % 32 == 0 &&
+                     (ta == 0 || (M % 4 == 0 && M >= 4)) && (tb == 1 || (N % 4 == 0 && N >= 4));
+  if (bf16k) {
+    rc = launch_gemm_bf16(p, ta, tb, st);
+  } else if (use128) {
     // LDS-DMA variant: whole 16-k tiles only, 16-byte aligned rows, row-contiguous operands with rows % 4 == 0
     // (AG_GEMM_NODMA=1 in the environment forces the register-staged kernel: A/B switch for tools/prof_gemm.py)
     const bool dma = p.vecA && p.vecB && K % 16 == 0 && p.kchunk % 16 == 0 && (ta == 0 || M % 4 == 0) &&
-                     (tb == 1 || N % 4 == 0) && M >= 4 && N >= 4 && getenv("AG_GEMM_NODMA") == nullptr;
+                     (tb == 1 || N % 4 == 0) && M >= 4 && N >= 4 && !p.rb && getenv("AG_GEMM_NODMA") == nullptr;
     rc = dma ? launch_gemm_dma(p, ta, tb, st) : launch_gemm<2, 2, 2, 2>(p, ta, tb, st);  // 128x128
   } else {
     rc = launch_gemm<1, 1, 2, 2>(p, ta, tb, st);              // 64x64

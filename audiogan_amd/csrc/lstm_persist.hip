@@ -46,6 +46,7 @@ struct PersistFwdP {
   int T, B, H, ndir;
   int nbt;             // batch tiles
   int ntile;           // H / 8
+  int rb;              // AG_PREC_BF16: both operands of the recurrent product rounded to bf16
 };
 
 __device__ __forceinline__ bool ps_wait_flags(unsigned* hdr, const unsigned* flags, int n, unsigned want, int lane) {
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(512) void lstm_persist_fwd_kernel(const PersistFwdP
     const int k4n = H >> 2;
     for (int idx = tid; idx < 32 * k4n; idx += 512) {
       const int j = idx / k4n, k4 = idx - j * k4n;
-      const f32x4 v = *reinterpret_cast<const f32x4*>(D.whh + (int64_t)((j >> 3) * H + u0 + (j & 7)) * H + 4 * k4);
+      const f32x4 v = ag_rbf4_if(*reinterpret_cast<const f32x4*>(D.whh + (int64_t)((j >> 3) * H + u0 + (j & 7)) * H + 4 * k4), p.rb);
       *reinterpret_cast<f32x4*>(wl + ((size_t)((k4 >> 1) * 2 + (k4 & 1)) * 32 + j) * 4) = v;
     }
   }
@@ -154,7 +155,7 @@ __global__ __launch_bounds__(512) void lstm_persist_fwd_kernel(const PersistFwdP
             const f32x4 b = *reinterpret_cast<const f32x4*>(wrow + (size_t)q * 256);
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-              acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a[i][e]), b[e], acc, 0, 0, 0);
+              acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ag_rbf_if(__uint_as_float(a[i][e]), p.rb), b[e], acc, 0, 0, 0);
           }
         }
       }
@@ -270,6 +271,7 @@ extern "C" int ag_lstm_seq_fwd_persist(float* const* pre, const float* const* wh
   p.hdr = (unsigned*)ws;
   p.xbuf = (float*)((char*)ws + PS_HDR_BYTES);
   p.T = T; p.B = B; p.H = H; p.ndir = ndir; p.nbt = nbt; p.ntile = H / 8;
+  p.rb = ag_precision() == AG_PREC_BF16;
   const size_t lds = ((size_t)32 * H + 8 * 1024) * sizeof(float);
   const int grid = ndir * nbt * p.ntile;
   if (rt == 1) {
@@ -318,6 +320,7 @@ struct PersistBwdP {
   int T, B, H, ndir;
   int nbt;              // 16-clip tiles
   int ntile;            // H / 32
+  int rb;               // AG_PREC_BF16: both operands of the recurrent product rounded to bf16
 };
 
 template <int NU>       // 16-k units per wave: 4H = 8 waves * NU * 16
@@ -341,7 +344,7 @@ __global__ __launch_bounds__(512) void lstm_persist_bwd_kernel(const PersistBwdP
     for (int e = 0; e < 4; ++e)
 #pragma unroll
       for (int c = 0; c < 2; ++c)
-        wreg[u][e][c] = D.whh[(int64_t)((wid * NU + u) * 16 + 4 * g + e) * H + n0 + 16 * c + li];
+        wreg[u][e][c] = ag_rbf_if(D.whh[(int64_t)((wid * NU + u) * 16 + 4 * g + e) * H + n0 + 16 * c + li], p.rb);
 
   unsigned* flags = p.hdr + PS_FLAG_OFF + grp * ntile;
   // epilogue role: thread <-> (clip row, unit)
@@ -383,7 +386,7 @@ __global__ __launch_bounds__(512) void lstm_persist_bwd_kernel(const PersistBwdP
           for (int e = 0; e < 4; ++e)
 #pragma unroll
             for (int c = 0; c < 2; ++c)
-              acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[i][e]), wreg[ub + i][e][c], acc[c], 0, 0, 0);
+              acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(ag_rbf_if(__uint_as_float(a[i][e]), p.rb), wreg[ub + i][e][c], acc[c], 0, 0, 0);
       }
     }
     // C layout of a 16x16 tile: col = lane & 15, row = 4 * (lane >> 4) + e
@@ -464,6 +467,7 @@ extern "C" int ag_lstm_seq_bwd_persist(const float* const* gates, const float* c
   }
   p.dy = dy; p.valid = valid_i64; p.hdr = (unsigned*)ws;
   p.T = T; p.B = B; p.H = H; p.ndir = ndir; p.nbt = ag_cdiv(B, 16); p.ntile = H / 32;
+  p.rb = ag_precision() == AG_PREC_BF16;
   const int grid = ndir * p.nbt * p.ntile;
   switch (H) {
     case 512: hipLaunchKernelGGL(lstm_persist_bwd_kernel<16>, dim3(grid), dim3(512), 0, st, p); break;

@@ -35,6 +35,7 @@ struct SkinnyP {
   int tb;        // 1: B stored [N][K]; 0: B stored [K][N]
   int act;
   float slope, beta;
+  int rb;        // AG_PREC_BF16: operands rounded to bf16 in registers
   int mtiles;    // grid.z = nprob * mtiles
   float* part;   // K split over workgroups (gridDim.y > 1): partial [gridDim.y][nprob][M][N] (two-stage reduction)
                  // or NULL -> fp32 atomics into C
@@ -47,12 +48,16 @@ struct SkinnyP {
 // vmcnt(0) per k-step, i.e. one dependent L2 round trip per 8 k instead of one per batch.
 template <int UNR>
 __device__ __forceinline__ void nt_batch(f32x16& acc, const float* __restrict__ ar,
-                                         const float* __restrict__ br, int k) {
+                                         const float* __restrict__ br, int k, int rb) {
   f32x4 a[UNR], b[UNR];
 #pragma unroll
   for (int u = 0; u < UNR; ++u) {
     b[u] = *reinterpret_cast<const f32x4*>(br + k + 8 * u);
     a[u] = *reinterpret_cast<const f32x4*>(ar + k + 8 * u);
+  }
+  if (rb) {
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) { a[u] = ag_rbf4_if(a[u], 1); b[u] = ag_rbf4_if(b[u], 1); }
   }
 #pragma unroll
   for (int u = 0; u < UNR; ++u)
@@ -62,26 +67,35 @@ __device__ __forceinline__ void nt_batch(f32x16& acc, const float* __restrict__ 
 
 __device__ __forceinline__ void skinny_core_nt(f32x16& acc, const float* __restrict__ arow, bool aok,
                                                const float* __restrict__ brow, bool bok, int k0, int k1,
-                                               int h) {
+                                               int h, int rb) {
   (void)aok; (void)bok;
   const float* ar = arow + 4 * h;
   const float* br = brow + 4 * h;
   int k = k0;
-  for (; k + 64 <= k1; k += 64) nt_batch<8>(acc, ar, br, k);
-  if (k + 32 <= k1) { nt_batch<4>(acc, ar, br, k); k += 32; }
-  if (k + 16 <= k1) { nt_batch<2>(acc, ar, br, k); k += 16; }
-  if (k + 8 <= k1) nt_batch<1>(acc, ar, br, k);
+  for (; k + 64 <= k1; k += 64) nt_batch<8>(acc, ar, br, k, rb);
+  if (k + 32 <= k1) { nt_batch<4>(acc, ar, br, k, rb); k += 32; }
+  if (k + 16 <= k1) { nt_batch<2>(acc, ar, br, k, rb); k += 16; }
+  if (k + 8 <= k1) nt_batch<1>(acc, ar, br, k, rb);
 }
 
 // the same for MT 32-row tiles that share the B registers (acc[t], ar[t])
 template <int UNR, int MT>
-__device__ __forceinline__ void nt_batch_mt(f32x16* acc, const float* const* ar, const float* __restrict__ br, int k) {
+__device__ __forceinline__ void nt_batch_mt(f32x16* acc, const float* const* ar, const float* __restrict__ br, int k,
+                                            int rb) {
   f32x4 a[MT][UNR], b[UNR];
 #pragma unroll
   for (int u = 0; u < UNR; ++u) {
     b[u] = *reinterpret_cast<const f32x4*>(br + k + 8 * u);
 #pragma unroll
     for (int t = 0; t < MT; ++t) a[t][u] = *reinterpret_cast<const f32x4*>(ar[t] + k + 8 * u);
+  }
+  if (rb) {
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      b[u] = ag_rbf4_if(b[u], 1);
+#pragma unroll
+      for (int t = 0; t < MT; ++t) a[t][u] = ag_rbf4_if(a[t][u], 1);
+    }
   }
 #pragma unroll
   for (int u = 0; u < UNR; ++u)
@@ -93,22 +107,22 @@ __device__ __forceinline__ void nt_batch_mt(f32x16* acc, const float* const* ar,
 
 template <int MT>
 __device__ __forceinline__ void skinny_core_nt_mt(f32x16* acc, const float* const* arow, const float* __restrict__ brow,
-                                                  int k0, int k1, int h) {
+                                                  int k0, int k1, int h, int rb) {
   const float* ar[MT];
 #pragma unroll
   for (int t = 0; t < MT; ++t) ar[t] = arow[t] + 4 * h;
   const float* br = brow + 4 * h;
   int k = k0;
-  for (; k + 64 <= k1; k += 64) nt_batch_mt<8, MT>(acc, ar, br, k);
-  if (k + 32 <= k1) { nt_batch_mt<4, MT>(acc, ar, br, k); k += 32; }
-  if (k + 16 <= k1) { nt_batch_mt<2, MT>(acc, ar, br, k); k += 16; }
-  if (k + 8 <= k1) nt_batch_mt<1, MT>(acc, ar, br, k);
+  for (; k + 64 <= k1; k += 64) nt_batch_mt<8, MT>(acc, ar, br, k, rb);
+  if (k + 32 <= k1) { nt_batch_mt<4, MT>(acc, ar, br, k, rb); k += 32; }
+  if (k + 16 <= k1) { nt_batch_mt<2, MT>(acc, ar, br, k, rb); k += 16; }
+  if (k + 8 <= k1) nt_batch_mt<1, MT>(acc, ar, br, k, rb);
 }
 
 // B stored [K][N]: lane j reads B[k][n0+j] (coalesced along n)
 template <int UNR>
 __device__ __forceinline__ void nn_batch(f32x16& acc, const float* __restrict__ ar,
-                                         const float* __restrict__ bc, int ldb, int k) {
+                                         const float* __restrict__ bc, int ldb, int k, int rb) {
   f32x4 a[UNR];
   float b[UNR][4];
 #pragma unroll
@@ -116,6 +130,14 @@ __device__ __forceinline__ void nn_batch(f32x16& acc, const float* __restrict__ 
 #pragma unroll
     for (int e = 0; e < 4; ++e) b[u][e] = bc[(int64_t)(k + 8 * u + e) * ldb];
     a[u] = *reinterpret_cast<const f32x4*>(ar + k + 8 * u);
+  }
+  if (rb) {
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      a[u] = ag_rbf4_if(a[u], 1);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) b[u][e] = ag_rbf(b[u][e]);
+    }
   }
 #pragma unroll
   for (int u = 0; u < UNR; ++u)
@@ -125,14 +147,14 @@ __device__ __forceinline__ void nn_batch(f32x16& acc, const float* __restrict__ 
 
 __device__ __forceinline__ void skinny_core_nn(f32x16& acc, const float* __restrict__ arow, bool aok,
                                                const float* __restrict__ bcol, int ldb, bool bok, int k0,
-                                               int k1, int h) {
+                                               int k1, int h, int rb) {
   (void)aok; (void)bok;
   const float* ar = arow + 4 * h;
   const float* bc = bcol + (int64_t)4 * h * ldb;
   int k = k0;
-  for (; k + 32 <= k1; k += 32) nn_batch<4>(acc, ar, bc, ldb, k);
-  if (k + 16 <= k1) { nn_batch<2>(acc, ar, bc, ldb, k); k += 16; }
-  if (k + 8 <= k1) nn_batch<1>(acc, ar, bc, ldb, k);
+  for (; k + 32 <= k1; k += 32) nn_batch<4>(acc, ar, bc, ldb, k, rb);
+  if (k + 16 <= k1) { nn_batch<2>(acc, ar, bc, ldb, k, rb); k += 16; }
+  if (k + 8 <= k1) nn_batch<1>(acc, ar, bc, ldb, k, rb);
 }
 
 // sum the per-wave 32x32 accumulators through LDS; afterwards red[0..1023] holds the block total,
@@ -166,9 +188,9 @@ __global__ __launch_bounds__(1024) void skinny_gemm_kernel(const SkinnyP p) {
   const bool bok = (n0 + l31) < p.N, aok = (m0 + l31) < p.M;
   const float* arow = Q.A + (int64_t)(aok ? m0 + l31 : 0) * p.lda;
   if (p.tb)
-    skinny_core_nt(acc, arow, aok, Q.B + (int64_t)(bok ? n0 + l31 : 0) * p.ldb, bok, k0, k1, h);
+    skinny_core_nt(acc, arow, aok, Q.B + (int64_t)(bok ? n0 + l31 : 0) * p.ldb, bok, k0, k1, h, p.rb);
   else
-    skinny_core_nn(acc, arow, aok, Q.B + (bok ? n0 + l31 : 0), p.ldb, bok, k0, k1, h);
+    skinny_core_nn(acc, arow, aok, Q.B + (bok ? n0 + l31 : 0), p.ldb, bok, k0, k1, h, p.rb);
   block_reduce_acc(acc, red, nw, wid, lane);
   const bool direct = gridDim.y == 1;
   for (int o = threadIdx.x; o < 1024; o += blockDim.x) {
@@ -212,8 +234,8 @@ __global__ __launch_bounds__(1024) void skinny16_nt_kernel(const SkinnyP p) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int u = min(ub + i, u1 - 1);
-      a[i] = *reinterpret_cast<const f32x4*>(ar + 16 * u);
-      b[i] = *reinterpret_cast<const f32x4*>(br + 16 * u);
+      a[i] = ag_rbf4_if(*reinterpret_cast<const f32x4*>(ar + 16 * u), p.rb);
+      b[i] = ag_rbf4_if(*reinterpret_cast<const f32x4*>(br + 16 * u), p.rb);
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -239,6 +261,7 @@ __global__ __launch_bounds__(1024) void skinny16_nt_kernel(const SkinnyP p) {
 
 static int launch_skinny(SkinnyP& p, int nprob, int accumulate_atomic, hipStream_t st, AgWs ws = AgWs{nullptr, 0}) {
   p.part = nullptr;
+  p.rb = ag_precision() == AG_PREC_BF16;
   const int gx = ag_cdiv(p.N, 32);
   const int KU = p.K / 8;
   p.mtiles = ag_cdiv(p.M, 32);
@@ -333,6 +356,7 @@ struct LstmStepP {
   const int64_t* valid;
   int B, H;
   int skip_h;          // 1: h_prev is known to be zero (first step) -> skip that product
+  int rb;              // AG_PREC_BF16: operands rounded to bf16 in registers
 };
 
 template <int MT>      // 32-clip row tiles per workgroup (they share the weight registers)
@@ -389,13 +413,13 @@ __global__ __launch_bounds__(512) void lstm_step_fwd_kernel(const LstmStepP p) {
     const int e1 = s1 < KxU ? s1 : KxU;
 #pragma unroll
     for (int t = 0; t < MT; ++t) arow[t] = D.x + (int64_t)min(m0 + 32 * t + l31, B - 1) * D.ldx;
-    skinny_core_nt_mt<MT>(acc, arow, D.wx + (int64_t)row * D.ldwx, s0 * 8, e1 * 8, h);
+    skinny_core_nt_mt<MT>(acc, arow, D.wx + (int64_t)row * D.ldwx, s0 * 8, e1 * 8, h, p.rb);
   }
   if (s1 > KxU) {
     const int b0 = (s0 > KxU ? s0 : KxU) - KxU;
 #pragma unroll
     for (int t = 0; t < MT; ++t) arow[t] = D.h_prev + (int64_t)min(m0 + 32 * t + l31, B - 1) * H;
-    skinny_core_nt_mt<MT>(acc, arow, D.whh + (int64_t)row * H, b0 * 8, (s1 - KxU) * 8, h);
+    skinny_core_nt_mt<MT>(acc, arow, D.whh + (int64_t)row * H, b0 * 8, (s1 - KxU) * 8, h, p.rb);
   }
   // per-wave accumulators -> LDS, element (t, e, lane) of wave w at red[(w*MT + t)*1024 + e*64 + lane]
 #pragma unroll
@@ -441,8 +465,9 @@ __global__ __launch_bounds__(512) void lstm_step_fwd_kernel(const LstmStepP p) {
   }
 }
 
-static int launch_lstm_step(const LstmStepP& p, int ndir, hipStream_t st) {
+static int launch_lstm_step(LstmStepP& p, int ndir, hipStream_t st) {
   const int nw = 8;
+  p.rb = ag_precision() == AG_PREC_BF16;
   // one wave of workgroups on the 256 CUs: two 32-clip tiles per workgroup once single tiles would not fit
   if ((int64_t)ag_cdiv(p.H, 8) * ndir * ag_cdiv(p.B, 32) > 256) {
     dim3 grid(ag_cdiv(p.H, 8), ndir, ag_cdiv(p.B, 64));
@@ -606,6 +631,7 @@ struct BwdStepP {
   BwdStepDir d[2];
   const int64_t* valid;
   int B, H;
+  int rb;               // AG_PREC_BF16: operands rounded to bf16 in registers
 };
 
 // 16 clips x 16 units per workgroup (v_mfma_f32_16x16x4_f32: lane (i = l&15, g = l>>4) supplies
@@ -688,6 +714,17 @@ __global__ __launch_bounds__(1024) void lstm_step_bwd_kernel(const BwdStepP p) {
           }
         }
       }
+      if (p.rb) {
+#pragma unroll
+        for (int i = 0; i < UB; ++i) {
+#pragma unroll
+          for (int t = 0; t < MT; ++t) a[t][i] = ag_rbf4_if(a[t][i], 1);
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int c = 0; c < NT; ++c) b[c][i][e] = ag_rbf(b[c][i][e]);
+        }
+      }
 #pragma unroll
       for (int i = 0; i < UB; ++i) {
         if (ub + i < u1) {
@@ -734,8 +771,9 @@ __global__ __launch_bounds__(1024) void lstm_step_bwd_kernel(const BwdStepP p) {
   if (D.dh_pass_out) D.dh_pass_out[o] = 0.f;
 }
 
-static void launch_bwd_step(const BwdStepP& q, int ndir, hipStream_t st) {
+static void launch_bwd_step(BwdStepP& q, int ndir, hipStream_t st) {
   const int B = q.B, H = q.H;
+  q.rb = ag_precision() == AG_PREC_BF16;
   // one wave of workgroups fills the 256 CUs; once 16x16 tiles would need more, widen the tile along the
   // units (full 128-byte W_hh lines per workgroup)
   if ((int64_t)(H / 16) * ndir * ag_cdiv(B, 16) > 256)
@@ -763,6 +801,7 @@ extern "C" int ag_lstm_front_bwd_step(const float* dxa, int lddxa, const float* 
              (uintptr_t)gx_out) & 15) == 0, "ag_lstm_front_bwd_step: rows must be 16-byte aligned");
   BwdStepP q;
   q.valid = nullptr; q.B = B; q.H = H;
+  q.rb = ag_precision() == AG_PREC_BF16;
   BwdStepDir& D = q.d[0];
   D.dg_next = dxa; D.lda = lddxa; D.Kp = Kp; D.whh = w_proj;
   D.ax = x; D.ldax = ldx; D.aout = gx_out; D.ldaout = ldgx;

@@ -10,9 +10,12 @@ import torch.distributed as dist
 class GradBucket(object):
     """Owns the flat gradient buffer of one network."""
 
-    def __init__(self, params, group=None, early=None, force_collective=False):
+    def __init__(self, params, group=None, early=None, force_collective=False, comm_dtype='f32'):
         """``early``: parameters whose gradients are final before the rest of backward has run (they
-        are laid out first, so their all-reduce can be issued while backward continues)."""
+        are laid out first, so their all-reduce can be issued while backward continues).
+        ``comm_dtype='bf16'`` (BASELINE configs[2]): the gradients cross xGMI as bfloat16 - each rank's fp32 sum is
+        rounded once into a bf16 staging buffer, RCCL sums that, and the result is widened back into the fp32 bucket
+        the optimiser reads (half the bytes per step; accumulation inside a rank and the optimiser state stay fp32)."""
         params = [p for p in params]
         early = [p for p in (early or [])]
         eid = set(id(p) for p in early)
@@ -22,6 +25,9 @@ class GradBucket(object):
         n = sum(p.numel() for p in self.params)
         dev = self.params[0].device
         self.flat = torch.zeros(n, device=dev, dtype=torch.float32)
+        assert comm_dtype in ('f32', 'bf16')
+        self.comm = torch.zeros(n, device=dev, dtype=torch.bfloat16) if comm_dtype == 'bf16' else None
+        self._pending = None
         o = 0
         for p in self.params:
             p.grad = self.flat[o:o + p.numel()].view(p.shape)
@@ -49,17 +55,31 @@ class GradBucket(object):
         (the leading n_early elements) or 'late' (the rest).  async_op=True: the collective runs on
         RCCL's own stream (after everything already enqueued on the current stream); call wait()."""
         if self.world > 1 or self.force:
-            buf = {'all': self.flat, 'early': self.flat[:self.n_early], 'late': self.flat[self.n_early:]}[part]
-            if buf.numel():
+            lo, hi = {'all': (0, self.flat.numel()), 'early': (0, self.n_early),
+                      'late': (self.n_early, self.flat.numel())}[part]
+            if hi > lo:
+                buf = self.flat[lo:hi]
+                if self.comm is not None:
+                    buf = self.comm[lo:hi]
+                    buf.copy_(self.flat[lo:hi])            # fp32 -> bf16 (RNE), once per rank
+                    self._pending = (lo, hi)
                 self._work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
                 if not async_op:
                     self._work = None
+                    self._widen()
         return 1.0 / self.world
+
+    def _widen(self):
+        if self._pending is not None:
+            lo, hi = self._pending
+            self.flat[lo:hi].copy_(self.comm[lo:hi])       # bf16 sum -> the fp32 bucket the optimiser reads
+            self._pending = None
 
     def wait(self):
         if self._work is not None:
             self._work.wait()
             self._work = None
+        self._widen()
 
 
 def broadcast_parameters(module, src=0, group=None):

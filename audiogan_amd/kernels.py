@@ -66,6 +66,36 @@ def _bind_ws(numel, dev):
     return ws
 
 
+# ------------------------------------------------------------------------------------
+# precision mode of the contractions (ag_set_precision): 'f32' (default) or 'bf16'
+# ------------------------------------------------------------------------------------
+def set_precision(mode):
+    """'f32': exact fp32 contractions.  'bf16': every contraction rounds both operands to bfloat16 (RNE) and
+    accumulates in fp32 (GEMMs and the persistent recurrent kernels on v_mfma_f32_32x32x16_bf16 / rounded operands);
+    memory, epilogues, losses and the optimiser stay fp32.  Returns the previous mode."""
+    old = 'bf16' if lib.ag_get_precision() == 1 else 'f32'
+    check(lib.ag_set_precision({'f32': 0, 'bf16': 1}[mode]), 'ag_set_precision')
+    return old
+
+
+def get_precision():
+    return 'bf16' if lib.ag_get_precision() == 1 else 'f32'
+
+
+class precision(object):
+    """``with K.precision('bf16'): ...``"""
+
+    def __init__(self, mode):
+        self.mode = mode
+
+    def __enter__(self):
+        self.old = set_precision(self.mode)
+        return self
+
+    def __exit__(self, *exc):
+        set_precision(self.old)
+
+
 def wpa_numel(d0, d1, K):
     return int(lib.ag_wpa_numel(d0, d1, K))
 
@@ -441,7 +471,11 @@ def _work_gemm(A, B, Cm, ta=False, tb=False, *a_, **kw):
     # mirrors ag_gemm's dispatch: the LDS-DMA kernel takes the 128x128 case when K % 16 == 0 and rows are 16-B aligned
     dma = use128 and Kd % 16 == 0 and (not ta or M % 4 == 0) and (tb or N % 4 == 0) and \
         A.stride(0) % 4 == 0 and B.stride(0) % 4 == 0 and _al16(A) and _al16(B)
-    if dma:
+    bf = (lib.ag_get_precision() == 1 and M > 32 and N > 32 and Kd % 4 == 0 and A.stride(0) % 4 == 0 and
+          B.stride(0) % 4 == 0 and _al16(A) and _al16(B) and (not ta or M % 4 == 0) and (tb or N % 4 == 0))
+    if bf:
+        key = 'gemm_bf16_kernel<%d,%d>' % (int(ta), int(tb))
+    elif dma:
         key = 'gemm_dma_kernel<%d,%d>' % (int(ta), int(tb))
     else:
         key = 'gemm_kernel<%s,%d,%d>' % ('2,2,2,2' if use128 else '1,1,2,2', int(ta), int(tb))

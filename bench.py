@@ -38,6 +38,7 @@ import torch.distributed as dist  # noqa: E402
 L = 8192
 FRAME = 256
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32 matrix peak (spec)
+PEAK_BF16_MFMA_TFLOPS = 2500.0 # MI355X_MICROARCH.md: dense bf16 matrix peak (spec)
 PEAK_HBM_GBS = 8000.0
 
 
@@ -146,6 +147,9 @@ def main():
     ap.add_argument('--batch', type=int, default=64, help='clips per GPU')
     ap.add_argument('--opt', default='adam', choices=['adam', 'rmsprop'],
                     help='adam = north_star; rmsprop = audiogan.py:693-694')
+    ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'],
+                    help='f32 = BASELINE configs[1] (the headline); bf16 = configs[2]: every contraction rounds its '
+                         'operands to bfloat16 and accumulates in fp32, gradients cross ranks as bfloat16')
     ap.add_argument('--cpu-batch', type=int, default=64)
     ap.add_argument('--cpu-steps', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -189,14 +193,17 @@ def main():
     import audiogan_amd as A
     from audiogan_amd import train, ddp, kernels as K
 
+    K.set_precision(args.dtype)
     g, d, opt_g, opt_d = build_models(A, dev, args.opt)
     hook_d = hook_g = None
     multi = world > 1 or args.force_phases
     if multi:
         ddp.broadcast_parameters(g)
         ddp.broadcast_parameters(d)
-        bd = ddp.GradBucket(list(d.parameters()), early=d.early_params(), force_collective=rehearse)
-        bg = ddp.GradBucket(list(g.parameters()), early=g.early_params(), force_collective=rehearse)
+        bd = ddp.GradBucket(list(d.parameters()), early=d.early_params(), force_collective=rehearse,
+                            comm_dtype=args.dtype)
+        bg = ddp.GradBucket(list(g.parameters()), early=g.early_params(), force_collective=rehearse,
+                            comm_dtype=args.dtype)
         opt_d.bucket, opt_g.bucket = bd, bg
         hook_d, hook_g = bd.all_reduce, bg.all_reduce
     batch = synthetic_batch(args.batch, dev, seed=1000 + rank)
@@ -369,10 +376,14 @@ def main():
             'metric': 'audio-samples/sec per G+D train step (8 kHz, 8192-sample clips)',
             'value': value, 'unit': 'audio-samples/sec', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': ms, 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'C2: full audiogan.py Conv1d/LSTM G + D, batch %d per GPU, 8192-sample '
+            'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
+            'config': {'workload': '%s: full audiogan.py Conv1d/LSTM G + D, batch %d per GPU, 8192-sample '
                                    'white-noise clips, frame_size 256 (T=32), canonical G+D step, %s, '
-                                   'per-parameter clip d=1 g=0.1' % (args.batch, args.opt),
+                                   'per-parameter clip d=1 g=0.1%s' % (
+                                       'C2' if args.dtype == 'f32' else 'C3 (the C2 models with bf16 contractions)',
+                                       args.batch, args.opt,
+                                       '' if args.dtype == 'f32' else '; every contraction rounds both operands to '
+                                       'bfloat16 and accumulates in fp32, gradient all-reduce in bfloat16'),
                        'global_batch': world * args.batch, 'clip_len': L,
                        'parallelism': 'dp%d' % world,
                        'launch': ('hipGraph replay (1 graph per step%s)' % ('' if args.no_overlap else
@@ -394,13 +405,14 @@ def main():
             tf = r['flops'] / r['n'] / (avg_ms * 1e-3) / 1e12
             gbs = r['bytes'] / r['n'] / (avg_ms * 1e-3) / 1e9
             share = disc[dominant]['ms'] / sum(v['ms'] for v in disc.values())
-            mfma_bound = tf / PEAK_F32_MFMA_TFLOPS >= gbs / PEAK_HBM_GBS
+            peak_tf = PEAK_BF16_MFMA_TFLOPS if 'bf16' in dominant else PEAK_F32_MFMA_TFLOPS
+            mfma_bound = tf / peak_tf >= gbs / PEAK_HBM_GBS
             out['roofline'] = {
                 'kernel': dominant, 'bound': 'mfma' if mfma_bound else 'hbm',
                 'achieved': tf if mfma_bound else gbs,
-                'peak': PEAK_F32_MFMA_TFLOPS if mfma_bound else PEAK_HBM_GBS,
+                'peak': peak_tf if mfma_bound else PEAK_HBM_GBS,
                 'unit': 'TFLOP/s' if mfma_bound else 'GB/s',
-                'frac': (tf / PEAK_F32_MFMA_TFLOPS) if mfma_bound else (gbs / PEAK_HBM_GBS),
+                'frac': (tf / peak_tf) if mfma_bound else (gbs / PEAK_HBM_GBS),
                 'traffic': pmc_traffic(dominant), 'launches_per_step': r['n'] / r.get('per_step_div', args.steps),
                 'avg_launch_us': avg_ms * 1e3,
                 'share_of_gpu_time': share,

@@ -206,6 +206,18 @@ int ag_gru_cell_bwd(const float* gates_act, const float* gh, const float* h_prev
                     const float* dh, int lddh, float* dgi, float* dgh, float* dh_prev, int lddhp, int B,
                     int H, void* stream);
 
+/* Precision mode of every contraction launched by this host thread from now on (default 0 = fp32).
+ *   1 = bf16: each contraction (conv / transposed conv / linear / recurrent products, in their forward,
+ *   backward-data and backward-weight forms) rounds BOTH operands to bfloat16 (round-to-nearest-even) and accumulates in
+ *   fp32; tensors in memory, epilogues, losses and the optimiser stay fp32.  ag_gemm and the persistent recurrent
+ *   kernels run v_mfma_f32_32x32x16_bf16 in this mode; the other kernels round their operands in registers in front of
+ *   the fp32 MFMA (same sums up to the order of the fp32 additions).  Spec: BASELINE.json configs[2] (bf16, 8 GPUs);
+ *   the reference itself is fp32 only. */
+#define AG_PREC_F32 0
+#define AG_PREC_BF16 1
+int ag_set_precision(int mode);
+int ag_get_precision(void);
+
 /* Deterministic cross-workgroup reductions.  Entry points that sum over workgroups (ag_conv1d_wgrad,
  * ag_conv1d_o1_wgrad, ag_channel_sum, ag_leaky_bwd's bias gradient, ag_gemm's split-K products, ag_col_sum,
  * ag_skinny_gemm in accumulate mode, ag_lstm_seq_bwd's unfused fallback, ag_grad_norms) do so in TWO STAGES when a

@@ -104,8 +104,120 @@ def length_mask(size, length):
     return (ar < length.view(b, 1).long()).float()
 
 
+# --------------------------------------------------------------------------------------
+# bf16 mode (BASELINE configs[2]; SURVEY 7 "bf16 ... stated against a bf16-rounded oracle").  The reference is
+# fp32 only; this is the CPU statement of audiogan_amd's AG_PREC_BF16 contract: EVERY contraction (conv,
+# transposed conv, linear, the LSTM / LSTMCell products; forward, backward-data and backward-weight forms)
+# rounds BOTH operands to bfloat16 (round-to-nearest-even) and accumulates in fp32; everything else is fp32.
+#   forward   y = op(rnd(x), rnd(w)) + bias
+#   backward  dx = op_bwd_data(rnd(dy), rnd(w)),  dw = op_bwd_weight(rnd(dy), rnd(x)),  dbias = sum(dy)
+# --------------------------------------------------------------------------------------
+BF16 = [False]
+
+
+def _rnd(x):
+    return x.bfloat16().float()
+
+
+class _RoundFwd(torch.autograd.Function):
+    """rounds the value; the gradient passes through unchanged"""
+
+    @staticmethod
+    def forward(ctx, x):
+        return _rnd(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+class _RoundBwd(torch.autograd.Function):
+    """identity; rounds the gradient that comes back"""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _rnd(g)
+
+
+class bf16_mode(object):
+    """``with O.bf16_mode(): ...`` - F.conv1d / F.conv_transpose1d / F.linear round their operands (and the gradient
+    entering their backward); nn.LSTMCell and the LSTM layers of ``dynamic_rnn`` are computed from F.linear products
+    so that their operands are rounded the same way."""
+
+    def __enter__(self):
+        self._saved = (F.conv1d, F.conv_transpose1d, F.linear, nn.LSTMCell.forward, BF16[0])
+        o_conv, o_convt, o_lin = F.conv1d, F.conv_transpose1d, F.linear
+
+        def _wrap(orig):
+            def op(x, w, bias=None, *a, **k):
+                y = _RoundBwd.apply(orig(_RoundFwd.apply(x), _RoundFwd.apply(w), None, *a, **k))
+                if bias is not None:
+                    y = y + bias.view([1, -1] + [1] * (y.dim() - 2)) if y.dim() > 2 else y + bias
+                return y
+            return op
+
+        F.conv1d, F.conv_transpose1d, F.linear = _wrap(o_conv), _wrap(o_convt), _wrap(o_lin)
+        torch.nn.functional.conv1d, torch.nn.functional.conv_transpose1d = F.conv1d, F.conv_transpose1d
+        torch.nn.functional.linear = F.linear
+
+        def cell_forward(self, x, state):
+            h, c = state
+            gates = F.linear(x, self.weight_ih, self.bias_ih) + F.linear(h, self.weight_hh, self.bias_hh)
+            i, f, g, o = gates.chunk(4, 1)
+            c2 = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(g)
+            return torch.sigmoid(o) * torch.tanh(c2), c2
+
+        nn.LSTMCell.forward = cell_forward
+        BF16[0] = True
+        return self
+
+    def __exit__(self, *exc):
+        F.conv1d, F.conv_transpose1d, F.linear, nn.LSTMCell.forward, BF16[0] = self._saved
+        torch.nn.functional.conv1d, torch.nn.functional.conv_transpose1d = F.conv1d, F.conv_transpose1d
+        torch.nn.functional.linear = F.linear
+
+
+def _lstm_explicit(rnn, seq, length):
+    """nn.LSTM (any layers / directions) over a padded batch with pack/unpack semantics, written with F.linear:
+    steps past a clip's length keep its state and output zeros"""
+    T, B, _ = seq.shape
+    ndir = 2 if rnn.bidirectional else 1
+    H = rnn.hidden_size
+    inp = seq
+    last_h, last_c = [], []
+    lens = length.view(B, 1)
+    for layer in range(rnn.num_layers):
+        outs = []
+        for d in range(ndir):
+            sfx = '_l%d%s' % (layer, '_reverse' if d else '')
+            w_ih, w_hh = getattr(rnn, 'weight_ih' + sfx), getattr(rnn, 'weight_hh' + sfx)
+            b_ih, b_hh = getattr(rnn, 'bias_ih' + sfx), getattr(rnn, 'bias_hh' + sfx)
+            h, c = seq.new_zeros(B, H), seq.new_zeros(B, H)
+            ys = [None] * T
+            for k in range(T):
+                t = k if d == 0 else T - 1 - k
+                gates = F.linear(inp[t], w_ih, b_ih) + F.linear(h, w_hh, b_hh)
+                i, f, g, o = gates.chunk(4, 1)
+                c2 = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(g)
+                h2 = torch.sigmoid(o) * torch.tanh(c2)
+                live = (t < lens).float()
+                h, c = live * h2 + (1 - live) * h, live * c2 + (1 - live) * c
+                ys[t] = live * h2
+            outs.append(torch.stack(ys, 0))
+            last_h.append(h)
+            last_c.append(c)
+        inp = torch.cat(outs, 2)
+    return inp, (torch.stack(last_h, 0), torch.stack(last_c, 0))
+
+
 def dynamic_rnn(rnn, seq, length, initial_state):
     """audiogan.py:214-229: sort by length, pack, run, unpack, unsort."""
+    if BF16[0] and isinstance(rnn, nn.LSTM):
+        return _lstm_explicit(rnn, seq, length)
     len_sorted, order = torch.sort(length, descending=True)
     _, inverse = torch.sort(order)
     packed = pack_padded_sequence(seq[:, order], len_sorted.cpu())

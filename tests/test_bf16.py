@@ -1,0 +1,193 @@
+"""BASELINE configs[2] (bf16): audiogan_amd's AG_PREC_BF16 mode - every contraction rounds both operands to bfloat16
+(RNE) and accumulates in fp32 - against (a) torch ops on rounded operands, kernel by kernel, and (b) the CPU oracle's
+``bf16_mode`` (oracle/audiogan_oracle.py), module by module and for a whole G+D step.
+
+DECLARED TOLERANCE:
+  * one contraction vs the same contraction on rounded operands in fp32: 1e-4 of the output scale (the products are
+    exact in fp32; only the order of the fp32 additions differs);
+  * networks / train step vs the bf16-rounded oracle: every activation / logit / waveform tensor within 1e-2 of its
+    largest magnitude elementwise and 3e-3 in relative L2 norm (an intermediate value that differs in the last fp32
+    bits can round to the other bf16 neighbour, a 2^-8 relative change of that one element); parameter gradients
+    (sums over batch and time in which such flips do not cancel; the weight-norm gain gradients are themselves
+    cancelling projections of them) 2e-2 elementwise and 2e-2 in relative L2 norm;
+  * vs the fp32 oracle: 3e-2 in relative L2 norm (what bf16 operands cost; informative)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import audiogan_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def K():
+    assert torch.cuda.is_available()
+    import audiogan_amd.kernels as K
+    return K
+
+
+@pytest.fixture()
+def bf16(K):
+    old = K.set_precision('bf16')
+    yield
+    K.set_precision(old)
+
+
+def rnd(t):
+    return t.bfloat16().float()
+
+
+def rel_l2(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).norm() / b.norm().clamp(min=1e-30))
+
+
+def close_bf16(got, ref, msg='', elem=1e-2, l2=3e-3):
+    got, ref = got.detach().cpu(), ref.detach().cpu()
+    scale = float(ref.abs().max())
+    assert float((got - ref).abs().max()) <= elem * max(scale, 1e-6), (msg, float((got - ref).abs().max()), scale)
+    if scale > 0:
+        assert rel_l2(got, ref) <= l2, (msg, rel_l2(got, ref))
+
+
+@pytest.mark.parametrize('shape', [(8192, 1024, 1024), (2048, 512, 1480), (130, 70, 36), (64, 4096, 1480),
+                                   (4096, 1480, 8192), (40, 36, 8)])
+@pytest.mark.parametrize('ta,tb', [(False, True), (False, False), (True, False), (True, True)])
+def test_gemm_bf16(K, bf16, shape, ta, tb):
+    M, N, Kd = shape
+    gen = torch.Generator().manual_seed(3)
+    A = torch.randn((Kd, M) if ta else (M, Kd), generator=gen)
+    B = torch.randn((N, Kd) if tb else (Kd, N), generator=gen)
+    bias, res = torch.randn(N, generator=gen), torch.randn(M, N, generator=gen)
+    ref = (rnd(A).t() if ta else rnd(A)).double() @ (rnd(B).t() if tb else rnd(B)).double()
+    ref = F.leaky_relu(ref + bias.double() + res.double(), 0.01)
+    out = torch.empty(M, N).cuda()
+    K.gemm(A.cuda(), B.cuda(), out, ta=ta, tb=tb, bias=bias.cuda(), res=res.cuda(), act=K.ACT_LEAKY)
+    err = float((out.cpu().double() - ref).abs().max())
+    assert err <= 1e-4 * float(ref.abs().max()), (shape, ta, tb, err)
+    # the fp32 result of the UNROUNDED operands is further away: the mode really rounds
+    full = F.leaky_relu((A.t() if ta else A).double() @ (B.t() if tb else B).double() + bias.double() + res.double(), 0.01)
+    if Kd >= 36:
+        assert float((out.cpu().double() - full).abs().max()) > 10 * err
+
+
+def test_gemm_bf16_splitk_weight_gradient(K, bf16):
+    """few output tiles, long reduction (a weight gradient): split-K slabs + fixed-order sum, also in bf16 mode"""
+    gen = torch.Generator().manual_seed(4)
+    dy, x = torch.randn(16384, 512, generator=gen), torch.randn(16384, 256, generator=gen)
+    out = torch.zeros(512, 256).cuda()
+    K.gemm(dy.cuda(), x.cuda(), out, ta=True, beta=1.0)
+    ref = rnd(dy).double().t() @ rnd(x).double()
+    assert float((out.cpu().double() - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
+    out2 = torch.zeros(512, 256).cuda()
+    K.gemm(dy.cuda(), x.cuda(), out2, ta=True, beta=1.0)
+    assert torch.equal(out, out2)
+
+
+LAYERS = [('conv', 1, 128, 17, 8, 8, 2048), ('convT', 128, 16, 16, 8, 4, 256), ('conv', 49, 64, 9, 4, 4, 2048),
+          ('convT', 64, 32, 8, 4, 2, 512), ('conv', 113, 1, 3, 1, 1, 2048), ('conv', 64, 128, 7, 2, 3, 1024),
+          ('conv', 256, 512, 7, 2, 3, 256)]
+
+
+@pytest.mark.parametrize('layer', LAYERS)
+def test_conv_layers_bf16(K, bf16, layer):
+    """forward, backward-data and backward-weight of C2 layer shapes vs torch convs on rounded operands"""
+    from audiogan_amd import ops
+    kind, cin, cout, k, s, p, lin = layer
+    B = 3
+    gen = torch.Generator().manual_seed(6)
+    spec = ops.ConvSpec(kind, cin, cout, k, s, p)
+    w = torch.randn((cout, cin, k) if kind == 'conv' else (cin, cout, k), generator=gen) / (cin * k) ** 0.5
+    x = torch.randn(B, cin, lin, generator=gen)
+    lout = spec.out_len(lin)
+    dy = torch.randn(B, cout, lout, generator=gen)
+    xr, wr, dyr = rnd(x).double().requires_grad_(True), rnd(w).double().requires_grad_(True), rnd(dy).double()
+    yr = F.conv1d(xr, wr, None, s, p) if kind == 'conv' else F.conv_transpose1d(xr, wr, None, s, p)
+    yr.backward(dyr)
+    d0, d1, _ = w.shape
+    prep = ops.Prepared(w=w.cuda(), wpa=torch.zeros(K.wpa_numel(d0, d1, k)).cuda(),
+                        wpb=torch.zeros(K.wpb_numel(d0, d1, k, s)).cuda(), pad=p)
+    K.prep_conv_weight(prep.w, prep.wpa, prep.wpb, s, p)
+    y = torch.empty(B, cout, lout).cuda()
+    ops.conv_fwd(spec, prep, x.cuda(), y)
+    dx = torch.empty(B, cin, lin).cuda()
+    ops.conv_bwd_data(spec, prep, dy.cuda(), dx)
+    dw = torch.zeros_like(w).cuda()
+    ops.conv_wgrad(spec, x.cuda(), dy.cuda(), dw, None)
+    for got, ref, n in ((y, yr, 'y'), (dx, xr.grad, 'dx'), (dw, wr.grad, 'dw')):
+        err = float((got.cpu().double() - ref.detach()).abs().max())
+        assert err <= 1e-4 * float(ref.abs().max()), (layer, n, err)
+
+
+def _small_models(A):
+    gcfg = dict(frame_size=64, embed_size=16, noise_size=16, state_size=128, num_layers=1,
+                struct=[[17, 8, 32, 8], [9, 4, 32, 16], [9, 4, 16, 16]])
+    dcfg = dict(state_size=128, embed_size=16, num_layers=1, cnn_struct=[[7, 2, 8], [7, 2, 16], [7, 2, 32], [7, 2, 64]])
+    torch.manual_seed(31)
+    go, do = O.Generator(**gcfg), O.Discriminator(**dcfg)
+    g, d = A.Generator(**gcfg), A.Discriminator(**dcfg)
+    g.load_state_dict(go.state_dict()); d.load_state_dict(do.state_dict())
+    return go, do, g.cuda(), d.cuda()
+
+
+def test_networks_bf16_vs_rounded_oracle(K, bf16):
+    """G and D (ragged lengths; persistent biLSTM kernels, split GEMMs, every conv class) forward + backward in bf16
+    mode vs the oracle's bf16_mode, and - informative bound - vs the fp32 oracle"""
+    import audiogan_amd as A
+    go, do, g, d = _small_models(A)
+    B, T, fs = 16, 16, 64
+    gen = torch.Generator().manual_seed(32)
+    z, c = torch.randn(B, T, 16, generator=gen), torch.randn(B, 16, generator=gen)
+    lens = torch.randint(300, T * fs + 1, (B,), generator=gen)
+    lens[0] = T * fs
+    wl = torch.randn(B, T * fs // 16, generator=gen)
+    stop = torch.zeros(B, T, dtype=torch.long)
+    x32 = go(z=z, c=c, stop=stop)[0]
+    l32 = do(x32, lens, c)[0]
+    with O.bf16_mode():
+        xo = go(z=z, c=c, stop=stop)[0]
+        lo, actso, _, _ = do(xo, lens, c)
+        (lo * wl).sum().backward()
+    x = g(z=z.cuda(), c=c.cuda(), stop='never')[0]
+    l, acts, _, _ = d(x, lens.cuda(), c.cuda())
+    (l * wl.cuda()).sum().backward()
+    close_bf16(x, xo, 'waveform')
+    close_bf16(l, lo, 'logits')
+    for i, (a, b) in enumerate(zip(acts, actso)):
+        close_bf16(a, b, 'act%d' % i)
+    for mod, ref in ((g, go), (d, do)):
+        rp = dict(ref.named_parameters())
+        for k, q in mod.named_parameters():
+            if k.split('.')[-1].startswith('bias') and k.endswith('_v'):
+                continue
+            r = rp[k].grad if rp[k].grad is not None else torch.zeros_like(rp[k])
+            close_bf16(q.grad if q.grad is not None else torch.zeros_like(q), r, k, elem=2e-2, l2=2e-2)
+    assert rel_l2(x, x32) <= 3e-2 and rel_l2(l, l32) <= 3e-2
+    assert rel_l2(x, x32) > 1e-5          # (and the mode is really on)
+
+
+def test_train_step_bf16_vs_rounded_oracle(K, bf16):
+    import audiogan_amd as A
+    from audiogan_amd import optim, train
+    go, do, g, d = _small_models(A)
+    B, T, fs = 8, 16, 64
+    gen = torch.Generator().manual_seed(33)
+    real = torch.rand(B, T * fs, generator=gen) * 2 - 1
+    rl = torch.full((B,), T * fs, dtype=torch.long)
+    c, z = torch.randn(B, 16, generator=gen), torch.randn(B, T, 16, generator=gen)
+    nr, nf = torch.randn(B, T * fs, generator=gen) * 0.01, torch.randn(B, T * fs, generator=gen) * 0.01
+    stop = torch.zeros(B, T, dtype=torch.long)
+    opt_do, opt_go = O.make_optimizer(list(do.parameters()), 'adam', 1e-4), O.make_optimizer(list(go.parameters()), 'adam', 1e-4)
+    opt_d, opt_g = optim.make_optimizer(list(d.parameters()), 'adam', 1e-4), optim.make_optimizer(list(g.parameters()), 'adam', 1e-4)
+    cu = lambda t: t.cuda()  # noqa: E731
+    with O.bf16_mode():
+        lo, cdo, cgo = O.d_step(go, do, opt_do, real, rl, c, z, nr, nf, 1.0, stop=stop)
+        lo2, fo, _ = O.g_step(go, do, opt_go, c, z, nf, 0.1, stop=stop)
+    l, cd, cg = train.d_step(g, d, opt_d, cu(real), cu(rl), cu(c), cu(z), cu(nr), cu(nf), 1.0, check=True)
+    l2, f, _ = train.g_step(g, d, opt_g, cu(c), cu(z), cu(nf), 0.1, check=True)
+    close_bf16(cd, cdo, 'D(real)'); close_bf16(cg, cgo, 'D(fake)'); close_bf16(f, fo, 'fake')
+    np.testing.assert_allclose([float(l), float(l2)], [float(lo), float(lo2)], rtol=2e-3)
