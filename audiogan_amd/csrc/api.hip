@@ -18,15 +18,18 @@ extern "C" const char* ag_arch(void) { return "gfx950"; }
 extern "C" const char* ag_last_error(void) { return g_err; }
 
 // ---- precision mode of the contractions (common.h) ---------------------------------------------------------------
-static thread_local int g_prec = AG_PREC_F32;
+// process-wide (NOT thread-local): torch runs a module's backward on its autograd engine thread, and both halves of a
+// step must contract in the same precision
+#include <atomic>
+static std::atomic<int> g_prec{AG_PREC_F32};
 
 extern "C" int ag_set_precision(int mode) {
   AG_REQUIRE(mode == AG_PREC_F32 || mode == AG_PREC_BF16, "ag_set_precision: mode must be 0 (f32) or 1 (bf16)");
-  g_prec = mode;
+  g_prec.store(mode);
   return AG_OK;
 }
-extern "C" int ag_get_precision(void) { return g_prec; }
-int ag_precision() { return g_prec; }
+extern "C" int ag_get_precision(void) { return g_prec.load(); }
+int ag_precision() { return g_prec.load(); }
 
 // ---- workspace binding for the two-stage reductions (common.h) -------------------------------------------------
 static thread_local AgWs g_ws = {nullptr, 0};

@@ -29,7 +29,7 @@ int ag_slab_reduce(const float* ws, int Z, int64_t n, float* dst, int accumulate
 int ag_splitk_reduce(const float* part, int Z, int64_t pitch, int M, int N, float* C, int ldc, float beta,
                      const float* bias, const float* res, int ldres, hipStream_t st);
 
-// Precision mode of the contractions (api.hip, thread-local, set by ag_set_precision):
+// Precision mode of the contractions (api.hip, process-wide, set by ag_set_precision):
 //   AG_PREC_F32   operands as stored (exact fp32 MFMA / FMA chains)
 //   AG_PREC_BF16  EVERY contraction (conv, transposed conv, linear, recurrent products; forward, backward-data and
 //                 backward-weight forms) rounds BOTH operands to bf16 (round-to-nearest-even) and accumulates in fp32.
@@ -40,20 +40,23 @@ int ag_precision();
 #define AG_PREC_F32 0
 #define AG_PREC_BF16 1
 
-// round-to-nearest-even to bf16 precision, result kept in an fp32 register (NaN payloads are not preserved)
-__device__ __forceinline__ float ag_rbf(float x) {
-  unsigned u = __float_as_uint(x);
-  u = (u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u;
-  return __uint_as_float(u);
+// fp32 -> bf16 by the hardware convert (v_cvt_pk_bf16_f32: round-to-nearest-even, NaN stays NaN), two values per
+// instruction.  ag_pack_bf16: packed pair (lo = a, hi = b); ag_rbf*: rounded values kept in fp32 registers.
+typedef __bf16 ag_bf2 __attribute__((ext_vector_type(2)));
+typedef float ag_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned ag_pack_bf16(float a, float b) {
+  const ag_f2 v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, ag_bf2));
 }
+__device__ __forceinline__ float ag_rbf(float x) { return __uint_as_float(ag_pack_bf16(x, x) << 16); }
 __device__ __forceinline__ float ag_rbf_if(float x, int rb) { return rb ? ag_rbf(x) : x; }
 __device__ __forceinline__ f32x4 ag_rbf4_if(f32x4 v, int rb) {
-  if (rb) { v[0] = ag_rbf(v[0]); v[1] = ag_rbf(v[1]); v[2] = ag_rbf(v[2]); v[3] = ag_rbf(v[3]); }
+  if (rb) {
+    const unsigned lo = ag_pack_bf16(v[0], v[1]), hi = ag_pack_bf16(v[2], v[3]);
+    v[0] = __uint_as_float(lo << 16); v[1] = __uint_as_float(lo & 0xFFFF0000u);
+    v[2] = __uint_as_float(hi << 16); v[3] = __uint_as_float(hi & 0xFFFF0000u);
+  }
   return v;
-}
-// two floats -> packed bf16x2 (lo = a, hi = b), RNE
-__device__ __forceinline__ unsigned ag_pack_bf16(float a, float b) {
-  return (__float_as_uint(ag_rbf(a)) >> 16) | (__float_as_uint(ag_rbf(b)) & 0xFFFF0000u);
 }
 
 #define AG_REQUIRE(cond, ...)     \

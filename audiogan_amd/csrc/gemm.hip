@@ -473,47 +473,63 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmP p) {
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x2g __attribute__((ext_vector_type(2)));
 
+#define BF_BK 64       // k per tile: 16 float4 loads in flight per lane and operand pair (the kernel is bound by how many
+                       // bytes it keeps in flight, not by the MFMA pipe)
+// LDS image per operand: [128 rows][64 k] bf16 = 128-byte rows of eight 16-byte chunks; chunk c of row r sits in slot
+// c ^ ((r >> 1) & 7): the 16 rows of a ds_read_b128 lane group then cover 16 distinct (slot, 128-B half) pairs.
+__device__ __forceinline__ int bf_slot(int r, int c) { return r * 128 + ((c ^ ((r >> 1) & 7)) << 4); }
+
 template <int T_>      // 0: stored [rows][K] (k contiguous)   1: stored [K][rows]
 struct Bf16Loader {
-  f32x4 v[4];
-  // k-contiguous: 128 rows x 8 float4 per tile = 4 per thread;  row-contiguous: one 4x4 micro-tile per thread
+  f32x4 v[8];
+  // k-contiguous: 128 rows x 16 float4 per tile = 8 per thread;  row-contiguous: two 4 k x 4 rows micro-tiles per thread
   __device__ __forceinline__ void load(const float* __restrict__ G, int ld, int r0, int nrows, int k0, int K, int tid) {
     if (T_ == 0) {
 #pragma unroll
-      for (int it = 0; it < 4; ++it) {
+      for (int it = 0; it < 8; ++it) {
         const int idx = tid + 256 * it;
-        const int r = idx >> 3, q = idx & 7;
+        const int r = idx >> 4, q = idx & 15;
         const int k = k0 + 4 * q;
-        const float* src = G + (int64_t)min(r0 + r, nrows - 1) * ld + min(k, K - 4);
-        const f32x4 x = *reinterpret_cast<const f32x4*>(src);
-        v[it] = k < K ? x : f32x4{0.f, 0.f, 0.f, 0.f};
+        // (loads only: no arithmetic on the loaded registers here, or the compiler waits for them before the MFMA loop
+        // of the current tile instead of after it; the k >= K zeroing happens in store())
+        v[it] = *reinterpret_cast<const f32x4*>(G + (int64_t)min(r0 + r, nrows - 1) * ld + min(k, K - 4));
       }
     } else {
-      const int kq = tid >> 5, r4 = tid & 31;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int k = k0 + 4 * kq + i;
-        const f32x4 x = *reinterpret_cast<const f32x4*>(G + (int64_t)min(k, K - 1) * ld + min(r0 + 4 * r4, nrows - 4));
-        v[i] = k < K ? x : f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int it = 0; it < 2; ++it) {
+        const int idx = tid + 256 * it;
+        const int kq = idx >> 5, r4 = idx & 31;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int k = k0 + 4 * kq + i;
+          v[4 * it + i] = *reinterpret_cast<const f32x4*>(G + (int64_t)min(k, K - 1) * ld + min(r0 + 4 * r4, nrows - 4));
+        }
       }
     }
   }
-  __device__ __forceinline__ void store(char* S, int tid) const {
+  __device__ __forceinline__ void store(char* S, int tid, int k0, int K) const {
     if (T_ == 0) {
 #pragma unroll
-      for (int it = 0; it < 4; ++it) {
+      for (int it = 0; it < 8; ++it) {
         const int idx = tid + 256 * it;
-        const int r = idx >> 3, q = idx & 7;
-        u32x2g w = {ag_pack_bf16(v[it][0], v[it][1]), ag_pack_bf16(v[it][2], v[it][3])};
-        *reinterpret_cast<u32x2g*>(S + r * 64 + (((q >> 1) ^ ((r >> 2) & 3)) << 4) + ((q & 1) << 3)) = w;
+        const int r = idx >> 4, q = idx & 15;
+        const unsigned msk = (k0 + 4 * q < K) ? 0xFFFFFFFFu : 0u;      // (K % 4 == 0: a float4 is entirely in or out)
+        u32x2g w = {ag_pack_bf16(v[it][0], v[it][1]) & msk, ag_pack_bf16(v[it][2], v[it][3]) & msk};
+        *reinterpret_cast<u32x2g*>(S + bf_slot(r, q >> 1) + ((q & 1) << 3)) = w;
       }
     } else {
-      const int kq = tid >> 5, r4 = tid & 31;
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {
-        const int r = 4 * r4 + rr;
-        u32x2g w = {ag_pack_bf16(v[0][rr], v[1][rr]), ag_pack_bf16(v[2][rr], v[3][rr])};
-        *reinterpret_cast<u32x2g*>(S + r * 64 + (((kq >> 1) ^ ((r >> 2) & 3)) << 4) + ((kq & 1) << 3)) = w;
+      for (int it = 0; it < 2; ++it) {
+        const int idx = tid + 256 * it;
+        const int kq = idx >> 5, r4 = idx & 31;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const int r = 4 * r4 + rr;
+          const unsigned msk = (k0 + 4 * kq < K) ? 0xFFFFFFFFu : 0u;   // (K % 4 == 0: a 4-k group is entirely in or out)
+          u32x2g w = {ag_pack_bf16(v[4 * it][rr], v[4 * it + 1][rr]) & msk,
+                      ag_pack_bf16(v[4 * it + 2][rr], v[4 * it + 3][rr]) & msk};
+          *reinterpret_cast<u32x2g*>(S + bf_slot(r, kq >> 1) + ((kq & 1) << 3)) = w;
+        }
       }
     }
   }
@@ -521,12 +537,24 @@ struct Bf16Loader {
 
 template <int TA, int TB>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmP p) {
-  constexpr int BM = 128, BN = 128, TILEB = 128 * 64;      // bytes per operand tile
-  __shared__ __attribute__((aligned(16))) char sm[2 * 2 * TILEB];
+  constexpr int BM = 128, BN = 128, TILEB = 128 * 128;      // bytes per operand tile
+  extern __shared__ __attribute__((aligned(16))) char sm[];   // 2 buffers x (A tile + B tile) = 64 KiB
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l31 = lane & 31, h = lane >> 5;
   const int wm0 = (wid >> 1) * 64, wn0 = (wid & 1) * 64;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  // XCD-aware tile order: workgroup ids go round-robin over the 8 XCDs (each with its own L2).  In plain order the 8
+  // column tiles of one row band land on 8 different XCDs and every XCD pulls ALL of A through the fabric; remapped,
+  // XCD i works on a contiguous band of row tiles (speed only - the result does not depend on placement).
+  int bx = blockIdx.x, by = blockIdx.y;
+  {
+    const int nwg = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;
+    if ((nwg & 7) == 0) {
+      const int tile = (lin & 7) * (nwg >> 3) + (lin >> 3);
+      by = tile / gridDim.x;
+      bx = tile - by * gridDim.x;
+    }
+  }
+  const int m0 = by * BM, n0 = bx * BN;
   Bf16Loader<TA> la;
   Bf16Loader<(TB == 1 ? 0 : 1)> lb;
   f32x16 acc[2][2];
@@ -540,31 +568,25 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmP p) {
   const int kend = (kbeg + p.kchunk < p.K) ? kbeg + p.kchunk : p.K;
   la.load(p.A, p.lda, m0, p.M, kbeg, kend, tid);
   lb.load(p.B, p.ldb, n0, p.N, kbeg, kend, tid);
-  la.store(sm, tid);
-  lb.store(sm + TILEB, tid);
+  la.store(sm, tid, kbeg, kend);
+  lb.store(sm + TILEB, tid, kbeg, kend);
   __syncthreads();
   int buf = 0;
-  for (int k0 = kbeg; k0 < kend; k0 += 32) {
-    const bool more = k0 + 32 < kend;
+  for (int k0 = kbeg; k0 < kend; k0 += BF_BK) {
+    const bool more = k0 + BF_BK < kend;
     if (more) {
-      la.load(p.A, p.lda, m0, p.M, k0 + 32, kend, tid);
-      lb.load(p.B, p.ldb, n0, p.N, k0 + 32, kend, tid);
+      la.load(p.A, p.lda, m0, p.M, k0 + BF_BK, kend, tid);
+      lb.load(p.B, p.ldb, n0, p.N, k0 + BF_BK, kend, tid);
     }
     const char* As = sm + buf * 2 * TILEB;
     const char* Bs = As + TILEB;
 #pragma unroll
-    for (int s_ = 0; s_ < 2; ++s_) {
+    for (int s_ = 0; s_ < BF_BK / 16; ++s_) {
       bf16x8 av[2], bv[2];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int m = wm0 + 32 * i + l31;
-        av[i] = *reinterpret_cast<const bf16x8*>(As + m * 64 + (((2 * s_ + h) ^ ((m >> 2) & 3)) << 4));
-      }
+      for (int i = 0; i < 2; ++i) av[i] = *reinterpret_cast<const bf16x8*>(As + bf_slot(wm0 + 32 * i + l31, 2 * s_ + h));
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int n = wn0 + 32 * j + l31;
-        bv[j] = *reinterpret_cast<const bf16x8*>(Bs + n * 64 + (((2 * s_ + h) ^ ((n >> 2) & 3)) << 4));
-      }
+      for (int j = 0; j < 2; ++j) bv[j] = *reinterpret_cast<const bf16x8*>(Bs + bf_slot(wn0 + 32 * j + l31, 2 * s_ + h));
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -572,8 +594,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmP p) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
     }
     if (more) {
-      la.store(sm + (buf ^ 1) * 2 * TILEB, tid);
-      lb.store(sm + (buf ^ 1) * 2 * TILEB + TILEB, tid);
+      la.store(sm + (buf ^ 1) * 2 * TILEB, tid, k0 + BF_BK, kend);
+      lb.store(sm + (buf ^ 1) * 2 * TILEB + TILEB, tid, k0 + BF_BK, kend);
     }
     __syncthreads();
     buf ^= 1;
@@ -610,12 +632,19 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmP p) {
     }
 }
 
+template <int TA, int TB>
+static void launch_bf16_one(const GemmP& p, dim3 grid, hipStream_t st) {
+  auto kern = gemm_bf16_kernel<TA, TB>;
+  (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+  hipLaunchKernelGGL(kern, grid, dim3(256), 64 * 1024, st, p);
+}
+
 static int launch_gemm_bf16(const GemmP& p, int ta, int tb, hipStream_t st) {
   dim3 grid(ag_cdiv(p.N, 128), ag_cdiv(p.M, 128), p.ksplit);
-  if (ta == 0 && tb == 0) hipLaunchKernelGGL((gemm_bf16_kernel<0, 0>), grid, dim3(256), 0, st, p);
-  if (ta == 0 && tb == 1) hipLaunchKernelGGL((gemm_bf16_kernel<0, 1>), grid, dim3(256), 0, st, p);
-  if (ta == 1 && tb == 0) hipLaunchKernelGGL((gemm_bf16_kernel<1, 0>), grid, dim3(256), 0, st, p);
-  if (ta == 1 && tb == 1) hipLaunchKernelGGL((gemm_bf16_kernel<1, 1>), grid, dim3(256), 0, st, p);
+  if (ta == 0 && tb == 0) launch_bf16_one<0, 0>(p, grid, st);
+  if (ta == 0 && tb == 1) launch_bf16_one<0, 1>(p, grid, st);
+  if (ta == 1 && tb == 0) launch_bf16_one<1, 0>(p, grid, st);
+  if (ta == 1 && tb == 1) launch_bf16_one<1, 1>(p, grid, st);
   AG_CHECK_LAUNCH("ag_gemm(bf16)");
   return AG_OK;
 }
@@ -697,7 +726,7 @@ extern "C" int ag_gemm(const float* A, int lda, int ta, const float* B, int ldb,
   p.rb = ag_precision() == AG_PREC_BF16;
   hipStream_t st = (hipStream_t)stream;
   p.ksplit = 1;
-  p.kchunk = ag_roundup(K, 32);
+  p.kchunk = ag_roundup(K, 64);
   const int64_t big = (int64_t)ag_cdiv(M, 128) * ag_cdiv(N, 128);
   const bool use128 = M > 64 && N > 64 && (big >= 192 || K >= 2048);
   const int64_t tiles = use128 ? big : (int64_t)ag_cdiv(M, 64) * ag_cdiv(N, 64);
@@ -715,7 +744,7 @@ extern "C" int ag_gemm(const float* A, int lda, int ta, const float* B, int ldb,
     if (slabs && (int64_t)ks * mn > ws.numel) ks = (int)(ws.numel / mn);
     if (ks >= 2 && (slabs || beta == 0.f || beta == 1.f)) {
       p.ksplit = ks;
-      p.kchunk = ag_roundup(ag_cdiv(K, ks), 32);
+      p.kchunk = ag_roundup(ag_cdiv(K, ks), 64);
       p.ksplit = ag_cdiv(K, p.kchunk);
       if (slabs) {
         p.part = ws.p;
@@ -736,7 +765,7 @@ extern "C" int ag_gemm(const float* A, int lda, int ta, const float* B, int ldb,
   int rc;
   // bf16 mode: the bf16-MFMA kernel takes every shape with more than one row tile's worth of work whose operands
   // can be read 16 bytes at a time; the rest runs the fp32 kernels on operands rounded in registers
-  const bool bf16k = p.rb && M > 32 && N > 32 && p.vecA && p.vecB && K % 4 == 0 && p.kchunk % 32 == 0 &&
+  const bool bf16k = p.rb && M > 32 && N > 32 && p.vecA && p.vecB && K % 4 == 0 && p.kchunk % 64 == 0 &&
                      (ta == 0 || (M % 4 == 0 && M >= 4)) && (tb == 1 || (N % 4 == 0 && N >= 4));
   if (bf16k) {
     rc = launch_gemm_bf16(p, ta, tb, st);

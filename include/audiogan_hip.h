@@ -206,7 +206,8 @@ int ag_gru_cell_bwd(const float* gates_act, const float* gh, const float* h_prev
                     const float* dh, int lddh, float* dgi, float* dgh, float* dh_prev, int lddhp, int B,
                     int H, void* stream);
 
-/* Precision mode of every contraction launched by this host thread from now on (default 0 = fp32).
+/* Precision mode of every contraction launched by this PROCESS from now on (default 0 = fp32; process-wide because
+ * an autograd engine runs backward passes on a thread of its own).
  *   1 = bf16: each contraction (conv / transposed conv / linear / recurrent products, in their forward,
  *   backward-data and backward-weight forms) rounds BOTH operands to bfloat16 (round-to-nearest-even) and accumulates in
  *   fp32; tensors in memory, epilogues, losses and the optimiser stay fp32.  ag_gemm and the persistent recurrent

@@ -9,7 +9,8 @@ DECLARED TOLERANCE:
     largest magnitude elementwise and 3e-3 in relative L2 norm (an intermediate value that differs in the last fp32
     bits can round to the other bf16 neighbour, a 2^-8 relative change of that one element); parameter gradients
     (sums over batch and time in which such flips do not cancel; the weight-norm gain gradients are themselves
-    cancelling projections of them) 2e-2 elementwise and 2e-2 in relative L2 norm;
+    cancelling projections of them, two orders of magnitude smaller, and get 5e-2) 2e-2 elementwise and 2e-2 in
+    relative L2 norm;
   * vs the fp32 oracle: 3e-2 in relative L2 norm (what bf16 operands cost; informative)."""
 import os
 
@@ -165,7 +166,8 @@ def test_networks_bf16_vs_rounded_oracle(K, bf16):
             if k.split('.')[-1].startswith('bias') and k.endswith('_v'):
                 continue
             r = rp[k].grad if rp[k].grad is not None else torch.zeros_like(rp[k])
-            close_bf16(q.grad if q.grad is not None else torch.zeros_like(q), r, k, elem=2e-2, l2=2e-2)
+            tol = 5e-2 if k.endswith('_g') else 2e-2
+            close_bf16(q.grad if q.grad is not None else torch.zeros_like(q), r, k, elem=tol, l2=tol)
     assert rel_l2(x, x32) <= 3e-2 and rel_l2(l, l32) <= 3e-2
     assert rel_l2(x, x32) > 1e-5          # (and the mode is really on)
 
