@@ -2,7 +2,12 @@
 but as ``state_dict``s instead of whole-module pickles, so they load into this package's modules AND
 into the reference's (the parameter names are identical, see tests/test_host_logic.py).  Optimiser
 state, step counters and RNG state -- which the reference never saved -- go
-into a fifth file ``%s-opt-%05d``."""
+into a fifth file ``%s-opt-%05d``.
+
+``load`` also reads the REFERENCE's own files: those hold whole-module pickles (``T.save(d, ...)``, audiogan.py:936-939,
+read back with ``T.load`` at :698-701); their ``state_dict()`` is taken (unpickling them needs the reference's classes
+importable, as it does for the reference itself).  The RNG streams (torch CPU + every CUDA device) saved in the
+``opt`` file are restored, so a resumed run draws the same z / noise / stop decisions."""
 import os
 
 import torch
@@ -25,25 +30,34 @@ def save(prefix, iteration, d=None, g=None, e_g=None, e_d=None, opt_d=None, opt_
     if opt_d is not None or opt_g is not None or extra is not None:
         blob = dict(opt_d=_cpu(opt_d.state_dict()) if opt_d is not None else None,
                     opt_g=_cpu(opt_g.state_dict()) if opt_g is not None else None,
-                    extra=extra, torch_rng=torch.get_rng_state())
+                    extra=extra, torch_rng=torch.get_rng_state(),
+                    cuda_rng=torch.cuda.get_rng_state_all() if torch.cuda.is_available() else None)
         torch.save(blob, _path(prefix, 'opt', iteration))
         written.append(_path(prefix, 'opt', iteration))
     return written
 
 
-def load(prefix, iteration, d=None, g=None, e_g=None, e_d=None, opt_d=None, opt_g=None, strict=True):
+def load(prefix, iteration, d=None, g=None, e_g=None, e_d=None, opt_d=None, opt_g=None, strict=True, restore_rng=True):
     mods = dict(d=d, g=g, e_g=e_g, e_d=e_d)
     for role, key in _ROLES:
         m = mods[key]
         if m is not None:
-            m.load_state_dict(torch.load(_path(prefix, role, iteration), map_location='cpu'), strict=strict)
+            obj = torch.load(_path(prefix, role, iteration), map_location='cpu', weights_only=False)
+            sd = obj.state_dict() if isinstance(obj, torch.nn.Module) else obj      # reference-style module pickle
+            m.load_state_dict(sd, strict=strict)
     extra = None
     p = _path(prefix, 'opt', iteration)
-    if os.path.exists(p) and (opt_d is not None or opt_g is not None):
+    if os.path.exists(p):
         blob = torch.load(p, map_location='cpu', weights_only=False)
         for o, key in ((opt_d, 'opt_d'), (opt_g, 'opt_g')):
             if o is not None and blob.get(key) is not None:
                 o.load_state_dict(_to(blob[key], o.params[0].device))
+        if restore_rng:
+            if blob.get('torch_rng') is not None:
+                torch.set_rng_state(blob['torch_rng'])
+            if blob.get('cuda_rng') is not None and torch.cuda.is_available() and \
+                    len(blob['cuda_rng']) == torch.cuda.device_count():
+                torch.cuda.set_rng_state_all(blob['cuda_rng'])
         extra = blob.get('extra')
     return extra
 

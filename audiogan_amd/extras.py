@@ -97,7 +97,7 @@ def adversarially_sample_z(g, d, batch_size, nframes, noise_size, maxlen, embed_
         fake, _, _, fake_len = g(batch_size=batch_size, length=maxlen, c=embed_g, z=z, stop=stop)
         if noise is None:
             noise = torch.randn_like(fake) * noisescale
-        cls_g, _, _, nframes_g = d(fake + noise, fake_len, embed_d)
+        cls_g, _, _, nframes_g = d(fake + noise[:, :fake.size(1)], fake_len, embed_d)
         target = 0.5 if g_optim == 'boundary_seeking' else 0.0
         loss = binary_cross_entropy_with_logits_per_sample(cls_g, target, nframes=nframes_g) / nframes_g.float()
         grad, = torch.autograd.grad(loss.sum(), z)

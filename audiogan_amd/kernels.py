@@ -107,30 +107,59 @@ def wpb_numel(d0, d1, K, stride):
 # ------------------------------------------------------------------------------------
 # descriptor tables (device copies of small C struct arrays), cached by content
 # ------------------------------------------------------------------------------------
-_table_cache = {}
+from collections import OrderedDict
+
+_table_cache = OrderedDict()     # descriptor tables created eagerly: LRU, bounded
+_table_pinned = {}               # tables created while a hipGraph was being captured: the graph's copy node re-reads
+                                 # the pinned slot and its kernels read the device table on every replay - never evicted
+_TABLE_LRU = 4096
 
 
 def _table(kind, structs, device):
     raw = b''.join(bytes(s) for s in structs)
     key = (kind, raw, str(device))
+    t = _table_pinned.get(key)
+    if t is not None:
+        return t[0]
+    capturing = torch.device(device).type == 'cuda' and torch.cuda.is_current_stream_capturing()
     t = _table_cache.get(key)
-    if t is None:
-        if len(_table_cache) > 4096:
-            _table_cache.clear()
-        src = torch.frombuffer(bytearray(raw), dtype=torch.uint8)
-        if torch.device(device).type == 'cuda':
-            # staged through a pre-allocated pinned arena + async copy: legal inside hipGraph
-            # capture (the copy becomes a graph node that re-reads the arena slot on replay, so
-            # slots are never recycled)
-            host = _pinned_slot(len(raw))
-            host.copy_(src)
-            t = torch.empty(len(raw), dtype=torch.uint8, device=device)
-            t.copy_(host, non_blocking=True)
-        else:
-            host, t = src, src.to(device)
+    if t is not None and not capturing:
+        _table_cache.move_to_end(key)
+        return t[0]
+    # (an eager entry is NOT reused by a capture: its upload happened outside the graph and the entry may be evicted)
+    src = torch.frombuffer(bytearray(raw), dtype=torch.uint8)
+    if torch.device(device).type == 'cuda':
+        # staged through a pre-allocated pinned arena + async copy: legal inside hipGraph capture (the copy becomes a
+        # graph node that re-reads the arena slot on replay, so slots are never recycled)
+        host = _pinned_slot(len(raw))
+        host.copy_(src)
+        t = torch.empty(len(raw), dtype=torch.uint8, device=device)
+        t.copy_(host, non_blocking=True)
+    else:
+        host, t = src, src.to(device)
+    if capturing:
+        _table_pinned[key] = (t, host)
+        _capture_log.append(key)
+    else:
         _table_cache[key] = (t, host)
-        return t
-    return t[0]
+        while len(_table_cache) > _TABLE_LRU:
+            _table_cache.popitem(last=False)
+    return t
+
+
+_capture_log = []
+
+
+def capture_mark():
+    """position in the log of tables created under capture (see drop_captured_tables)"""
+    return len(_capture_log)
+
+
+def drop_captured_tables(mark):
+    """forget the tables created under a capture that FAILED or will never be replayed (their device content was
+    never written): call with the capture_mark() taken before the capture started"""
+    while len(_capture_log) > mark:
+        _table_pinned.pop(_capture_log.pop(), None)
 
 
 _arena = {'buf': None, 'off': 0}

@@ -85,16 +85,22 @@ def stopper_surrogate_loss(stop_logits, stops, reward, weight=None):
 class only_stopper_trains(object):
     """context manager: every generator parameter except the stop head is frozen (audiogan.py:897-901)"""
 
-    def __init__(self, g):
+    def __init__(self, g, *also_frozen):
         self.g = g
+        self.also = also_frozen          # further modules trained by the same optimiser (the text embedder e_g, :691)
 
     def __enter__(self):
         keep = set(id(p) for p in self.g.stopper.parameters())
-        self.flags = [(p, p.requires_grad) for p in self.g.parameters()]
+        self.flags = [(p, p.requires_grad) for m in (self.g,) + tuple(self.also) for p in m.parameters()]
         for p, _ in self.flags:
             p.requires_grad_(id(p) in keep)
+        from . import recurrent
+        self._prev = recurrent.STOPPER_ONLY[0]
+        recurrent.STOPPER_ONLY[0] = True
         return self
 
     def __exit__(self, *exc):
+        from . import recurrent
+        recurrent.STOPPER_ONLY[0] = self._prev
         for p, r in self.flags:
             p.requires_grad_(r)

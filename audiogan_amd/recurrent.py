@@ -17,6 +17,11 @@ from .kernels import ACT_NONE, ACT_TANH
 from .common import WNGroup, _zeros_like_list, grad_target
 
 
+# set inside losses.only_stopper_trains: the backward that runs there is the REINFORCE update of the stop head, whose
+# gradient is wanted in the stopper's parameters ONLY (audiogan.py:897-903) - not in the block's input either
+STOPPER_ONLY = [False]
+
+
 def _small(A, B, Cm, tb=False, beta=0.0, bias=None, act=ACT_NONE, res=None):
     """Cm = act(A @ op(B) + beta*Cm + bias + res) for a product with few rows"""
     if res is None and K.skinny_ok(A, B, tb):
@@ -321,6 +326,17 @@ class GFrontFn(torch.autograd.Function):
         # no parameter of the block needs a gradient (FGSM-style input-gradient passes): skip every weight-gradient
         # product and leave ``.grad`` untouched
         wg = any(ctx.needs_input_grad[2:])
+        items = front.group.items
+        if dx is None and ds is not None and (STOPPER_ONLY[0] or not ctx.needs_input_grad[0]) and \
+                not any(it['v'].requires_grad or it['g'].requires_grad for it in items[:4 * nl + 2]):
+            # REINFORCE backward of the stop head alone (audiogan.py:897-903: every other generator parameter is
+            # frozen): s_t = h_t W_s^T + b_s, so only dW_s = ds^T h and db_s = sum ds are wanted - no frame loop
+            dws = [None] * len(items)
+            dws[4 * nl + 2], dws[4 * nl + 3] = _zeros_like_list([items[4 * nl + 2]['v'], items[4 * nl + 3]['v']])
+            ds_tb = ds.t().contiguous().view(T * B, 1)
+            K.gemm(ds_tb, hs[-1].view(T * B, S), dws[4 * nl + 2], ta=True)
+            K.col_sum(ds_tb, dws[4 * nl + 3])
+            return (None, None) + tuple(front.group.backward(dws))
         dws = _zeros_like_list([it['v'] for it in front.group.items]) if wg else None
         fused = (nl == 1 and T > 0 and (S + fs) % 4 == 0
                  and K.lstm_front_bwd_ok(B, S, fs, x[:, :fs], x[:, :fs]) and K.skinny_ok(gates[0][0], lw[0][1], False))

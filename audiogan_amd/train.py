@@ -4,7 +4,8 @@ numbers can be fed to the CPU oracle."""
 import torch
 
 from .common import frozen
-from .losses import masked_bce_mean
+from .extras import adversarial_movement_d, adversarially_sample_z, calc_dists, feature_penalty
+from .losses import length_mask, masked_bce_mean, only_stopper_trains, stopper_surrogate_loss
 
 _SIDE = {}
 
@@ -165,3 +166,80 @@ def g_backward_early(g, d, opt_g, c, z, noise_fake, keep, g_optim='boundary_seek
 def g_backward_late(keep):
     """the recurrent front's backward from the cut gradient (weight gradients of rnn / proj / stopper)"""
     keep['x'].backward(keep['x_cut'].grad)
+
+
+# --------------------------------------------------------------------------------------
+# The reference's CURRENT iterations: the classic step plus the FGSM-style passes (audiogan.py:99-150), the
+# feature-matching penalty (:847-855) and the REINFORCE update of the stop head (:444-460, :866-908).  Same arguments
+# and results as oracle.audiogan_oracle.d_step_full / g_step_full (every random quantity is an argument).
+# --------------------------------------------------------------------------------------
+def _acc(cls, nframes, positive):
+    w = length_mask(cls.size(), nframes)
+    hit = (cls > 0) if positive else (cls < 0)
+    return float((hit.float() * w).sum() / w.sum())
+
+
+def d_step_full(g, d, e_g, e_d, opt_d, dis_iter, real, real_len, cs, cl, cs2, cl2, z, noise_real, noise_fake,
+                dgradclip=1.0, stop=None, check=True):
+    """critic iteration ``dis_iter`` of audiogan.py:706-788.  Even iterations: instance noise on the real and the
+    generated clips (:724-728, :749-751).  Odd iterations: clean real clips (the FGSM perturbation of :735-736 is
+    computed after ``cls_d`` and never reaches the loss, so it is not computed here) and generated clips moved by
+    +-1e-3 along the sign of the critic's input gradient (:752-759, ``extras.adversarial_movement_d``: an
+    input-gradient pass that leaves every ``.grad`` untouched).  ``opt_d`` holds the parameters of d and e_d (:691)."""
+    even = dis_iter % 2 == 0
+    embed_real = e_d(cs, cl)
+    cls_d, _, _, nf_d = d(real + noise_real if even else real, real_len, embed_real)
+    loss_d, _ = masked_bce_mean(cls_d, 0.9, nf_d.contiguous())
+    with torch.no_grad():
+        embed_g = e_g(cs2, cl2)
+        fake, _, _, fake_len = g(z=z, c=embed_g, stop=stop)
+    embed_d = e_d(cs2, cl2)
+    if even:
+        fake = fake + noise_fake[:, :fake.size(1)]
+    else:
+        fake = fake + adversarial_movement_d(fake, fake_len, embed_d.detach(), 0.0, None, d, scale=1e-3)
+    cls_g, _, _, nf_g = d(fake, fake_len, embed_d)
+    loss_g, _ = masked_bce_mean(cls_g, 0.0, nf_g.contiguous())
+    loss = loss_d + loss_g
+    opt_d.zero_grad()
+    loss.backward()
+    opt_d.step(clip_norm=dgradclip, check=check)
+    return dict(loss=loss.detach(), loss_d=loss_d.detach(), loss_g=loss_g.detach(), cls_d=cls_d.detach(),
+                cls_g=cls_g.detach(), grad_norm=opt_d.last_norm_sum,
+                acc_d=_acc(cls_d.detach(), nf_d, True), acc_g=_acc(cls_g.detach(), nf_g, False))
+
+
+def g_step_full(g, d, e_g, e_d, opt_g, real, real_len, cs, cl, z0, noise_real, noise_adv, noise_fake, stop_adv, stop,
+                baseline=None, ggradclip=0.1, g_optim='boundary_seeking', lambda_fp=1.0, check=True):
+    """generator iteration of audiogan.py:816-921: adversarial z (:836), generator + critic forward (:841-847), feature
+    penalty against the critic's statistics on the real clips (:847-855), BCE towards 0.5 (:857-864), reward / baseline
+    (:873-887), loss + penalty (:897), REINFORCE of the stop draws into the stop head only (:898-908), per-parameter clip
+    and step over the parameters of g and e_g (:909-921).  Returns a dict with the new ``baseline``."""
+    B = real.size(0)
+    fs, ns = g._frame_size, g._noise_size
+    embed_g = e_g(cs, cl)
+    with frozen(d, e_d):
+        embed_d = e_d(cs, cl).detach()
+        z = adversarially_sample_z(g, d, B, z0.size(1), ns, z0.size(1) * fs, embed_g.detach(), 0.0, embed_d,
+                                   g_optim=g_optim, scale=1e-2, z=z0, noise=noise_adv, stop=stop_adv)
+        fake, s, stop_list, fake_len = g(z=z, c=embed_g, stop=stop)
+        fake = fake + noise_fake[:, :fake.size(1)]
+        cls_g, hs_g, hl_g, nf_g = d(fake, fake_len, embed_d)
+        with torch.no_grad():
+            _, hs_d, hl_d, _ = d(real + noise_real, real_len, embed_d)
+        pen = feature_penalty(calc_dists(hs_d, hl_d), calc_dists(hs_g, hl_g), B)
+        bce, per = masked_bce_mean(cls_g, 0.5 if g_optim == 'boundary_seeking' else 0.0, nf_g.contiguous())
+        reward = -(per / nf_g.float())                       # per-sample loss, a constant for the stop head
+        rmean = float(reward.mean())
+        baseline = rmean if baseline is None else baseline * 0.5 + rmean * 0.5
+        frames = fake_len // fs
+        weight_r = length_mask((B, int(frames.max())), frames)
+        reward = (reward - baseline).unsqueeze(1) * weight_r
+        loss = bce + pen * lambda_fp
+        opt_g.zero_grad()
+        loss.backward(retain_graph=True)
+        with only_stopper_trains(g, e_g):
+            stopper_surrogate_loss(s, stop_list, reward).backward()
+    opt_g.step(clip_norm=ggradclip, check=check)
+    return dict(loss=loss.detach(), bce=bce.detach(), feature_penalty=pen.detach(), z=z, fake=fake.detach(),
+                fake_len=fake_len, s=s.detach(), baseline=baseline, grad_norm=opt_g.last_norm_sum)

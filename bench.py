@@ -250,6 +250,7 @@ def main():
 
     b_ = batch
     if not args.no_graph:
+        table_mark = K.capture_mark()
         try:
             K.reserve_table_arena()
             if not multi:
@@ -297,6 +298,7 @@ def main():
         except Exception as e:  # noqa: BLE001
             sys.stderr.write('hipGraph capture failed (%s: %s); running eagerly\n' % (type(e).__name__, e))
             graph = phases = None
+            K.drop_captured_tables(table_mark)      # their device copies were never executed
             capture_error = '%s: %s' % (type(e).__name__, str(e)[:200])
             torch.cuda.synchronize()
 

