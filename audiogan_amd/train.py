@@ -243,3 +243,47 @@ def g_step_full(g, d, e_g, e_d, opt_g, real, real_len, cs, cl, z0, noise_real, n
     opt_g.step(clip_norm=ggradclip, check=check)
     return dict(loss=loss.detach(), bce=bce.detach(), feature_penalty=pen.detach(), z=z, fake=fake.detach(),
                 fake_len=fake_len, s=s.detach(), baseline=baseline, grad_norm=opt_g.last_norm_sum)
+
+
+# --------------------------------------------------------------------------------------
+# BASELINE configs[3] (C4) and configs[4] (C5): the step with a conv critic that scores a whole clip
+# (``convnets.ConvPoolCritic``: the a4 conv stack + average pool + Linear(1)).
+#   c4_step       GRU-front generator (modules.GRUGenerator) + conv critic, BCE-with-logits adversarial loss
+#   wgan_gp_step  WGAN-GP (modeltf.py:460-469, lambda 10): critic loss with the gradient penalty's double backward,
+#                 generator loss -D(G(z))
+# Same oracle-side statements: oracle.audiogan_oracle.c4_step / wgan_gp_step.
+# --------------------------------------------------------------------------------------
+def c4_step(g, critic, opt_g, opt_d, real, c, z, noise_real, noise_fake, dgradclip=1.0, ggradclip=0.1, check=False,
+            hook_d=None, hook_g=None):
+    with torch.no_grad():
+        fake = g(z=z, c=c, stop='never')[0] + noise_fake
+    B = real.size(0)
+    cls = critic(torch.cat([real + noise_real, fake], 0)).view(2 * B, 1)
+    loss_d = masked_bce_mean(cls[:B], 0.9, None)[0] + masked_bce_mean(cls[B:], 0.0, None)[0]
+    opt_d.zero_grad()
+    loss_d.backward()
+    opt_d.step(clip_norm=dgradclip, grad_scale=hook_d() if hook_d is not None else 1.0, check=check)
+    with frozen(critic):
+        fake = g(z=z, c=c, stop='never')[0]
+        loss_g = masked_bce_mean(critic(fake + noise_fake).view(B, 1), 0.5, None)[0]
+        opt_g.zero_grad()
+        loss_g.backward()
+    opt_g.step(clip_norm=ggradclip, grad_scale=hook_g() if hook_g is not None else 1.0, check=check)
+    return loss_d.detach(), loss_g.detach()
+
+
+def wgan_gp_step(g, critic, opt_g, opt_d, real, c, z, eps, lam=10.0, dgradclip=0.0, ggradclip=0.0, check=False,
+                 hook_d=None, hook_g=None):
+    from .convnets import wgan_gp_d_loss, wgan_g_loss
+    with torch.no_grad():
+        fake = g(z=z, c=c, stop='never')[0]
+    loss_d = wgan_gp_d_loss(critic, real, fake, eps, lam)
+    opt_d.zero_grad()
+    loss_d.backward()
+    opt_d.step(clip_norm=dgradclip, grad_scale=hook_d() if hook_d is not None else 1.0, check=check)
+    with frozen(critic):
+        loss_g = wgan_g_loss(critic, g(z=z, c=c, stop='never')[0])
+        opt_g.zero_grad()
+        loss_g.backward()
+    opt_g.step(clip_norm=ggradclip, grad_scale=hook_g() if hook_g is not None else 1.0, check=check)
+    return loss_d.detach(), loss_g.detach()

@@ -42,11 +42,19 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0 # MI355X_MICROARCH.md: dense bf16 matrix peak (sp
 PEAK_HBM_GBS = 8000.0
 
 
-def build_models(A, dev, opt_kind, seed=0):
+def build_models(A, dev, opt_kind, seed=0, workload='c2'):
+    """c2: the audiogan.py Generator + Discriminator (BASELINE configs[1]/[2]).  c4: GRU-front generator + conv critic
+    (configs[3]).  c5: the audiogan.py Generator + conv critic trained with WGAN-GP (configs[4])."""
     from audiogan_amd import optim
     torch.manual_seed(seed)
-    g = A.Generator(frame_size=FRAME, embed_size=100, noise_size=100, state_size=1024).to(dev)
-    d = A.Discriminator(state_size=1024, embed_size=100).to(dev)
+    if workload == 'c4':
+        g = A.GRUGenerator(frame_size=FRAME, embed_size=100, noise_size=100, state_size=1024).to(dev)
+    else:
+        g = A.Generator(frame_size=FRAME, embed_size=100, noise_size=100, state_size=1024).to(dev)
+    if workload == 'c2':
+        d = A.Discriminator(state_size=1024, embed_size=100).to(dev)
+    else:
+        d = A.ConvPoolCritic().to(dev)
     opt_g = optim.make_optimizer(list(g.parameters()), opt_kind, 1e-4)
     opt_d = optim.make_optimizer(list(d.parameters()), opt_kind, 1e-4)
     return g, d, opt_g, opt_d
@@ -63,16 +71,36 @@ def synthetic_batch(batch, dev, seed):
     out = dict(real=torch.from_numpy(x), real_len=torch.full((batch,), L, dtype=torch.long),
                c=torch.randn(batch, 100, generator=gen), z=torch.randn(batch, T, 100, generator=gen),
                noise_real=torch.randn(batch, L, generator=gen) * 0.01,
-               noise_fake=torch.randn(batch, L, generator=gen) * 0.01)
+               noise_fake=torch.randn(batch, L, generator=gen) * 0.01,
+               eps=torch.rand(batch, 1, generator=gen))
     return {k: v.to(dev) for k, v in out.items()}
 
 
 _SIDE = [None]
 
 
+WORKLOAD = ['c2']
+WORKLOAD_TEXT = {
+    'c2': '%s: full audiogan.py Conv1d/LSTM G + D, batch %d per GPU, 8192-sample white-noise clips, frame_size 256 '
+          '(T=32), canonical G+D step, %s, per-parameter clip d=1 g=0.1',
+    'c4': '%s: GRU-front generator (the audiogan.py Generator with a GRU cell in its frame loop) + conv critic (a4 conv '
+          'stack + average pool + Linear), batch %d per GPU, 8192-sample white-noise clips, frame_size 256 (T=32), BCE '
+          'G+D step, %s, per-parameter clip d=1 g=0.1',
+    'c5': '%s: audiogan.py Generator + conv critic (a4 conv stack + average pool + Linear), WGAN-GP (lambda 10, gradient '
+          'penalty by a hand-written double backward), batch %d per GPU, 8192-sample white-noise clips, frame_size 256 '
+          '(T=32), critic + generator iteration, %s',
+}
+
+
 def one_step(train, g, d, opt_g, opt_d, b, hook_d=None, hook_g=None, overlap=False):
     """the canonical step (train.gd_step).  overlap=True: the generator iteration's G forward runs on a second
     stream beside the critic iteration (see train.gd_step).  Returns (loss_d, loss_g)."""
+    if WORKLOAD[0] == 'c4':
+        return train.c4_step(g, d, opt_g, opt_d, b['real'], b['c'], b['z'], b['noise_real'], b['noise_fake'], 1.0, 0.1,
+                             hook_d=hook_d, hook_g=hook_g)
+    if WORKLOAD[0] == 'c5':
+        return train.wgan_gp_step(g, d, opt_g, opt_d, b['real'], b['c'], b['z'], b['eps'], 10.0,
+                                  hook_d=hook_d, hook_g=hook_g)
     return train.gd_step(g, d, opt_g, opt_d, b['real'], b['real_len'], b['c'], b['z'], b['noise_real'],
                          b['noise_fake'], 1.0, 0.1, overlap=overlap, hook_d=hook_d, hook_g=hook_g)
 
@@ -89,7 +117,7 @@ def pmc_traffic(kernel):
     return ent['bytes_per_launch'] if ent else None
 
 
-def cpu_baseline(batch, steps, opt_kind, threads=0, budget_s=110.0, warm=2):
+def cpu_baseline(batch, steps, opt_kind, threads=0, budget_s=110.0, warm=2, workload='c2'):
     """the oracle's canonical step on `batch` clips of the same workload on the host cores (the full
     C2 batch, 2 warm-up + >= 5 timed steps, median).  Bounded: it keeps timing steps only while the total stays
     under `budget_s`; a slow host therefore reports from fewer steps (and says so) instead of stalling the bench."""
@@ -97,8 +125,14 @@ def cpu_baseline(batch, steps, opt_kind, threads=0, budget_s=110.0, warm=2):
     if threads:
         torch.set_num_threads(threads)
     torch.manual_seed(0)
-    g = O.Generator(frame_size=FRAME, embed_size=100, noise_size=100, state_size=1024)
-    d = O.Discriminator(state_size=1024, embed_size=100)
+    if workload == 'c4':
+        g = O.GRUGenerator(frame_size=FRAME, embed_size=100, noise_size=100, state_size=1024)
+    else:
+        g = O.Generator(frame_size=FRAME, embed_size=100, noise_size=100, state_size=1024)
+    if workload == 'c2':
+        d = O.Discriminator(state_size=1024, embed_size=100)
+    else:
+        d = O.Conv1DDiscriminator(config=[(16, 7, 2), (32, 7, 2), (64, 7, 2), (128, 7, 2), (256, 7, 2), (512, 7, 2)])
     og, od = O.make_optimizer(list(g.parameters()), opt_kind, 1e-4), O.make_optimizer(list(d.parameters()), opt_kind, 1e-4)
     b = synthetic_batch(batch, torch.device('cpu'), 0)
     stop = torch.zeros(batch, L // FRAME, dtype=torch.long)
@@ -106,8 +140,13 @@ def cpu_baseline(batch, steps, opt_kind, threads=0, budget_s=110.0, warm=2):
     times, t_start = [], time.perf_counter()
     for i in range(steps + warm):
         t0 = time.perf_counter()
-        O.d_step(g, d, od, b['real'], b['real_len'], b['c'], b['z'], b['noise_real'], b['noise_fake'], 1.0, stop=stop)
-        O.g_step(g, d, og, b['c'], b['z'], b['noise_fake'], 0.1, stop=stop)
+        if workload == 'c4':
+            O.c4_step(g, d, og, od, b['real'], b['c'], b['z'], b['noise_real'], b['noise_fake'], 1.0, 0.1, stop=stop)
+        elif workload == 'c5':
+            O.wgan_gp_step(g, d, og, od, b['real'], b['c'], b['z'], b['eps'], 10.0, stop=stop)
+        else:
+            O.d_step(g, d, od, b['real'], b['real_len'], b['c'], b['z'], b['noise_real'], b['noise_fake'], 1.0, stop=stop)
+            O.g_step(g, d, og, b['c'], b['z'], b['noise_fake'], 0.1, stop=stop)
         times.append(time.perf_counter() - t0)
         sys.stderr.write('cpu_baseline: step %d of %d took %.1f s\n' % (i, steps + warm, times[-1]))
         sys.stderr.flush()
@@ -150,6 +189,10 @@ def main():
     ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'],
                     help='f32 = BASELINE configs[1] (the headline); bf16 = configs[2]: every contraction rounds its '
                          'operands to bfloat16 and accumulates in fp32, gradients cross ranks as bfloat16')
+    ap.add_argument('--workload', default='c2', choices=['c2', 'c4', 'c5'],
+                    help='c2 = the headline (BASELINE configs[1]; with --dtype bf16: configs[2]); c4 = GRU-front '
+                         'generator + conv critic (configs[3]); c5 = WGAN-GP with the conv critic (configs[4]): extra '
+                         'lines, never the headline')
     ap.add_argument('--cpu-batch', type=int, default=64)
     ap.add_argument('--cpu-steps', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -194,13 +237,15 @@ def main():
     from audiogan_amd import train, ddp, kernels as K
 
     K.set_precision(args.dtype)
-    g, d, opt_g, opt_d = build_models(A, dev, args.opt)
+    WORKLOAD[0] = args.workload
+    alt = args.workload != 'c2'
+    g, d, opt_g, opt_d = build_models(A, dev, args.opt, workload=args.workload)
     hook_d = hook_g = None
     multi = world > 1 or args.force_phases
     if multi:
         ddp.broadcast_parameters(g)
         ddp.broadcast_parameters(d)
-        bd = ddp.GradBucket(list(d.parameters()), early=d.early_params(), force_collective=rehearse,
+        bd = ddp.GradBucket(list(d.parameters()), early=None if alt else d.early_params(), force_collective=rehearse,
                             comm_dtype=args.dtype)
         bg = ddp.GradBucket(list(g.parameters()), early=g.early_params(), force_collective=rehearse,
                             comm_dtype=args.dtype)
@@ -249,13 +294,14 @@ def main():
         return gr
 
     b_ = batch
-    if not args.no_graph:
+    if not args.no_graph and not (alt and multi):
         table_mark = K.capture_mark()
         try:
             K.reserve_table_arena()
             if not multi:
                 def whole():
-                    losses['d'], losses['g'] = one_step(train, g, d, opt_g, opt_d, batch, overlap=not args.no_overlap)
+                    losses['d'], losses['g'] = one_step(train, g, d, opt_g, opt_d, batch,
+                                                        overlap=not args.no_overlap and not alt)
 
                 graph = capture(whole)
                 graph.replay()
@@ -379,16 +425,14 @@ def main():
             'value': value, 'unit': 'audio-samples/sec', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': ms, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
-            'config': {'workload': '%s: full audiogan.py Conv1d/LSTM G + D, batch %d per GPU, 8192-sample '
-                                   'white-noise clips, frame_size 256 (T=32), canonical G+D step, %s, '
-                                   'per-parameter clip d=1 g=0.1%s' % (
-                                       'C2' if args.dtype == 'f32' else 'C3 (the C2 models with bf16 contractions)',
-                                       args.batch, args.opt,
+            'config': {'workload': WORKLOAD_TEXT[args.workload] % (
+                                       ('C2' if args.dtype == 'f32' else 'C3 (the C2 models with bf16 contractions)')
+                                       if args.workload == 'c2' else args.workload.upper(), args.batch, args.opt) + (
                                        '' if args.dtype == 'f32' else '; every contraction rounds both operands to '
                                        'bfloat16 and accumulates in fp32, gradient all-reduce in bfloat16'),
                        'global_batch': world * args.batch, 'clip_len': L,
                        'parallelism': 'dp%d' % world,
-                       'launch': ('hipGraph replay (1 graph per step%s)' % ('' if args.no_overlap else
+                       'launch': ('hipGraph replay (1 graph per step%s)' % ('' if (args.no_overlap or alt) else
                                   '; generator forward of the G iteration on a second stream beside the critic '
                                   'iteration') if graph is not None else
                                   'hipGraph replay (6 graphs per step; D all-reduce overlaps the conv-stack backward, '
@@ -441,8 +485,9 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             # torch CPU does not scale past ~32 threads on this model (128 threads measured slower
             # than 8): use min(32, cores); `cores` in the result is the thread count actually used
-            out['cpu_baseline'] = cpu_baseline(args.cpu_batch, args.cpu_steps, args.opt,
-                                               min(32, os.cpu_count() or 1))
+            out['cpu_baseline'] = cpu_baseline(args.cpu_batch if not alt else min(args.cpu_batch, 16),
+                                               args.cpu_steps if not alt else min(args.cpu_steps, 3), args.opt,
+                                               min(32, os.cpu_count() or 1), workload=args.workload)
         print(json.dumps(out), flush=True)
     if world > 1 or rehearse:
         dist.barrier()

@@ -769,3 +769,43 @@ def g_step_full(g, d, e_g, e_d, opt_g, real, real_len, cs, cl, z0, noise_real, n
     opt_g.step()
     return dict(loss=loss.detach(), bce=loss_ps.mean().detach(), feature_penalty=pen.detach(), z=z, fake=fake.detach(),
                 fake_len=fake_len, s=s.detach(), baseline=baseline, grad_norm=gnorm)
+
+
+# --------------------------------------------------------------------------
+# BASELINE configs[3] / [4] steps with a whole-clip conv critic (Conv1DDiscriminator with the a4 struct): the CPU
+# statements of audiogan_amd.train.c4_step / wgan_gp_step.  Parity unpinned (no GRU / WGAN-GP in the PyTorch reference).
+# --------------------------------------------------------------------------
+def _bce_mean(logits, target):
+    return binary_cross_entropy_with_logits_per_sample(logits, torch.full_like(logits, target)).mean()
+
+
+def c4_step(g, critic, opt_g, opt_d, real, c, z, noise_real, noise_fake, dgradclip=1.0, ggradclip=0.1, stop=None):
+    B = real.size(0)
+    with torch.no_grad():
+        fake = g(z=z, c=c, stop=stop)[0] + noise_fake
+    loss_d = _bce_mean(critic(real + noise_real).view(B, 1), 0.9) + _bce_mean(critic(fake).view(B, 1), 0.0)
+    opt_d.zero_grad()
+    loss_d.backward()
+    clip_grad(list(critic.parameters()), dgradclip)
+    opt_d.step()
+    fake = g(z=z, c=c, stop=stop)[0]
+    loss_g = _bce_mean(critic(fake + noise_fake).view(B, 1), 0.5)
+    opt_g.zero_grad()
+    loss_g.backward()
+    clip_grad(list(g.parameters()), ggradclip)
+    opt_g.step()
+    return loss_d.detach(), loss_g.detach()
+
+
+def wgan_gp_step(g, critic, opt_g, opt_d, real, c, z, eps, lam=10.0, stop=None):
+    with torch.no_grad():
+        fake = g(z=z, c=c, stop=stop)[0]
+    loss_d = wgan_gp_d_loss(critic, real, fake, eps, lam)
+    opt_d.zero_grad()
+    loss_d.backward()
+    opt_d.step()
+    loss_g = wgan_g_loss(critic, g(z=z, c=c, stop=stop)[0])
+    opt_g.zero_grad()
+    loss_g.backward()
+    opt_g.step()
+    return loss_d.detach(), loss_g.detach()

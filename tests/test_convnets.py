@@ -90,3 +90,43 @@ def test_gru_generator_host_logic(monkeypatch):
 def test_gru_generator_gpu():
     import audiogan_amd as A
     _run_gru(torch.device('cuda'), A)
+
+
+@pytest.mark.gpu
+def test_c4_c5_at_c2_widths_gpu():
+    """BASELINE configs[3] / [4] at the C2 widths (state 1024, frame 256, default structs, 8192-sample clips): one
+    GRU-front + conv-critic BCE step (train.c4_step) and one WGAN-GP step (train.wgan_gp_step) vs the oracle's
+    statements; losses, the generated waveforms and the parameters after the step"""
+    import audiogan_amd as A
+    from audiogan_amd import optim, train
+    dev = torch.device('cuda')
+    cfg = [(16, 7, 2), (32, 7, 2), (64, 7, 2), (128, 7, 2), (256, 7, 2), (512, 7, 2)]
+    B, T, fs = 4, 32, 256
+    gen = torch.Generator().manual_seed(52)
+    real = torch.rand(B, T * fs, generator=gen) * 2 - 1
+    c, z = torch.randn(B, 100, generator=gen), torch.randn(B, T, 100, generator=gen)
+    nr, nf = torch.randn(B, T * fs, generator=gen) * 0.01, torch.randn(B, T * fs, generator=gen) * 0.01
+    eps = torch.rand(B, 1, generator=gen)
+    stop = torch.zeros(B, T, dtype=torch.long)
+    to = lambda t: t.to(dev)  # noqa: E731
+    for wl in ('c4', 'c5'):
+        torch.manual_seed(53)
+        go = (O.GRUGenerator if wl == 'c4' else O.Generator)(frame_size=fs, embed_size=100, noise_size=100, state_size=1024)
+        co = O.Conv1DDiscriminator(config=cfg)
+        g = (A.GRUGenerator if wl == 'c4' else A.Generator)(frame_size=fs, embed_size=100, noise_size=100, state_size=1024)
+        cr = A.ConvPoolCritic()
+        g.load_state_dict(go.state_dict()); cr.load_state_dict(co.state_dict())
+        g.to(dev); cr.to(dev)
+        ogo, odo = O.make_optimizer(list(go.parameters()), 'adam', 1e-4), O.make_optimizer(list(co.parameters()), 'adam', 1e-4)
+        og, od = optim.make_optimizer(list(g.parameters()), 'adam', 1e-4), optim.make_optimizer(list(cr.parameters()), 'adam', 1e-4)
+        if wl == 'c4':
+            lo = O.c4_step(go, co, ogo, odo, real, c, z, nr, nf, 1.0, 0.1, stop=stop)
+            l = train.c4_step(g, cr, og, od, to(real), to(c), to(z), to(nr), to(nf), 1.0, 0.1, check=True)
+        else:
+            lo = O.wgan_gp_step(go, co, ogo, odo, real, c, z, eps, 10.0, stop=stop)
+            l = train.wgan_gp_step(g, cr, og, od, to(real), to(c), to(z), to(eps), 10.0, check=True)
+        np.testing.assert_allclose([float(l[0]), float(l[1])], [float(lo[0]), float(lo[1])], rtol=1e-3, err_msg=wl)
+        xo = go(z=z, c=c, stop=stop)[0]
+        x = g(z=to(z), c=to(c), stop='never')[0]
+        np.testing.assert_allclose(x.detach().cpu().numpy(), xo.detach().numpy(), rtol=2e-3,
+                                   atol=2e-3 * float(xo.abs().max()), err_msg=wl + ' waveform after the step')
