@@ -543,6 +543,68 @@ extern "C" int ag_leaky_bwd(const float* dy, int64_t dy_bs, int64_t dy_cs, const
 // ------------------------------------------------------------------------------------------
 #define O1_MAXK 9
 
+// A thread owns 4 consecutive time steps and reads each channel row as ONE aligned 16-byte piece; the K-1 halo values
+// come from the neighbouring lanes (wave shuffles), only the first / last lane of a wave loads its halo from memory.
+// UC channels are in flight per thread before the first FMA: the layer streams the 237 MB slab once and is bound by how
+// many bytes are in flight, not by arithmetic.
+#define O1_UC 8
+
+template <int K>       // odd K, pad = (K-1)/2 <= 4
+__global__ __launch_bounds__(256) void conv_o1_fwd_vec_kernel(const float* __restrict__ x, int64_t x_bs, int64_t x_cs,
+                                                              const float* __restrict__ w,
+                                                              const float* __restrict__ bias, float* __restrict__ y,
+                                                              int64_t y_bs, int C, int L, int act, float slope, int rb) {
+  constexpr int P = (K - 1) / 2;
+  const int b = blockIdx.y, lane = threadIdx.x & 63;
+  const int t0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+  const bool live = t0 < L;                               // L % 4 == 0: a piece is entirely inside or outside
+  const float* xb = x + (int64_t)b * x_bs + (live ? t0 : 0);
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int c0 = 0; c0 < C; c0 += O1_UC) {
+    f32x4 v[O1_UC];
+    float hl[O1_UC][P], hr[O1_UC][P];
+#pragma unroll
+    for (int u = 0; u < O1_UC; ++u) {
+      const int c = min(c0 + u, C - 1);
+      const float* xc = xb + (int64_t)c * x_cs;
+      v[u] = *reinterpret_cast<const f32x4*>(xc);
+      // halo of the wave's edge lanes straight from memory (clamped address, zeroed below when outside the clip)
+#pragma unroll
+      for (int i = 0; i < P; ++i) {
+        hl[u][i] = (lane == 0 && live) ? xc[max(-(int)(i + 1), -t0)] : 0.f;
+        hr[u][i] = (lane == 63 && live) ? xc[min(4 + i, L - 1 - t0)] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < O1_UC; ++u) {
+      if (c0 + u >= C) break;
+      float win[4 + 2 * P];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) win[P + j] = ag_rbf_if(v[u][j], rb);
+#pragma unroll
+      for (int i = 0; i < P; ++i) {
+        // left halo element i+1 positions before t0 = element 3-i of the previous lane; right: element i of the next
+        const float l_ = __shfl_up(v[u][3 - i], 1, 64), r_ = __shfl_down(v[u][i], 1, 64);
+        const float lv = (lane == 0) ? hl[u][i] : l_, rv = (lane == 63) ? hr[u][i] : r_;
+        win[P - 1 - i] = (t0 - 1 - i >= 0) ? ag_rbf_if(lv, rb) : 0.f;
+        win[P + 4 + i] = (t0 + 4 + i < L) ? ag_rbf_if(rv, rb) : 0.f;
+      }
+      const float* wc = w + (c0 + u) * K;
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        const float wk = ag_rbf_if(wc[k], rb);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] += wk * win[j + k];
+      }
+    }
+  }
+  if (!live) return;
+  const float bo = bias ? bias[0] : 0.f;
+  f32x4 o = {ag_apply_act(acc[0] + bo, act, slope), ag_apply_act(acc[1] + bo, act, slope),
+             ag_apply_act(acc[2] + bo, act, slope), ag_apply_act(acc[3] + bo, act, slope)};
+  *reinterpret_cast<f32x4*>(y + (int64_t)b * y_bs + t0) = o;
+}
+
 __global__ __launch_bounds__(256) void conv_o1_fwd_kernel(const float* __restrict__ x, int64_t x_bs, int64_t x_cs,
                                                           const float* __restrict__ w, const float* __restrict__ bias,
                                                           float* __restrict__ y, int64_t y_bs, int C, int L, int K,
@@ -600,6 +662,12 @@ __global__ __launch_bounds__(256) void conv_o1_bwdx_kernel(const float* __restri
     for (int j = 0; j < 4; ++j) acc[j] += wk * win[j + (K - 1) - k];
   }
   float* d = dx + (int64_t)b * dx_bs + (int64_t)c * dx_cs;
+  if (t0 + 3 < L && (((uintptr_t)(d + t0)) & 15) == 0) {        // one 16-byte store (and load when accumulating)
+    f32x4 o = {acc[0], acc[1], acc[2], acc[3]};
+    if (accumulate) o += *reinterpret_cast<const f32x4*>(d + t0);
+    *reinterpret_cast<f32x4*>(d + t0) = o;
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < 4; ++j)
     if (t0 + j < L) d[t0 + j] = accumulate ? d[t0 + j] + acc[j] : acc[j];
@@ -662,10 +730,53 @@ extern "C" int ag_conv1d_o1_fwd(const float* x, int64_t x_bs, int64_t x_cs, cons
   AG_REQUIRE(x && w && y && B > 0 && C > 0 && L > 0 && K > 0 && K <= O1_MAXK && pad >= 0 && B <= 65535,
              "ag_conv1d_o1_fwd: bad args (needs stride 1, K <= 9)");
   AG_REQUIRE(L + 2 * pad - K + 1 == L, "ag_conv1d_o1_fwd: needs a length-preserving ('same') conv");
+  const int rb_ = (int)(ag_precision() == AG_PREC_BF16);
+  // vector path: 16-byte aligned rows of x and y, L % 4 == 0 (a thread's 4 outputs are one aligned piece)
+  if (K == 3 && L % 4 == 0 && L >= 4 && x_bs % 4 == 0 && x_cs % 4 == 0 && y_bs % 4 == 0 &&
+      (((uintptr_t)x | (uintptr_t)y) & 15) == 0) {
+    hipLaunchKernelGGL((conv_o1_fwd_vec_kernel<3>), dim3(ag_cdiv(L, 1024), B), dim3(256), 0, (hipStream_t)stream, x, x_bs,
+                       x_cs, w, bias, y, y_bs, C, L, act, slope, rb_);
+    AG_CHECK_LAUNCH("ag_conv1d_o1_fwd");
+    return AG_OK;
+  }
   hipLaunchKernelGGL(conv_o1_fwd_kernel, dim3(ag_cdiv(L, 1024), B), dim3(256), 0, (hipStream_t)stream, x, x_bs, x_cs,
                      w, bias, y, y_bs, C, L, K, pad, act, slope, (int)(ag_precision() == AG_PREC_BF16));
   AG_CHECK_LAUNCH("ag_conv1d_o1_fwd");
   return AG_OK;
+}
+
+// vector form for K = 3: a thread keeps the dy window of its 4 time steps in registers (one 16-byte piece + halo by
+// wave shuffles) and walks CPB channels, one 16-byte store each - the layer is a 237 MB write and nothing else
+#define O1_CPB 16
+__global__ __launch_bounds__(256) void conv_o1_bwdx_vec3_kernel(const float* __restrict__ dy, int64_t dy_bs,
+                                                                const float* __restrict__ w, float* __restrict__ dx,
+                                                                int64_t dx_bs, int64_t dx_cs, int C, int L,
+                                                                int accumulate, int rb) {
+  const int b = blockIdx.z, lane = threadIdx.x & 63;
+  const int t0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+  const bool live = t0 < L;
+  const float* dyr = dy + (int64_t)b * dy_bs + (live ? t0 : 0);
+  const f32x4 g = *reinterpret_cast<const f32x4*>(dyr);
+  const float hl = (lane == 0 && live) ? dyr[max(-1, -t0)] : 0.f;
+  const float hr = (lane == 63 && live) ? dyr[min(4, L - 1 - t0)] : 0.f;
+  const float l_ = __shfl_up(g[3], 1, 64), r_ = __shfl_down(g[0], 1, 64);
+  float win[6];
+  win[0] = (t0 - 1 >= 0) ? ag_rbf_if(lane == 0 ? hl : l_, rb) : 0.f;
+  win[5] = (t0 + 4 < L) ? ag_rbf_if(lane == 63 ? hr : r_, rb) : 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) win[1 + j] = ag_rbf_if(g[j], rb);
+  if (!live) return;
+  // dx[c, t] = sum_k w[c, k] dy[t - k + 1]  (pad 1):  k = 0 -> dy[t+1], k = 1 -> dy[t], k = 2 -> dy[t-1]
+  const int c0 = blockIdx.y * O1_CPB, c1 = min(C, c0 + O1_CPB);
+  float* d = dx + (int64_t)b * dx_bs + (int64_t)c0 * dx_cs + t0;
+  for (int c = c0; c < c1; ++c, d += dx_cs) {
+    const float w0 = ag_rbf_if(w[c * 3], rb), w1 = ag_rbf_if(w[c * 3 + 1], rb), w2 = ag_rbf_if(w[c * 3 + 2], rb);
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = w0 * win[j + 2] + w1 * win[j + 1] + w2 * win[j];
+    if (accumulate) o += *reinterpret_cast<const f32x4*>(d);
+    *reinterpret_cast<f32x4*>(d) = o;
+  }
 }
 
 extern "C" int ag_conv1d_o1_bwd_data(const float* dy, int64_t dy_bs, const float* w, float* dx, int64_t dx_bs,
@@ -673,10 +784,73 @@ extern "C" int ag_conv1d_o1_bwd_data(const float* dy, int64_t dy_bs, const float
                                      void* stream) {
   AG_REQUIRE(dy && w && dx && B > 0 && C > 0 && L > 0 && K > 0 && K <= O1_MAXK && B <= 65535 && C <= 65535,
              "ag_conv1d_o1_bwd_data: bad args");
+  if (K == 3 && pad == 1 && L % 4 == 0 && L >= 4 && dy_bs % 4 == 0 && dx_bs % 4 == 0 && dx_cs % 4 == 0 &&
+      (((uintptr_t)dy | (uintptr_t)dx) & 15) == 0) {
+    hipLaunchKernelGGL(conv_o1_bwdx_vec3_kernel, dim3(ag_cdiv(L, 1024), ag_cdiv(C, O1_CPB), B), dim3(256), 0,
+                       (hipStream_t)stream, dy, dy_bs, w, dx, dx_bs, dx_cs, C, L, accumulate,
+                       (int)(ag_precision() == AG_PREC_BF16));
+    AG_CHECK_LAUNCH("ag_conv1d_o1_bwd_data");
+    return AG_OK;
+  }
   hipLaunchKernelGGL(conv_o1_bwdx_kernel, dim3(ag_cdiv(L, 1024), C, B), dim3(256), 0, (hipStream_t)stream, dy, dy_bs,
                      w, dx, dx_bs, dx_cs, C, L, K, pad, accumulate, (int)(ag_precision() == AG_PREC_BF16));
   AG_CHECK_LAUNCH("ag_conv1d_o1_bwd_data");
   return AG_OK;
+}
+
+// vector form of conv_o1_wgrad_kernel for K = 3: 16-byte pieces of dy and of the channel row, halo by wave shuffles,
+// 4 clips in flight per thread
+__global__ __launch_bounds__(256) void conv_o1_wgrad_vec3_kernel(const float* __restrict__ dy, int64_t dy_bs,
+                                                                 const float* __restrict__ x, int64_t x_bs, int64_t x_cs,
+                                                                 float* __restrict__ dw, int B, int C, int L, int bper,
+                                                                 float* __restrict__ part, int rb) {
+  __shared__ float red[17];
+  const int c = blockIdx.y, lane = threadIdx.x & 63;
+  const int t0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+  const bool live = t0 < L;
+  const int b0 = blockIdx.z * bper, b1 = min(B, b0 + bper);
+  const float* xc0 = x + (int64_t)c * x_cs + (live ? t0 : 0);
+  const float* dy0 = dy + (live ? t0 : 0);
+  float acc[3] = {0.f, 0.f, 0.f};
+  for (int bb = b0; bb < b1; bb += 4) {
+    f32x4 xv[4], gv[4];
+    float hl[4], hr[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int b = min(bb + u, b1 - 1);
+      const float* xr = xc0 + (int64_t)b * x_bs;
+      xv[u] = *reinterpret_cast<const f32x4*>(xr);
+      gv[u] = *reinterpret_cast<const f32x4*>(dy0 + (int64_t)b * dy_bs);
+      hl[u] = (lane == 0 && live) ? xr[max(-1, -t0)] : 0.f;
+      hr[u] = (lane == 63 && live) ? xr[min(4, L - 1 - t0)] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (bb + u >= b1) break;
+      const float l_ = __shfl_up(xv[u][3], 1, 64), r_ = __shfl_down(xv[u][0], 1, 64);
+      float win[6];
+      win[0] = (t0 - 1 >= 0) ? ag_rbf_if(lane == 0 ? hl[u] : l_, rb) : 0.f;
+      win[5] = (t0 + 4 < L) ? ag_rbf_if(lane == 63 ? hr[u] : r_, rb) : 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) win[1 + j] = ag_rbf_if(xv[u][j], rb);
+      if (live) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float g = ag_rbf_if(gv[u][j], rb);
+#pragma unroll
+          for (int k = 0; k < 3; ++k) acc[k] += g * win[j + k];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float s = ag_block_sum(acc[k], red);
+    if (threadIdx.x == 0) {
+      if (part) part[((int64_t)(blockIdx.z * gridDim.x + blockIdx.x) * C + c) * 3 + k] = s;
+      else atomicAdd(dw + c * 3 + k, s);
+    }
+  }
 }
 
 extern "C" int ag_conv1d_o1_wgrad(const float* dy, int64_t dy_bs, const float* x, int64_t x_bs, int64_t x_cs,
@@ -696,6 +870,14 @@ extern "C" int ag_conv1d_o1_wgrad(const float* dy, int64_t dy_bs, const float* x
   }
   const int bper = ag_cdiv(B, gz);
   gz = ag_cdiv(B, bper);
+  if (K == 3 && pad == 1 && L % 4 == 0 && L >= 4 && x_bs % 4 == 0 && x_cs % 4 == 0 && dy_bs % 4 == 0 &&
+      (((uintptr_t)x | (uintptr_t)dy) & 15) == 0) {
+    hipLaunchKernelGGL(conv_o1_wgrad_vec3_kernel, dim3(gx, C, gz), dim3(256), 0, (hipStream_t)stream, dy, dy_bs, x, x_bs,
+                       x_cs, dw, B, C, L, bper, part, (int)(ag_precision() == AG_PREC_BF16));
+    AG_CHECK_LAUNCH("ag_conv1d_o1_wgrad");
+    if (part) return ag_slab_reduce(part, gx * gz, (int64_t)C * K, dw, 1, (hipStream_t)stream);
+    return AG_OK;
+  }
   hipLaunchKernelGGL(conv_o1_wgrad_kernel, dim3(gx, C, gz), dim3(256), 0, (hipStream_t)stream, dy, dy_bs, x, x_bs,
                      x_cs, dw, B, C, L, K, pad, bper, part, (int)(ag_precision() == AG_PREC_BF16));
   AG_CHECK_LAUNCH("ag_conv1d_o1_wgrad");
