@@ -126,6 +126,12 @@ __global__ __launch_bounds__(512) void conv_engine_kernel(const ConvP p) {
             wv[u] = *reinterpret_cast<const f32x4*>(a.wp + ((int64_t)c0 * taps + ct) * p.Mpad + row);
         }
       }
+      if (p.rb) {      // AG_PREC_BF16 (uniform branch): both operands rounded on the way into LDS
+#pragma unroll
+        for (int u = 0; u < UX; ++u) xv[u] = ag_rbf4_if(xv[u], 1);
+#pragma unroll
+        for (int u = 0; u < UW; ++u) wv[u] = ag_rbf4_if(wv[u], 1);
+      }
 #pragma unroll
       for (int u = 0; u < UX; ++u) {
         const int e = xe + u * step;
@@ -149,7 +155,7 @@ __global__ __launch_bounds__(512) void conv_engine_kernel(const ConvP p) {
               qq = rem / p.sp;
               r = rem - qq * p.sp;
             }
-            xs[cc * chs + r * rowlen + qq] = ag_rbf_if(xv[u][q], p.rb);
+            xs[cc * chs + r * rowlen + qq] = xv[u][q];
           }
         }
       }
@@ -158,7 +164,7 @@ __global__ __launch_bounds__(512) void conv_engine_kernel(const ConvP p) {
         const int idx = we + u * step;
         if (idx < wtot) {
           const int r4 = idx % (OT / 4), ct = idx / (OT / 4);
-          *reinterpret_cast<f32x4*>(ws + (size_t)ct * OT + r4 * 4) = ag_rbf4_if(wv[u], p.rb);
+          *reinterpret_cast<f32x4*>(ws + (size_t)ct * OT + r4 * 4) = wv[u];
         }
       }
       xe += UX * step;
@@ -258,14 +264,20 @@ __global__ __launch_bounds__(512) void conv_engine_kernel(const ConvP p) {
       for (int u = 0; u < FX; ++u) xv[u] = *reinterpret_cast<const f32x4*>(xc0 + max(xsrc[u], 0));
 #pragma unroll
       for (int u = 0; u < FW; ++u) wv[u] = *reinterpret_cast<const f32x4*>(wc0 + wsrc[u]);
+      if (p.rb) {      // AG_PREC_BF16 (uniform branch)
+#pragma unroll
+        for (int u = 0; u < FX; ++u) xv[u] = ag_rbf4_if(xv[u], 1);
+#pragma unroll
+        for (int u = 0; u < FW; ++u) wv[u] = ag_rbf4_if(wv[u], 1);
+      }
 #pragma unroll
       for (int u = 0; u < FX; ++u)
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-          if (xl[u][q] >= 0) xs[xl[u][q]] = xsrc[u] < 0 ? 0.f : ag_rbf_if(xv[u][q], p.rb);
+          if (xl[u][q] >= 0) xs[xl[u][q]] = xsrc[u] < 0 ? 0.f : xv[u][q];
 #pragma unroll
       for (int u = 0; u < FW; ++u)
-        if (wl[u] >= 0) *reinterpret_cast<f32x4*>(ws + wl[u]) = ag_rbf4_if(wv[u], p.rb);
+        if (wl[u] >= 0) *reinterpret_cast<f32x4*>(ws + wl[u]) = wv[u];
       __syncthreads();
     }
     for (; ci < nchunk; ++ci) {

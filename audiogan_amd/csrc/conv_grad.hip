@@ -93,13 +93,19 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgP p) {
           if (g >= 0 && g < p.Llg) lv[u] = lb[(int64_t)(c_lo + r) * p.lg_cs + g];
         }
       }
+      if (p.rb) {      // AG_PREC_BF16 (uniform branch): both operands rounded on the way into LDS
+#pragma unroll
+        for (int u = 0; u < US; ++u) sv[u] = ag_rbf4_if(sv[u], 1);
+#pragma unroll
+        for (int u = 0; u < UL; ++u) lv[u] = ag_rbf(lv[u]);
+      }
 #pragma unroll
       for (int u = 0; u < US; ++u) {
         const int e = se + u * step;
         if (e < stot) {
           const int r = e / q4, q = e - r * q4;
 #pragma unroll
-          for (int x = 0; x < 4; ++x) shs[(4 * q + x) * SP + r] = ag_rbf_if(sv[u][x], p.rb);
+          for (int x = 0; x < 4; ++x) shs[(4 * q + x) * SP + r] = sv[u][x];
         }
       }
 #pragma unroll
@@ -107,7 +113,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgP p) {
         const int e = le + u * step;
         if (e < ltot) {
           const int r = e / span, i = e - r * span;
-          lgs[r * p.lgp + i] = ag_rbf_if(lv[u], p.rb);
+          lgs[r * p.lgp + i] = lv[u];
         }
       }
       se += US * step;
@@ -176,18 +182,24 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgP p) {
             lok[u] = gp >= 0 && gp + 3 < p.Llg;
             lv[u] = *reinterpret_cast<const f32x4*>(lrow0 + (lok[u] ? lsrc[u] + (g0 - shift) : 0));
           }
+          if (p.rb) {      // AG_PREC_BF16 (uniform branch)
+#pragma unroll
+            for (int u = 0; u < FS; ++u) sv[u] = ag_rbf4_if(sv[u], 1);
+#pragma unroll
+            for (int u = 0; u < FL; ++u) lv[u] = ag_rbf4_if(lv[u], 1);
+          }
 #pragma unroll
           for (int u = 0; u < FS; ++u)
             if (sl[u] >= 0) {
 #pragma unroll
-              for (int x = 0; x < 4; ++x) shs[sl[u] + x * SP] = ssrc[u] < 0 ? 0.f : ag_rbf_if(sv[u][x], p.rb);
+              for (int x = 0; x < 4; ++x) shs[sl[u] + x * SP] = ssrc[u] < 0 ? 0.f : sv[u][x];
             }
 #pragma unroll
           for (int u = 0; u < FL; ++u)
 #pragma unroll
             for (int x = 0; x < 4; ++x) {
               const int i = li0[u] + x;
-              if (i >= 0 && i < span) lgs[lrow[u] + i] = lok[u] ? ag_rbf_if(lv[u][x], p.rb) : 0.f;
+              if (i >= 0 && i < span) lgs[lrow[u] + i] = lok[u] ? lv[u][x] : 0.f;
             }
         }
         __syncthreads();

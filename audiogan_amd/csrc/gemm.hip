@@ -91,13 +91,17 @@ struct KContig {
     for (int it = 0; it < ITER; ++it) v[it] = *reinterpret_cast<const f32x4*>(base[it] + k0);
   }
   template <int PITCH>
-  __device__ __forceinline__ void store(float* S, int tid, int rb = 0) const {
+  __device__ __forceinline__ void store(float* S, int tid, int rb = 0) {
+    if (rb) {      // AG_PREC_BF16 (uniform branch)
+#pragma unroll
+      for (int it = 0; it < ITER; ++it) v[it] = ag_rbf4_if(v[it], 1);
+    }
 #pragma unroll
     for (int it = 0; it < ITER; ++it) {
       const int idx = tid + it * 256;
       const int r = idx / GKQ, kq = idx % GKQ;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) S[(kq * 4 + e) * PITCH + r] = ag_rbf_if(v[it][e], rb);
+      for (int e = 0; e < 4; ++e) S[(kq * 4 + e) * PITCH + r] = v[it][e];
     }
   }
 };
@@ -156,12 +160,16 @@ struct RContig {
     for (int it = 0; it < ITER; ++it) v[it] = *reinterpret_cast<const f32x4*>(base[it] + koff);
   }
   template <int PITCH>
-  __device__ __forceinline__ void store(float* S, int tid, int rb = 0) const {
+  __device__ __forceinline__ void store(float* S, int tid, int rb = 0) {
+    if (rb) {      // AG_PREC_BF16 (uniform branch)
+#pragma unroll
+      for (int it = 0; it < ITER; ++it) v[it] = ag_rbf4_if(v[it], 1);
+    }
 #pragma unroll
     for (int it = 0; it < ITER; ++it) {
       const int idx = tid + it * 256;
       const int k = idx / R4, r = (idx % R4) * 4;
-      *reinterpret_cast<f32x4*>(S + k * PITCH + r) = ag_rbf4_if(v[it], rb);
+      *reinterpret_cast<f32x4*>(S + k * PITCH + r) = v[it];
     }
   }
 };
@@ -316,7 +324,18 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmP p) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l31 = lane & 31, h = lane >> 5;
   const int wm0 = (wid >> 1) * 64, wn0 = (wid & 1) * 64;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  // XCD-aware tile order (see gemm_bf16_kernel): XCD i works on a contiguous band of row tiles, so each XCD's L2 pulls
+  // its own share of A plus B instead of all of A
+  int bx = blockIdx.x, by = blockIdx.y;
+  {
+    const int nwg = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;
+    if ((nwg & 7) == 0) {
+      const int tile = (lin & 7) * (nwg >> 3) + (lin >> 3);
+      by = tile / gridDim.x;
+      bx = tile - by * gridDim.x;
+    }
+  }
+  const int m0 = by * BM, n0 = bx * BN;
 
   // per-lane DMA sources at k = 0 (two 16-byte pieces per operand per tile)
   const float* asrc[2];

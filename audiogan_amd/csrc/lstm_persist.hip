@@ -70,7 +70,7 @@ __device__ __forceinline__ bool ps_wait_flags(unsigned* hdr, const unsigned* fla
   }
 }
 
-template <int RT>      // 32-clip row tiles per workgroup
+template <int RT, bool RB>      // 32-clip row tiles per workgroup; RB: operands rounded to bf16 (AG_PREC_BF16)
 __global__ __launch_bounds__(512) void lstm_persist_fwd_kernel(const PersistFwdP p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NKS = 8 / RT;                 // K slices (waves per row tile)
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(512) void lstm_persist_fwd_kernel(const PersistFwdP
     const int k4n = H >> 2;
     for (int idx = tid; idx < 32 * k4n; idx += 512) {
       const int j = idx / k4n, k4 = idx - j * k4n;
-      const f32x4 v = ag_rbf4_if(*reinterpret_cast<const f32x4*>(D.whh + (int64_t)((j >> 3) * H + u0 + (j & 7)) * H + 4 * k4), p.rb);
+      const f32x4 v = ag_rbf4_if(*reinterpret_cast<const f32x4*>(D.whh + (int64_t)((j >> 3) * H + u0 + (j & 7)) * H + 4 * k4), RB);
       *reinterpret_cast<f32x4*>(wl + ((size_t)((k4 >> 1) * 2 + (k4 & 1)) * 32 + j) * 4) = v;
     }
   }
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(512) void lstm_persist_fwd_kernel(const PersistFwdP
             const f32x4 b = *reinterpret_cast<const f32x4*>(wrow + (size_t)q * 256);
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-              acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ag_rbf_if(__uint_as_float(a[i][e]), p.rb), b[e], acc, 0, 0, 0);
+              acc = __builtin_amdgcn_mfma_f32_32x32x2f32(RB ? ag_rbf(__uint_as_float(a[i][e])) : __uint_as_float(a[i][e]), b[e], acc, 0, 0, 0);
           }
         }
       }
@@ -274,15 +274,10 @@ extern "C" int ag_lstm_seq_fwd_persist(float* const* pre, const float* const* wh
   p.rb = ag_precision() == AG_PREC_BF16;
   const size_t lds = ((size_t)32 * H + 8 * 1024) * sizeof(float);
   const int grid = ndir * nbt * p.ntile;
-  if (rt == 1) {
-    auto kern = lstm_persist_fwd_kernel<1>;
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, p);
-  } else {
-    auto kern = lstm_persist_fwd_kernel<2>;
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, p);
-  }
+  void (*kern)(const PersistFwdP) = rt == 1 ? (p.rb ? lstm_persist_fwd_kernel<1, true> : lstm_persist_fwd_kernel<1, false>)
+                                            : (p.rb ? lstm_persist_fwd_kernel<2, true> : lstm_persist_fwd_kernel<2, false>);
+  (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, p);
   AG_CHECK_LAUNCH("ag_lstm_seq_fwd_persist");
   return AG_OK;
 }
@@ -323,7 +318,7 @@ struct PersistBwdP {
   int rb;               // AG_PREC_BF16: both operands of the recurrent product rounded to bf16
 };
 
-template <int NU>       // 16-k units per wave: 4H = 8 waves * NU * 16
+template <int NU, bool RB>       // 16-k units per wave: 4H = 8 waves * NU * 16; RB: operands rounded to bf16
 __global__ __launch_bounds__(512) void lstm_persist_bwd_kernel(const PersistBwdP p) {
   __shared__ float red[8 * 512];
   const int H = p.H, B = p.B, T = p.T, ntile = p.ntile;
@@ -344,7 +339,7 @@ __global__ __launch_bounds__(512) void lstm_persist_bwd_kernel(const PersistBwdP
     for (int e = 0; e < 4; ++e)
 #pragma unroll
       for (int c = 0; c < 2; ++c)
-        wreg[u][e][c] = ag_rbf_if(D.whh[(int64_t)((wid * NU + u) * 16 + 4 * g + e) * H + n0 + 16 * c + li], p.rb);
+        wreg[u][e][c] = ag_rbf_if(D.whh[(int64_t)((wid * NU + u) * 16 + 4 * g + e) * H + n0 + 16 * c + li], RB);
 
   unsigned* flags = p.hdr + PS_FLAG_OFF + grp * ntile;
   // epilogue role: thread <-> (clip row, unit)
@@ -381,12 +376,16 @@ __global__ __launch_bounds__(512) void lstm_persist_bwd_kernel(const PersistBwdP
 #pragma unroll
         for (int i = 0; i < UB; ++i) a[i] = __builtin_amdgcn_raw_buffer_load_b128(ar, aoff + (unsigned)((ub + i) * 64), 0, 16);
 #pragma unroll
-        for (int i = 0; i < UB; ++i)
+        for (int i = 0; i < UB; ++i) {
+          float av[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) av[e] = RB ? ag_rbf(__uint_as_float(a[i][e])) : __uint_as_float(a[i][e]);
 #pragma unroll
           for (int e = 0; e < 4; ++e)
 #pragma unroll
             for (int c = 0; c < 2; ++c)
-              acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(ag_rbf_if(__uint_as_float(a[i][e]), p.rb), wreg[ub + i][e][c], acc[c], 0, 0, 0);
+              acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], wreg[ub + i][e][c], acc[c], 0, 0, 0);
+        }
       }
     }
     // C layout of a 16x16 tile: col = lane & 15, row = 4 * (lane >> 4) + e
@@ -469,12 +468,14 @@ extern "C" int ag_lstm_seq_bwd_persist(const float* const* gates, const float* c
   p.T = T; p.B = B; p.H = H; p.ndir = ndir; p.nbt = ag_cdiv(B, 16); p.ntile = H / 32;
   p.rb = ag_precision() == AG_PREC_BF16;
   const int grid = ndir * p.nbt * p.ntile;
+  void (*kern)(const PersistBwdP);
   switch (H) {
-    case 512: hipLaunchKernelGGL(lstm_persist_bwd_kernel<16>, dim3(grid), dim3(512), 0, st, p); break;
-    case 256: hipLaunchKernelGGL(lstm_persist_bwd_kernel<8>, dim3(grid), dim3(512), 0, st, p); break;
-    case 128: hipLaunchKernelGGL(lstm_persist_bwd_kernel<4>, dim3(grid), dim3(512), 0, st, p); break;
-    default:  hipLaunchKernelGGL(lstm_persist_bwd_kernel<2>, dim3(grid), dim3(512), 0, st, p); break;
+    case 512: kern = p.rb ? lstm_persist_bwd_kernel<16, true> : lstm_persist_bwd_kernel<16, false>; break;
+    case 256: kern = p.rb ? lstm_persist_bwd_kernel<8, true> : lstm_persist_bwd_kernel<8, false>; break;
+    case 128: kern = p.rb ? lstm_persist_bwd_kernel<4, true> : lstm_persist_bwd_kernel<4, false>; break;
+    default:  kern = p.rb ? lstm_persist_bwd_kernel<2, true> : lstm_persist_bwd_kernel<2, false>; break;
   }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), 0, st, p);
   AG_CHECK_LAUNCH("ag_lstm_seq_bwd_persist");
   return AG_OK;
 }
