@@ -479,3 +479,270 @@ extern "C" int ag_lstm_seq_bwd_persist(const float* const* gates, const float* c
   AG_CHECK_LAUNCH("ag_lstm_seq_bwd_persist");
   return AG_OK;
 }
+
+// ------------------------------------------------------------------------------------------
+// The Generator's recurrent front (audiogan.py:428-460, one LSTMCell layer) as ONE persistent launch:
+//   frame t:  gates = pre_t + [x_{t-1} | h_{t-1}] [W_x | W_hh]^T ;  (c_t, h_t) = cell(gates) ;  x_t = tanh(h_t W_p^T + b_p)
+// (pre_t = the z/c columns of W_ih and both biases, one GEMM over all frames beforehand; the stop head is one GEMM over
+// all frames afterwards).  Per frame the launch-per-op path costs a fused step kernel plus a projection kernel, each
+// re-streaming its weights (21 MB + 1 MB); here every weight stays in REGISTERS for all T frames:
+//
+//   workgroup (rt, ut): 32 clips x 8 hidden units (32 gate columns); its 8 waves split K: each holds S/8 rows of the
+//   [W_hh] panel and fs/8 rows of the [W_x] panel as MFMA B operands (80 VGPRs at S = 1024, fs = 256).
+//   phase A, frame t: h_{t-1} part of the product as soon as the group's h flags are up, x_{t-1} part when the
+//   projection tiles are up, LDS sum over the waves, cell, h_t published (write-through) + flag.
+//   phase B, frame t (workgroups ut < 2*fs/16 only): one [16 clips x 16 frame samples] tile of x_t = tanh(h_t W_p^T + b):
+//   waits for all h_t of its clips, v_mfma_f32_16x16x4_f32 against its resident W_p panel, publishes x_t + flag.
+//   The h part of frame t+1 (80 % of the MFMAs) overlaps phase B of frame t on the other workgroups.
+// Exchange buffers ([parity][rt][8-unit tile][32 clips][8], as in the layer kernels) hold h and x; two parities are
+// enough (h_{t+1} / x_{t+1} are written only after every reader of h_{t-1} / x_{t-1} has finished frame t).
+// ------------------------------------------------------------------------------------------
+struct FrontFwdP {
+  float* gates;        // [T,B,4S] in: pre; out: activated gates
+  const float* wx;     // W_ih[:, :fs]   [4S, ldwx]
+  const float* whh;    // [4S, S]
+  const float* wp;     // [fs, S]
+  const float* bp;     // [fs]
+  float* hs;           // [T,B,S]
+  float* cs;           // [T+1,B,S]  (cs[0] = 0 on entry)
+  float* x;            // [B, T*fs]
+  float* hx;           // exchange: h   [2][nrt][S/8][32][8]
+  float* xx;           // exchange: x   [2][nrt][fs/8][32][8]
+  unsigned* hdr;
+  int T, B, ldwx, nrt, rb;
+};
+
+template <int S, int FS>
+__global__ __launch_bounds__(512) void gfront_persist_fwd_kernel(const FrontFwdP p) {
+  constexpr int NUT = S / 8;                 // unit tiles = workgroups per row tile
+  constexpr int QH = S / 64, QX = FS / 64;   // 8-k groups of the h / x panel per wave
+  constexpr int NB = 2 * (FS / 16);          // projection tiles per row tile (2 x 16-clip subtiles)
+  constexpr int UP = S / 128;                // 16-k units of W_p per wave
+  static_assert(S % 128 == 0 && FS % 64 == 0 && NB <= NUT, "unsupported front shape");
+  __shared__ float red[8 * 1024];
+  const int T = p.T, B = p.B;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l31 = lane & 31, hh = lane >> 5, li = lane & 15, g = lane >> 4;
+  const int rt = blockIdx.x % p.nrt, ut = blockIdx.x / p.nrt;
+  const int u0 = ut * 8, row0 = rt * 32;
+
+  // ---- resident panels (B operands).  Gate column j = gate (j>>3), unit u0 + (j&7).
+  float wh[QH][4], wxr[QX][4];
+  {
+    const int wrow = (l31 >> 3) * S + u0 + (l31 & 7);
+#pragma unroll
+    for (int q = 0; q < QH; ++q) {
+      const f32x4 v = ag_rbf4_if(*reinterpret_cast<const f32x4*>(p.whh + (int64_t)wrow * S + (wid * QH + q) * 8 + 4 * hh), p.rb);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) wh[q][e] = v[e];
+    }
+#pragma unroll
+    for (int q = 0; q < QX; ++q) {
+      const f32x4 v = ag_rbf4_if(*reinterpret_cast<const f32x4*>(p.wx + (int64_t)wrow * p.ldwx + (wid * QX + q) * 8 + 4 * hh), p.rb);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) wxr[q][e] = v[e];
+    }
+  }
+  const bool bwg = ut < NB;                  // this workgroup also owns a projection tile
+  const int bsub = ut & 1, bcol0 = (ut >> 1) * 16;
+  float wpr[UP][4];
+#pragma unroll
+  for (int u = 0; u < UP; ++u) {
+    const f32x4 v = bwg ? ag_rbf4_if(*reinterpret_cast<const f32x4*>(p.wp + (int64_t)(bcol0 + li) * S + (wid * UP + u) * 16 + 4 * g), p.rb)
+                        : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) wpr[u][e] = v[e];
+  }
+
+  unsigned* flag_h = p.hdr + PS_FLAG_OFF + rt * NUT;
+  unsigned* flag_x = p.hdr + PS_FLAG_OFF + p.nrt * NUT + rt * NB;
+  const int64_t hgs = (int64_t)NUT * 32 * 8, xgs = (int64_t)(FS / 8) * 32 * 8;     // floats per (parity, rt)
+  __amdgpu_buffer_rsrc_t hr = __builtin_amdgcn_make_buffer_rsrc(p.hx, 0, (int)(2 * p.nrt * hgs * 4), 0x00020000);
+  __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(p.xx, 0, (int)(2 * p.nrt * xgs * 4), 0x00020000);
+
+  // phase A epilogue role: thread (clip row, unit), tid < 256
+  const int erow = tid >> 3, euu = tid & 7;
+  const int em = row0 + erow, eu = u0 + euu;
+  const bool epi = tid < 256 && em < B;
+  const int ee = (erow & 3) + 4 * (erow >> 3), ehq = (erow >> 2) & 1;
+  float creg = 0.f;
+  // phase B epilogue role: thread (clip row within the 16-row subtile, column), tid < 256
+  const int brow = tid >> 4, bcl = tid & 15;
+  const int bm = row0 + 16 * bsub + brow;
+  const float bbias = (bwg && tid < 256) ? p.bp[bcol0 + bcl] : 0.f;
+  bool alive = true;
+
+  for (int t = 0; t < T; ++t) {
+    float pre4[4] = {0.f, 0.f, 0.f, 0.f};
+    if (epi) {
+      const float* pr = p.gates + ((int64_t)t * B + em) * 4 * S + eu;
+      pre4[0] = pr[0]; pre4[1] = pr[S]; pre4[2] = pr[2 * S]; pre4[3] = pr[3 * S];
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    if (t > 0) {
+      const int par = (t - 1) & 1;
+      // ---- h part (its flags were already waited for by the projection phase of frame t-1 on projection workgroups)
+      if (wid == 0 && alive) alive = ps_wait_flags(p.hdr, flag_h, NUT, (unsigned)t, lane);
+      __syncthreads();
+      {
+        const unsigned ab = (unsigned)(((int64_t)(par * p.nrt + rt) * hgs + (int64_t)l31 * 8 + 4 * hh) * 4);
+        u32x4 a[QH];
+#pragma unroll
+        for (int q = 0; q < QH; ++q) a[q] = __builtin_amdgcn_raw_buffer_load_b128(hr, ab + (unsigned)((wid * QH + q) * 32 * 32), 0, 16);
+        if (p.rb) {
+#pragma unroll
+          for (int q = 0; q < QH; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[q][e] = __float_as_uint(ag_rbf(__uint_as_float(a[q][e])));
+        }
+#pragma unroll
+        for (int q = 0; q < QH; ++q)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a[q][e]), wh[q][e], acc, 0, 0, 0);
+      }
+      // ---- x part
+      if (wid == 0 && alive) alive = ps_wait_flags(p.hdr, flag_x, NB, (unsigned)t, lane);
+      __syncthreads();
+      {
+        const unsigned ab = (unsigned)(((int64_t)(par * p.nrt + rt) * xgs + (int64_t)l31 * 8 + 4 * hh) * 4);
+        u32x4 a[QX];
+#pragma unroll
+        for (int q = 0; q < QX; ++q) a[q] = __builtin_amdgcn_raw_buffer_load_b128(xr, ab + (unsigned)((wid * QX + q) * 32 * 32), 0, 16);
+        if (p.rb) {
+#pragma unroll
+          for (int q = 0; q < QX; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[q][e] = __float_as_uint(ag_rbf(__uint_as_float(a[q][e])));
+        }
+#pragma unroll
+        for (int q = 0; q < QX; ++q)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a[q][e]), wxr[q][e], acc, 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) red[wid * 1024 + e * 64 + lane] = acc[e];
+    __syncthreads();
+    float hreg = 0.f, ig = 0.f, fg = 0.f, gg = 0.f, og = 0.f;
+    if (epi) {
+      float g4[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float s = pre4[q];
+        if (t > 0) {
+#pragma unroll
+          for (int w = 0; w < 8; ++w) s += red[w * 1024 + ee * 64 + 32 * ehq + 8 * q + euu];
+        }
+        g4[q] = s;
+      }
+      ig = ag_sigmoid(g4[0]); fg = ag_sigmoid(g4[1]); gg = tanhf(g4[2]); og = ag_sigmoid(g4[3]);
+      creg = fg * creg + ig * gg;
+      hreg = og * tanhf(creg);
+    }
+    if (tid < 256) {
+      // publish h_t (rows past the batch: zeros, so that the exchange buffer stays defined)
+      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(hreg), hr,
+          (unsigned)(((int64_t)((t & 1) * p.nrt + rt) * hgs + ((int64_t)ut * 32 + erow) * 8 + euu) * 4), 0, 16);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(flag_h + ut, (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (epi) {
+      float* pr = p.gates + ((int64_t)t * B + em) * 4 * S + eu;
+      pr[0] = ig; pr[S] = fg; pr[2 * S] = gg; pr[3 * S] = og;
+      p.cs[((int64_t)(t + 1) * B + em) * S + eu] = creg;
+      p.hs[((int64_t)t * B + em) * S + eu] = hreg;
+    }
+    // ---- phase B: this workgroup's tile of x_t = tanh(h_t W_p^T + b)
+    if (bwg) {
+      if (wid == 0 && alive) alive = ps_wait_flags(p.hdr, flag_h, NUT, (unsigned)(t + 1), lane);
+      __syncthreads();
+      f32x4 pacc = {0.f, 0.f, 0.f, 0.f};
+      {
+        // A = h_t rows of the 16-clip subtile: lane (clip li, k slot g) takes k = 16u + 4g .. +3 = unit tile 2u + (g>>1), half g&1
+        const unsigned ab = (unsigned)(((int64_t)((t & 1) * p.nrt + rt) * hgs + (int64_t)(16 * bsub + li) * 8 + 4 * (g & 1)) * 4);
+        u32x4 a[UP];
+#pragma unroll
+        for (int u = 0; u < UP; ++u)
+          a[u] = __builtin_amdgcn_raw_buffer_load_b128(hr, ab + (unsigned)((2 * (wid * UP + u) + (g >> 1)) * 32 * 32), 0, 16);
+        if (p.rb) {
+#pragma unroll
+          for (int u = 0; u < UP; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[u][e] = __float_as_uint(ag_rbf(__uint_as_float(a[u][e])));
+        }
+#pragma unroll
+        for (int u = 0; u < UP; ++u)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) pacc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[u][e]), wpr[u][e], pacc, 0, 0, 0);
+      }
+      // 16x16 tile: col = lane & 15, row = 4 * (lane >> 4) + e   (red is free again: the gate sums were consumed above)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) red[wid * 256 + (4 * g + e) * 16 + li] = pacc[e];
+      __syncthreads();
+      if (tid < 256) {
+        float v = bbias;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) v += red[w * 256 + tid];
+        v = tanhf(v);
+        const int col = bcol0 + bcl;
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(bm < B ? v : 0.f), xr,
+            (unsigned)(((int64_t)((t & 1) * p.nrt + rt) * xgs + ((int64_t)(col >> 3) * 32 + 16 * bsub + brow) * 8 + (col & 7)) * 4), 0, 16);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (bm < B) p.x[(int64_t)bm * T * FS + (int64_t)t * FS + col] = v;
+      }
+      __syncthreads();
+      if (tid == 0) __hip_atomic_store(flag_x + ut, (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+static bool front_shape_ok(int B, int S, int fs, int n_cu) {
+  if (!((S == 1024 && fs == 256) || (S == 128 && fs == 64))) return false;
+  if (B < 1 || B > 64) return false;
+  if (n_cu > 256) n_cu = 256;
+  return ag_cdiv(B, 32) * (S / 8) <= n_cu;
+}
+
+extern "C" int ag_gfront_persist_ok(int B, int S, int fs, int n_cu) { return front_shape_ok(B, S, fs, n_cu) ? 1 : 0; }
+
+extern "C" int64_t ag_gfront_persist_ws_bytes(int B, int S, int fs) {
+  return PS_HDR_BYTES + (int64_t)2 * ag_cdiv(B, 32) * 32 * (S + fs) * 4;
+}
+
+// One launch for the whole frame loop of the Generator front (one LSTMCell layer).  gates [T,B,4S]: in = the z/c
+// part of the pre-activations + both biases, out = activated gates; w_x = W_ih[:, :fs] (row pitch ldwx), w_hh [4S,S],
+// w_p [fs,S], b_p [fs]; outputs hs [T,B,S], cs [T+1,B,S] (cs[0] = 0 on entry), x [B,T*fs].  Shapes: ag_gfront_persist_ok.
+extern "C" int ag_gfront_fwd_persist(float* gates, const float* w_x, int ldwx, const float* w_hh, const float* w_p,
+                                     const float* b_p, float* hs, float* cs, float* x, void* ws, int64_t ws_bytes,
+                                     int T, int B, int S, int fs, int n_cu, void* stream) {
+  AG_REQUIRE(gates && w_x && w_hh && w_p && b_p && hs && cs && x && ws, "ag_gfront_fwd_persist: null tensor");
+  AG_REQUIRE(T > 0, "ag_gfront_fwd_persist: T must be positive");
+  if (!front_shape_ok(B, S, fs, n_cu)) {
+    ag_set_error("ag_gfront_fwd_persist: shape B=%d S=%d fs=%d is not supported on %d CUs", B, S, fs, n_cu);
+    return AG_ERR_UNSUPPORTED;
+  }
+  AG_REQUIRE(ws_bytes >= ag_gfront_persist_ws_bytes(B, S, fs) && ((uintptr_t)ws & 15) == 0,
+             "ag_gfront_fwd_persist: workspace too small or misaligned");
+  AG_REQUIRE(ldwx % 4 == 0 && (((uintptr_t)w_x | (uintptr_t)w_hh | (uintptr_t)w_p) & 15) == 0,
+             "ag_gfront_fwd_persist: weights must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(ws, 0, PS_HDR_BYTES, st) != hipSuccess) {
+    ag_set_error("ag_gfront_fwd_persist: memset failed");
+    return AG_ERR_LAUNCH;
+  }
+  FrontFwdP p;
+  p.gates = gates; p.wx = w_x; p.whh = w_hh; p.wp = w_p; p.bp = b_p; p.hs = hs; p.cs = cs; p.x = x;
+  p.hdr = (unsigned*)ws;
+  p.nrt = ag_cdiv(B, 32);
+  p.hx = (float*)((char*)ws + PS_HDR_BYTES);
+  p.xx = p.hx + (int64_t)2 * p.nrt * 32 * S;
+  p.T = T; p.B = B; p.ldwx = ldwx; p.rb = ag_precision() == AG_PREC_BF16;
+  const int grid = p.nrt * (S / 8);
+  if (S == 1024) hipLaunchKernelGGL((gfront_persist_fwd_kernel<1024, 256>), dim3(grid), dim3(512), 0, st, p);
+  else hipLaunchKernelGGL((gfront_persist_fwd_kernel<128, 64>), dim3(grid), dim3(512), 0, st, p);
+  AG_CHECK_LAUNCH("ag_gfront_fwd_persist");
+  return AG_OK;
+}

@@ -123,10 +123,15 @@ def _table(kind, structs, device):
         return t[0]
     capturing = torch.device(device).type == 'cuda' and torch.cuda.is_current_stream_capturing()
     t = _table_cache.get(key)
-    if t is not None and not capturing:
+    if t is not None:
+        if capturing:
+            # uploaded eagerly before the capture began (complete: capture starts behind a synchronize): the graph's
+            # kernels may read it as it is, without a copy node - but from now on it must never be evicted
+            _table_pinned[key] = _table_cache.pop(key)
+            _capture_log.append(key)
+            return t[0]
         _table_cache.move_to_end(key)
         return t[0]
-    # (an eager entry is NOT reused by a capture: its upload happened outside the graph and the entry may be evicted)
     src = torch.frombuffer(bytearray(raw), dtype=torch.uint8)
     if torch.device(device).type == 'cuda':
         # staged through a pre-allocated pinned arena + async copy: legal inside hipGraph capture (the copy becomes a
@@ -752,6 +757,35 @@ def _lstm_seq_fwd_range(pre, whh, c_all, hbuf, y, valid, k0, k1, static=None):
                               _stream()), 'ag_lstm_seq_fwd')
 
 
+def gfront_persist_ok(B, S, fs, dev):
+    return bool(PERSIST[0] and torch.device(dev).type == 'cuda' and lib.ag_gfront_persist_ok(B, S, fs, _n_cu(dev)))
+
+
+def gfront_fwd_persist(gates, wx, whh, wp, bp, hs, cs, x):
+    """the Generator front's frame loop in ONE persistent launch (ag_gfront_fwd_persist)"""
+    T, B, S4 = gates.shape
+    S = S4 // 4
+    fs = wp.size(0)
+    for t_, n, shp in ((gates, 'gates', (T, B, 4 * S)), (whh, 'whh', (4 * S, S)), (wp, 'wp', (fs, S)), (bp, 'bp', (fs,)),
+                       (hs, 'hs', (T, B, S)), (cs, 'cs', (T + 1, B, S)), (x, 'x', (B, T * fs))):
+        _chk(t_, n)
+        assert t_.is_contiguous() and tuple(t_.shape) == shp, (n, tuple(t_.shape), shp)
+    _chk(wx, 'wx')
+    assert tuple(wx.shape) == (4 * S, fs) and wx.stride(1) == 1
+    nb = int(lib.ag_gfront_persist_ws_bytes(B, S, fs))
+    ws = _persist_workspace(x.device, nb)
+    check(lib.ag_gfront_fwd_persist(_p(gates), _p(wx), wx.stride(0), _p(whh), _p(wp), _p(bp), _p(hs), _p(cs), _p(x),
+                                    _p(ws), ws.numel(), T, B, S, fs, _n_cu(x.device), _stream()),
+          'ag_gfront_fwd_persist')
+
+
+def _work_gfront(gates, wx, whh, wp, *a_, **kw):
+    T, B, S4 = gates.shape
+    S, fs = S4 // 4, wp.size(0)
+    return 'gfront_persist_fwd_kernel', T * 2.0 * B * (S4 * (S + fs) + fs * S), \
+        4.0 * (S4 * (S + fs) + fs * S + T * B * (2 * S4 + 2 * S + fs)), 1
+
+
 def lstm_persist_bwd_ok(B, H, ndir, dev):
     return bool(PERSIST[0] and lib.ag_lstm_persist_bwd_ok(B, H, ndir, _n_cu(dev)))
 
@@ -874,7 +908,7 @@ def _work_seq_bwd_cell(gates, whh, *a_, **kw):
 
 for _n, _w in (('skinny_gemm', _work_skinny), ('lstm_step_fwd', _work_step),
                ('_lstm_seq_fwd_range', _work_seq_fwd), ('_lstm_seq_fwd_persist_call', _work_seq_fwd_persist),
-               ('_lstm_seq_bwd_persist_call', _work_seq_bwd_persist), ('_lstm_seq_bwd_prod', _work_seq_bwd_prod),
+               ('_lstm_seq_bwd_persist_call', _work_seq_bwd_persist), ('gfront_fwd_persist', _work_gfront), ('_lstm_seq_bwd_prod', _work_seq_bwd_prod),
                ('_lstm_seq_bwd_cell', _work_seq_bwd_cell), ('_lstm_seq_bwd_step', _work_seq_bwd_step)):
     _instrument(_n, _w)
 

@@ -223,7 +223,11 @@ class GFrontFn(torch.autograd.Function):
         # all frames at once: zc_t @ W_ih[:, fs:]^T + b_ih + b_hh
         K.gemm(zc.contiguous().view(T * B, Fz), wz, gates[0].view(T * B, 4 * S), tb=True, bias=bsum[0])
         fused0 = K.lstm_step_ok(B, S, x[:, :fs], wx)
-        for t in range(T):
+        persist = nl == 1 and K.gfront_persist_ok(B, S, fs, dev)
+        if persist:
+            # the whole frame loop (LSTMCell step + projection, fed back) in ONE launch, weights resident in registers
+            K.gfront_fwd_persist(gates[0], wx, lw[0][1], pw, pb, hs[0], cs[0], x)
+        for t in range(0 if persist else T):
             xprev = x[:, (t - 1) * fs:t * fs] if t > 0 else x[:, :fs]
             if fused0:
                 K.lstm_step_fwd(gates[0][t], xprev, wx, hs[0][t - 1] if t > 0 else h0, lw[0][1], cs[0][t],

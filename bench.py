@@ -107,9 +107,9 @@ def one_step(train, g, d, opt_g, opt_d, b, hook_d=None, hook_g=None, overlap=Fal
 
 def pmc_traffic(kernel):
     """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes
-    (profiles/r01_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE in separate passes, gfx950 x2 read
+    (profiles/r02_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE in separate passes, gfx950 x2 read
     correction applied); None when that kernel was not profiled."""
-    path = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
+    path = os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json')
     if not os.path.exists(path):
         return None
     tab = json.load(open(path))

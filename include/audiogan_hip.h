@@ -296,6 +296,18 @@ int ag_lstm_seq_bwd_persist(const float* const* gates, const float* const* whh, 
                             const float* dy, float* const* dgates, const int64_t* valid_i64, void* ws,
                             int64_t ws_bytes, int T, int B, int H, int ndir, int n_cu, void* stream);
 
+/* The Generator front's whole frame loop (audiogan.py:428-460, one LSTMCell layer + tanh(proj) fed back) as ONE
+ * persistent launch with every weight resident in registers (csrc/lstm_persist.hip).  gates [T,B,4S]: in = the z / c
+ * part of the gate pre-activations + both biases (one GEMM over all frames), out = activated gates; w_x = W_ih[:, :fs]
+ * (row pitch ldwx), w_hh [4S,S], w_p [fs,S], b_p [fs]; outputs hs [T,B,S], cs [T+1,B,S] (cs[0] = 0 on entry) and the
+ * frames x [B,T*fs].  Supported: (S, fs) in {(1024, 256), (128, 64)}, B <= 64 (ag_gfront_persist_ok); `ws` =
+ * ag_gfront_persist_ws_bytes() bytes, used as for ag_lstm_seq_fwd_persist. */
+int ag_gfront_persist_ok(int B, int S, int fs, int n_cu);
+int64_t ag_gfront_persist_ws_bytes(int B, int S, int fs);
+int ag_gfront_fwd_persist(float* gates, const float* w_x, int ldwx, const float* w_hh, const float* w_p,
+                          const float* b_p, float* hs, float* cs, float* x, void* ws, int64_t ws_bytes, int T, int B,
+                          int S, int fs, int n_cu, void* stream);
+
 /* One fused backward step of the Generator front (audiogan.py:428-460: LSTMCell -> tanh(Linear) fed back), frame t:
  *   gx     = dxa * (1 - x_t^2)                        d(pre-tanh) of the projection, stored to gx_out [B,Kp]
  *   dh     = dh_acc + gx * w_proj                      w_proj [Kp = frame size, H]; dh_acc [B,H] rows, pitch lddh

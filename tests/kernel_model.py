@@ -327,6 +327,11 @@ def install(monkeypatch):
         monkeypatch.setattr(K, n, globals()[n])
 
 
+def gfront_persist_ok(B, S, fs, dev):
+    """the persistent Generator-front launch has no CPU model: the host logic takes the frame-by-frame path"""
+    return False
+
+
 # ---- skinny products / fused recurrent steps (same contracts as lstm_step.hip) -----------------
 def skinny_ok(A, B, tb):
     M, Kd = A.shape

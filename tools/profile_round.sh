@@ -5,4 +5,4 @@ rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_stats -o
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_f -o f -- python bench.py --steps 2 --warmup 1 --no-graph --no-roofline --no-cpu-baseline > gpurun_out/pmc_f.log 2>&1 || exit 1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_w -o w -- python bench.py --steps 2 --warmup 1 --no-graph --no-roofline --no-cpu-baseline > gpurun_out/pmc_w.log 2>&1 || exit 1
 python tools/pmc_traffic.py gpurun_out/pmc_f/f_counter_collection.csv gpurun_out/pmc_w/w_counter_collection.csv
-cp profiles/r01_pmc_traffic.json gpurun_out/r01_pmc_traffic.json
+cp profiles/r02_pmc_traffic.json gpurun_out/r02_pmc_traffic.json
