@@ -166,6 +166,13 @@ class Generator(nn.Module):
     def _front_apply(self, zc):
         return ops.GFrontFn.apply(zc, self._front, *self._front.group.params())
 
+    def front_is_persistent(self, batch_size, dev):
+        """does the frame loop of a forward at this batch size run as ONE persistent launch (all CUs, one such launch at
+        a time per device)?  Callers that want to run two forwards side by side on two streams must not when it does."""
+        from . import kernels as K
+        return self._num_layers == 1 and type(self) is Generator and \
+            K.gfront_persist_ok(batch_size, self._state_size, self._frame_size, dev)
+
     def prepare_weights(self):
         """materialise the weight-normed weights of every block NOW, on the current stream (no-op when the
         parameters have not changed since the last materialisation).  A caller that runs two forwards of this

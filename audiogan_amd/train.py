@@ -19,6 +19,10 @@ def gd_step(g, d, opt_g, opt_d, real, real_len, c, z, noise_real, noise_fake, dg
     weight-normed weights are materialised on the main stream BEFORE the fork, so neither branch rewrites a buffer
     the other one reads.  Returns (loss_d, loss_g)."""
     pre = None
+    if overlap and real.is_cuda and g.front_is_persistent(z.size(0), real.device):
+        # a persistent launch occupies every CU and must be the only one in flight: nothing to gain from a second stream
+        # (and two persistent launches racing for the CUs would stall each other)
+        overlap = False
     if overlap and real.is_cuda:
         dev = real.device
         side = _SIDE.get(dev)

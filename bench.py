@@ -307,6 +307,8 @@ def main():
                 graph.replay()
             else:
                 scale = 1.0 / world
+                # (no second stream when the generator's frame loop is a persistent launch: one at a time per device)
+                side_ok = not args.no_overlap and not g.front_is_persistent(args.batch, dev)
                 # critic: graph 1a ends where the gradients of heads + biLSTM are final; their all-reduce
                 # (93 % of D's bytes) then runs on RCCL's stream WHILE graph 1b does the conv-stack backward.
                 # generator: graph 3a ends where the conv trunk's gradients are final; their all-reduce runs
@@ -315,16 +317,18 @@ def main():
                     # the G forward of the generator iteration is a parallel branch of this graph (as in the
                     # single-graph step): G's weights are materialised on the main stream, then fork, run it
                     # beside the critic, join before the capture ends
-                    if not args.no_overlap:
+                    if side_ok:
                         if _SIDE[0] is None:
                             _SIDE[0] = torch.cuda.Stream()
                         g.prepare_weights()
                         _SIDE[0].wait_stream(torch.cuda.current_stream())
                         with torch.cuda.stream(_SIDE[0]):
                             keep['pre'] = g(z=b_['z'], c=b_['c'], stop='never', cut=gkeep)
+                    else:
+                        keep['pre'] = None
                     keep['loss_d'] = train.d_backward_early(g, d, opt_d, b_['real'], b_['real_len'], b_['c'], b_['z'],
                                                             b_['noise_real'], b_['noise_fake'], keep)
-                    if not args.no_overlap:
+                    if side_ok:
                         torch.cuda.current_stream().wait_stream(_SIDE[0])
 
                 def gen_early():
@@ -335,7 +339,7 @@ def main():
                 g1b = capture(lambda: train.d_backward_late(keep), warm=False)
                 bd.all_reduce()
                 g2 = capture(lambda: opt_d.step(clip_norm=1.0, grad_scale=scale))
-                g3a = capture(gen_early, warm=args.no_overlap)
+                g3a = capture(gen_early, warm=not side_ok)
                 g3b = capture(lambda: train.g_backward_late(gkeep), warm=False)
                 bg.all_reduce()
                 g4 = capture(lambda: opt_g.step(clip_norm=0.1, grad_scale=scale))
@@ -432,7 +436,8 @@ def main():
                                        'bfloat16 and accumulates in fp32, gradient all-reduce in bfloat16'),
                        'global_batch': world * args.batch, 'clip_len': L,
                        'parallelism': 'dp%d' % world,
-                       'launch': ('hipGraph replay (1 graph per step%s)' % ('' if (args.no_overlap or alt) else
+                       'launch': ('hipGraph replay (1 graph per step%s)' % ('' if (args.no_overlap or alt or
+                                                                            g.front_is_persistent(args.batch, dev)) else
                                   '; generator forward of the G iteration on a second stream beside the critic '
                                   'iteration') if graph is not None else
                                   'hipGraph replay (6 graphs per step; D all-reduce overlaps the conv-stack backward, '
