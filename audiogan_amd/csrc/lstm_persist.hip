@@ -70,8 +70,21 @@ __device__ __forceinline__ bool ps_wait_flags(unsigned* hdr, const unsigned* fla
   }
 }
 
-template <int RT, bool RB>      // 32-clip row tiles per workgroup; RB: operands rounded to bf16 (AG_PREC_BF16)
+typedef short ps_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned ps_u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ ps_bf16x8 ps_pack8(u32x4 lo, u32x4 hi) {      // 8 floats (bit patterns) -> 8 bf16, RNE
+  ps_u32x4 r = {ag_pack_bf16(__uint_as_float(lo[0]), __uint_as_float(lo[1])), ag_pack_bf16(__uint_as_float(lo[2]), __uint_as_float(lo[3])),
+                ag_pack_bf16(__uint_as_float(hi[0]), __uint_as_float(hi[1])), ag_pack_bf16(__uint_as_float(hi[2]), __uint_as_float(hi[3]))};
+  return __builtin_bit_cast(ps_bf16x8, r);
+}
+
+// PM (precision mode of the recurrent product): 0 = fp32 operands on the fp32 MFMA; 1 = AG_PREC_BF16 with operands
+// rounded in registers in front of the fp32 MFMA (shapes whose K slices are not multiples of 16); 2 = AG_PREC_BF16 on
+// v_mfma_f32_32x32x16_bf16: W_hh slice in LDS as bf16 (8 k per 16-byte piece), h rows packed on load.
+template <int RT, int PM>      // 32-clip row tiles per workgroup
 __global__ __launch_bounds__(512) void lstm_persist_fwd_kernel(const PersistFwdP p) {
+  constexpr bool RB = PM == 1;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NKS = 8 / RT;                 // K slices (waves per row tile)
   constexpr int ROWS = 32 * RT;
@@ -87,7 +100,16 @@ __global__ __launch_bounds__(512) void lstm_persist_fwd_kernel(const PersistFwdP
   const int u0 = ut * 8, row0 = bt * ROWS;
 
   // ---- W_hh slice -> LDS, once: column j = gate (j>>3), unit u0 + (j&7);  element (q, hslot, j, e) = W[row(j)][8q+4hslot+e]
-  {
+  if (PM == 2) {      // bf16 image: piece (q, j) = W[row(j)][8q .. 8q+7] as 8 bf16
+    const int k8n = H >> 3;
+    for (int idx = tid; idx < 32 * k8n; idx += 512) {
+      const int j = idx / k8n, q = idx - j * k8n;
+      const float* src = D.whh + (int64_t)((j >> 3) * H + u0 + (j & 7)) * H + 8 * q;
+      const f32x4 a = *reinterpret_cast<const f32x4*>(src), b = *reinterpret_cast<const f32x4*>(src + 4);
+      ps_u32x4 r = {ag_pack_bf16(a[0], a[1]), ag_pack_bf16(a[2], a[3]), ag_pack_bf16(b[0], b[1]), ag_pack_bf16(b[2], b[3])};
+      *reinterpret_cast<ps_u32x4*>(wl + ((size_t)q * 32 + j) * 4) = r;
+    }
+  } else {
     const int k4n = H >> 2;
     for (int idx = tid; idx < 32 * k4n; idx += 512) {
       const int j = idx / k4n, k4 = idx - j * k4n;
@@ -141,6 +163,28 @@ __global__ __launch_bounds__(512) void lstm_persist_fwd_kernel(const PersistFwdP
       // byte offset of (q, row, 4*hh) in the exchange buffer
       const unsigned abase = (unsigned)((((int64_t)(par * ngroups + grp) * xg) + (int64_t)(rt * 32 + l31) * 8 + 4 * hh) * 4);
       const float* wrow = wl + ((size_t)hh * 32 + l31) * 4;
+      if (PM == 2) {
+        // one MFMA per 16 k: lane half hh takes units 8*(2Q+hh) .. +7 of its row = one 32-byte row of tile 2Q+hh
+        const unsigned ab2 = (unsigned)((((int64_t)(par * ngroups + grp) * xg) + (int64_t)(rt * 32 + l31) * 8) * 4);
+        const float* w2 = wl + (size_t)l31 * 4;
+        for (int qb = 0; qb < QW; qb += 16) {
+          u32x4 a0[8], a1[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const int q = q0w + min(qb + 2 * i, QW - 2) + hh;
+            a0[i] = __builtin_amdgcn_raw_buffer_load_b128(xr, ab2 + (unsigned)(q * ROWS * 32), 0, 16);
+            a1[i] = __builtin_amdgcn_raw_buffer_load_b128(xr, ab2 + (unsigned)(q * ROWS * 32) + 16u, 0, 16);
+          }
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            if (qb + 2 * i < QW) {
+              const int q = q0w + qb + 2 * i + hh;
+              const ps_bf16x8 b = *reinterpret_cast<const ps_bf16x8*>(w2 + (size_t)q * 128);
+              acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ps_pack8(a0[i], a1[i]), b, acc, 0, 0, 0);
+            }
+          }
+        }
+      } else
       for (int qb = 0; qb < QW; qb += 8) {
         u32x4 a[8];
 #pragma unroll
@@ -274,8 +318,11 @@ extern "C" int ag_lstm_seq_fwd_persist(float* const* pre, const float* const* wh
   p.rb = ag_precision() == AG_PREC_BF16;
   const size_t lds = ((size_t)32 * H + 8 * 1024) * sizeof(float);
   const int grid = ndir * nbt * p.ntile;
-  void (*kern)(const PersistFwdP) = rt == 1 ? (p.rb ? lstm_persist_fwd_kernel<1, true> : lstm_persist_fwd_kernel<1, false>)
-                                            : (p.rb ? lstm_persist_fwd_kernel<2, true> : lstm_persist_fwd_kernel<2, false>);
+  // bf16 mode: the bf16 MFMA needs 16-k steps inside a wave's K slice (H/8 unit tiles over 8/rt waves, 2 tiles a step)
+  const int pm = !p.rb ? 0 : ((p.ntile / (8 / rt)) % 2 == 0 ? 2 : 1);
+  void (*kern)(const PersistFwdP) =
+      rt == 1 ? (pm == 0 ? lstm_persist_fwd_kernel<1, 0> : pm == 1 ? lstm_persist_fwd_kernel<1, 1> : lstm_persist_fwd_kernel<1, 2>)
+              : (pm == 0 ? lstm_persist_fwd_kernel<2, 0> : pm == 1 ? lstm_persist_fwd_kernel<2, 1> : lstm_persist_fwd_kernel<2, 2>);
   (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, p);
   AG_CHECK_LAUNCH("ag_lstm_seq_fwd_persist");
@@ -318,8 +365,12 @@ struct PersistBwdP {
   int rb;               // AG_PREC_BF16: both operands of the recurrent product rounded to bf16
 };
 
-template <int NU, bool RB>       // 16-k units per wave: 4H = 8 waves * NU * 16; RB: operands rounded to bf16
+typedef short ps_bf16x8b __attribute__((ext_vector_type(8)));
+
+// PM: 0 = fp32; 2 = AG_PREC_BF16 on v_mfma_f32_16x16x32_bf16 (the W_hh panel in registers as bf16: half the VGPRs)
+template <int NU, int PM>       // 16-k units per wave: 4H = 8 waves * NU * 16
 __global__ __launch_bounds__(512) void lstm_persist_bwd_kernel(const PersistBwdP p) {
+  constexpr bool RB = false;
   __shared__ float red[8 * 512];
   const int H = p.H, B = p.B, T = p.T, ntile = p.ntile;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -332,14 +383,31 @@ __global__ __launch_bounds__(512) void lstm_persist_bwd_kernel(const PersistBwdP
   const int64_t BG = (int64_t)B * 4 * H, BH = (int64_t)B * H;
 
   // ---- resident weight panel: wreg[u][e][c] = W_hh[(wid*NU + u)*16 + 4g + e][n0 + 16c + li]
-  float wreg[NU][4][2];
+  constexpr int NW = PM == 2 ? 1 : NU;        // (the fp32 panel is not allocated in bf16 mode)
+  float wreg[NW][4][2];
+  if (PM != 2) {
 #pragma unroll
-  for (int u = 0; u < NU; ++u)
+    for (int u = 0; u < NW; ++u)
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
+      for (int e = 0; e < 4; ++e)
 #pragma unroll
-      for (int c = 0; c < 2; ++c)
-        wreg[u][e][c] = ag_rbf_if(D.whh[(int64_t)((wid * NU + u) * 16 + 4 * g + e) * H + n0 + 16 * c + li], RB);
+        for (int c = 0; c < 2; ++c)
+          wreg[u][e][c] = ag_rbf_if(D.whh[(int64_t)((wid * NU + u) * 16 + 4 * g + e) * H + n0 + 16 * c + li], RB);
+  }
+  // bf16 panel: 32-k steps; wbf[U][c] = W_hh[(wid*NU/2 + U)*32 + 8g + 0..7][n0 + 16c + li]
+  constexpr int NU2 = PM == 2 ? NU / 2 : 1;
+  ps_bf16x8b wbf[NU2][2];
+  if (PM == 2) {
+#pragma unroll
+    for (int U = 0; U < NU2; ++U)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const float* src = D.whh + (int64_t)((wid * NU2 + U) * 32 + 8 * g) * H + n0 + 16 * c + li;
+        ps_u32x4 r = {ag_pack_bf16(src[0], src[H]), ag_pack_bf16(src[2 * (int64_t)H], src[3 * (int64_t)H]),
+                      ag_pack_bf16(src[4 * (int64_t)H], src[5 * (int64_t)H]), ag_pack_bf16(src[6 * (int64_t)H], src[7 * (int64_t)H])};
+        wbf[U][c] = __builtin_bit_cast(ps_bf16x8b, r);
+      }
+  }
 
   unsigned* flags = p.hdr + PS_FLAG_OFF + grp * ntile;
   // epilogue role: thread <-> (clip row, unit)
@@ -369,9 +437,25 @@ __global__ __launch_bounds__(512) void lstm_persist_bwd_kernel(const PersistBwdP
       __syncthreads();
       const int tn = dir == 0 ? k + 1 : T - 2 - k;
       __amdgpu_buffer_rsrc_t ar = __builtin_amdgcn_make_buffer_rsrc(D.dgates + (int64_t)tn * BG, 0, (int)(BG * 4), 0x00020000);
+      if (PM == 2) {
+        // lane (clip li, k slot g) takes k = 32U + 8g .. +7 of its dgates row (32 contiguous bytes)
+        const unsigned aoff2 = (unsigned)(((int64_t)arow * 4 * H + (wid * NU2) * 32 + 8 * g) * 4);
+        u32x4 a0[NU2], a1[NU2];
+#pragma unroll
+        for (int U = 0; U < NU2; ++U) {
+          a0[U] = __builtin_amdgcn_raw_buffer_load_b128(ar, aoff2 + (unsigned)(U * 128), 0, 16);
+          a1[U] = __builtin_amdgcn_raw_buffer_load_b128(ar, aoff2 + (unsigned)(U * 128) + 16u, 0, 16);
+        }
+#pragma unroll
+        for (int U = 0; U < NU2; ++U) {
+          const ps_bf16x8b av = __builtin_bit_cast(ps_bf16x8b, ps_pack8(a0[U], a1[U]));
+#pragma unroll
+          for (int c = 0; c < 2; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, wbf[U][c], acc[c], 0, 0, 0);
+        }
+      }
       constexpr int UB = NU < 8 ? NU : 8;
 #pragma unroll
-      for (int ub = 0; ub < NU; ub += UB) {
+      for (int ub = 0; ub < (PM == 2 ? 0 : NU); ub += UB) {
         u32x4 a[UB];
 #pragma unroll
         for (int i = 0; i < UB; ++i) a[i] = __builtin_amdgcn_raw_buffer_load_b128(ar, aoff + (unsigned)((ub + i) * 64), 0, 16);
@@ -384,7 +468,7 @@ __global__ __launch_bounds__(512) void lstm_persist_bwd_kernel(const PersistBwdP
           for (int e = 0; e < 4; ++e)
 #pragma unroll
             for (int c = 0; c < 2; ++c)
-              acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], wreg[ub + i][e][c], acc[c], 0, 0, 0);
+              acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], wreg[PM == 2 ? 0 : ub + i][e][c], acc[c], 0, 0, 0);
         }
       }
     }
@@ -470,10 +554,10 @@ extern "C" int ag_lstm_seq_bwd_persist(const float* const* gates, const float* c
   const int grid = ndir * p.nbt * p.ntile;
   void (*kern)(const PersistBwdP);
   switch (H) {
-    case 512: kern = p.rb ? lstm_persist_bwd_kernel<16, true> : lstm_persist_bwd_kernel<16, false>; break;
-    case 256: kern = p.rb ? lstm_persist_bwd_kernel<8, true> : lstm_persist_bwd_kernel<8, false>; break;
-    case 128: kern = p.rb ? lstm_persist_bwd_kernel<4, true> : lstm_persist_bwd_kernel<4, false>; break;
-    default:  kern = p.rb ? lstm_persist_bwd_kernel<2, true> : lstm_persist_bwd_kernel<2, false>; break;
+    case 512: kern = p.rb ? lstm_persist_bwd_kernel<16, 2> : lstm_persist_bwd_kernel<16, 0>; break;
+    case 256: kern = p.rb ? lstm_persist_bwd_kernel<8, 2> : lstm_persist_bwd_kernel<8, 0>; break;
+    case 128: kern = p.rb ? lstm_persist_bwd_kernel<4, 2> : lstm_persist_bwd_kernel<4, 0>; break;
+    default:  kern = p.rb ? lstm_persist_bwd_kernel<2, 2> : lstm_persist_bwd_kernel<2, 0>; break;
   }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), 0, st, p);
   AG_CHECK_LAUNCH("ag_lstm_seq_bwd_persist");
@@ -512,7 +596,9 @@ struct FrontFwdP {
   int T, B, ldwx, nrt, rb;
 };
 
-template <int S, int FS>
+// PM: 0 = as stored / operands rounded in registers when p.rb (fp32 MFMA); 2 = AG_PREC_BF16 on the bf16 MFMAs (panels
+// in registers as bf16: 8 k per 4 VGPRs)
+template <int S, int FS, int PM>
 __global__ __launch_bounds__(512) void gfront_persist_fwd_kernel(const FrontFwdP p) {
   constexpr int NUT = S / 8;                 // unit tiles = workgroups per row tile
   constexpr int QH = S / 64, QX = FS / 64;   // 8-k groups of the h / x panel per wave
@@ -527,8 +613,26 @@ __global__ __launch_bounds__(512) void gfront_persist_fwd_kernel(const FrontFwdP
   const int u0 = ut * 8, row0 = rt * 32;
 
   // ---- resident panels (B operands).  Gate column j = gate (j>>3), unit u0 + (j&7).
-  float wh[QH][4], wxr[QX][4];
-  {
+  constexpr int QHf = PM == 2 ? 1 : QH, QXf = PM == 2 ? 1 : QX, QH2 = PM == 2 ? QH / 2 : 1, QX2 = PM == 2 ? QX / 2 : 1;
+  float wh[QHf][4], wxr[QXf][4];
+  ps_bf16x8 whb[QH2], wxb[QX2];
+  if (PM == 2) {
+    const int wrow = (l31 >> 3) * S + u0 + (l31 & 7);
+#pragma unroll
+    for (int Q = 0; Q < QH2; ++Q) {
+      const float* src = p.whh + (int64_t)wrow * S + (wid * QH + 2 * Q + hh) * 8;
+      const f32x4 a = *reinterpret_cast<const f32x4*>(src), b = *reinterpret_cast<const f32x4*>(src + 4);
+      ps_u32x4 r = {ag_pack_bf16(a[0], a[1]), ag_pack_bf16(a[2], a[3]), ag_pack_bf16(b[0], b[1]), ag_pack_bf16(b[2], b[3])};
+      whb[Q] = __builtin_bit_cast(ps_bf16x8, r);
+    }
+#pragma unroll
+    for (int Q = 0; Q < QX2; ++Q) {
+      const float* src = p.wx + (int64_t)wrow * p.ldwx + (wid * QX + 2 * Q + hh) * 8;
+      const f32x4 a = *reinterpret_cast<const f32x4*>(src), b = *reinterpret_cast<const f32x4*>(src + 4);
+      ps_u32x4 r = {ag_pack_bf16(a[0], a[1]), ag_pack_bf16(a[2], a[3]), ag_pack_bf16(b[0], b[1]), ag_pack_bf16(b[2], b[3])};
+      wxb[Q] = __builtin_bit_cast(ps_bf16x8, r);
+    }
+  } else {
     const int wrow = (l31 >> 3) * S + u0 + (l31 & 7);
 #pragma unroll
     for (int q = 0; q < QH; ++q) {
@@ -545,13 +649,28 @@ __global__ __launch_bounds__(512) void gfront_persist_fwd_kernel(const FrontFwdP
   }
   const bool bwg = ut < NB;                  // this workgroup also owns a projection tile
   const int bsub = ut & 1, bcol0 = (ut >> 1) * 16;
-  float wpr[UP][4];
+  constexpr int UPf = PM == 2 ? 1 : UP, UP2 = PM == 2 ? UP / 2 : 1;
+  float wpr[UPf][4];
+  ps_bf16x8b wpb[UP2];
+  if (PM == 2) {
 #pragma unroll
-  for (int u = 0; u < UP; ++u) {
-    const f32x4 v = bwg ? ag_rbf4_if(*reinterpret_cast<const f32x4*>(p.wp + (int64_t)(bcol0 + li) * S + (wid * UP + u) * 16 + 4 * g), p.rb)
-                        : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int U = 0; U < UP2; ++U) {
+      ps_u32x4 r = {0u, 0u, 0u, 0u};
+      if (bwg) {
+        const float* src = p.wp + (int64_t)(bcol0 + li) * S + (wid * UP2 + U) * 32 + 8 * g;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(src), b = *reinterpret_cast<const f32x4*>(src + 4);
+        r = ps_u32x4{ag_pack_bf16(a[0], a[1]), ag_pack_bf16(a[2], a[3]), ag_pack_bf16(b[0], b[1]), ag_pack_bf16(b[2], b[3])};
+      }
+      wpb[U] = __builtin_bit_cast(ps_bf16x8b, r);
+    }
+  } else {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) wpr[u][e] = v[e];
+    for (int u = 0; u < UPf; ++u) {
+      const f32x4 v = bwg ? ag_rbf4_if(*reinterpret_cast<const f32x4*>(p.wp + (int64_t)(bcol0 + li) * S + (wid * UP + u) * 16 + 4 * g), p.rb)
+                          : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) wpr[u][e] = v[e];
+    }
   }
 
   unsigned* flag_h = p.hdr + PS_FLAG_OFF + rt * NUT;
@@ -586,7 +705,18 @@ __global__ __launch_bounds__(512) void gfront_persist_fwd_kernel(const FrontFwdP
       // ---- h part (its flags were already waited for by the projection phase of frame t-1 on projection workgroups)
       if (wid == 0 && alive) alive = ps_wait_flags(p.hdr, flag_h, NUT, (unsigned)t, lane);
       __syncthreads();
-      {
+      if (PM == 2) {
+        const unsigned ab = (unsigned)(((int64_t)(par * p.nrt + rt) * hgs + (int64_t)l31 * 8) * 4);
+        u32x4 a0[QH2], a1[QH2];
+#pragma unroll
+        for (int Q = 0; Q < QH2; ++Q) {
+          const unsigned o = ab + (unsigned)((wid * QH + 2 * Q + hh) * 32 * 32);
+          a0[Q] = __builtin_amdgcn_raw_buffer_load_b128(hr, o, 0, 16);
+          a1[Q] = __builtin_amdgcn_raw_buffer_load_b128(hr, o + 16u, 0, 16);
+        }
+#pragma unroll
+        for (int Q = 0; Q < QH2; ++Q) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ps_pack8(a0[Q], a1[Q]), whb[Q], acc, 0, 0, 0);
+      } else {
         const unsigned ab = (unsigned)(((int64_t)(par * p.nrt + rt) * hgs + (int64_t)l31 * 8 + 4 * hh) * 4);
         u32x4 a[QH];
 #pragma unroll
@@ -600,12 +730,23 @@ __global__ __launch_bounds__(512) void gfront_persist_fwd_kernel(const FrontFwdP
 #pragma unroll
         for (int q = 0; q < QH; ++q)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a[q][e]), wh[q][e], acc, 0, 0, 0);
+          for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a[q][e]), wh[PM == 2 ? 0 : q][e], acc, 0, 0, 0);
       }
       // ---- x part
       if (wid == 0 && alive) alive = ps_wait_flags(p.hdr, flag_x, NB, (unsigned)t, lane);
       __syncthreads();
-      {
+      if (PM == 2) {
+        const unsigned ab = (unsigned)(((int64_t)(par * p.nrt + rt) * xgs + (int64_t)l31 * 8) * 4);
+        u32x4 a0[QX2], a1[QX2];
+#pragma unroll
+        for (int Q = 0; Q < QX2; ++Q) {
+          const unsigned o = ab + (unsigned)((wid * QX + 2 * Q + hh) * 32 * 32);
+          a0[Q] = __builtin_amdgcn_raw_buffer_load_b128(xr, o, 0, 16);
+          a1[Q] = __builtin_amdgcn_raw_buffer_load_b128(xr, o + 16u, 0, 16);
+        }
+#pragma unroll
+        for (int Q = 0; Q < QX2; ++Q) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ps_pack8(a0[Q], a1[Q]), wxb[Q], acc, 0, 0, 0);
+      } else {
         const unsigned ab = (unsigned)(((int64_t)(par * p.nrt + rt) * xgs + (int64_t)l31 * 8 + 4 * hh) * 4);
         u32x4 a[QX];
 #pragma unroll
@@ -619,7 +760,7 @@ __global__ __launch_bounds__(512) void gfront_persist_fwd_kernel(const FrontFwdP
 #pragma unroll
         for (int q = 0; q < QX; ++q)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a[q][e]), wxr[q][e], acc, 0, 0, 0);
+          for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a[q][e]), wxr[PM == 2 ? 0 : q][e], acc, 0, 0, 0);
       }
     }
 #pragma unroll
@@ -660,7 +801,20 @@ __global__ __launch_bounds__(512) void gfront_persist_fwd_kernel(const FrontFwdP
       if (wid == 0 && alive) alive = ps_wait_flags(p.hdr, flag_h, NUT, (unsigned)(t + 1), lane);
       __syncthreads();
       f32x4 pacc = {0.f, 0.f, 0.f, 0.f};
-      {
+      if (PM == 2) {
+        // lane (clip li, k slot g) takes k = 32U + 8g .. +7 = the whole row of unit tile 4U + g
+        const unsigned ab = (unsigned)(((int64_t)((t & 1) * p.nrt + rt) * hgs + (int64_t)(16 * bsub + li) * 8) * 4);
+        u32x4 a0[UP2], a1[UP2];
+#pragma unroll
+        for (int U = 0; U < UP2; ++U) {
+          const unsigned o = ab + (unsigned)((4 * (wid * UP2 + U) + g) * 32 * 32);
+          a0[U] = __builtin_amdgcn_raw_buffer_load_b128(hr, o, 0, 16);
+          a1[U] = __builtin_amdgcn_raw_buffer_load_b128(hr, o + 16u, 0, 16);
+        }
+#pragma unroll
+        for (int U = 0; U < UP2; ++U)
+          pacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(ps_bf16x8b, ps_pack8(a0[U], a1[U])), wpb[U], pacc, 0, 0, 0);
+      } else {
         // A = h_t rows of the 16-clip subtile: lane (clip li, k slot g) takes k = 16u + 4g .. +3 = unit tile 2u + (g>>1), half g&1
         const unsigned ab = (unsigned)(((int64_t)((t & 1) * p.nrt + rt) * hgs + (int64_t)(16 * bsub + li) * 8 + 4 * (g & 1)) * 4);
         u32x4 a[UP];
@@ -676,7 +830,7 @@ __global__ __launch_bounds__(512) void gfront_persist_fwd_kernel(const FrontFwdP
 #pragma unroll
         for (int u = 0; u < UP; ++u)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) pacc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[u][e]), wpr[u][e], pacc, 0, 0, 0);
+          for (int e = 0; e < 4; ++e) pacc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[u][e]), wpr[PM == 2 ? 0 : u][e], pacc, 0, 0, 0);
       }
       // 16x16 tile: col = lane & 15, row = 4 * (lane >> 4) + e   (red is free again: the gate sums were consumed above)
 #pragma unroll
@@ -741,8 +895,12 @@ extern "C" int ag_gfront_fwd_persist(float* gates, const float* w_x, int ldwx, c
   p.xx = p.hx + (int64_t)2 * p.nrt * 32 * S;
   p.T = T; p.B = B; p.ldwx = ldwx; p.rb = ag_precision() == AG_PREC_BF16;
   const int grid = p.nrt * (S / 8);
-  if (S == 1024) hipLaunchKernelGGL((gfront_persist_fwd_kernel<1024, 256>), dim3(grid), dim3(512), 0, st, p);
-  else hipLaunchKernelGGL((gfront_persist_fwd_kernel<128, 64>), dim3(grid), dim3(512), 0, st, p);
+  if (S == 1024) {
+    if (p.rb) hipLaunchKernelGGL((gfront_persist_fwd_kernel<1024, 256, 2>), dim3(grid), dim3(512), 0, st, p);
+    else hipLaunchKernelGGL((gfront_persist_fwd_kernel<1024, 256, 0>), dim3(grid), dim3(512), 0, st, p);
+  } else {
+    hipLaunchKernelGGL((gfront_persist_fwd_kernel<128, 64, 0>), dim3(grid), dim3(512), 0, st, p);   // (FS/8 per wave is odd)
+  }
   AG_CHECK_LAUNCH("ag_gfront_fwd_persist");
   return AG_OK;
 }

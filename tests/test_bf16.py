@@ -8,9 +8,9 @@ DECLARED TOLERANCE:
   * networks / train step vs the bf16-rounded oracle: every activation / logit / waveform tensor within 1e-2 of its
     largest magnitude elementwise and 3e-3 in relative L2 norm (an intermediate value that differs in the last fp32
     bits can round to the other bf16 neighbour, a 2^-8 relative change of that one element); parameter gradients
-    (sums over batch and time in which such flips do not cancel; the weight-norm gain gradients are themselves
-    cancelling projections of them, two orders of magnitude smaller, and get 5e-2) 2e-2 elementwise and 2e-2 in
-    relative L2 norm;
+    (sums over batch and time in which such flips do not cancel) 2e-2 in relative L2 norm and 5e-2 of the largest
+    magnitude elementwise (the worst of up to a million elements); the weight-norm gain gradients, cancelling projections
+    two orders of magnitude smaller, 5e-2 in both;
   * vs the fp32 oracle: 3e-2 in relative L2 norm (what bf16 operands cost; informative)."""
 import os
 
@@ -166,8 +166,8 @@ def test_networks_bf16_vs_rounded_oracle(K, bf16):
             if k.split('.')[-1].startswith('bias') and k.endswith('_v'):
                 continue
             r = rp[k].grad if rp[k].grad is not None else torch.zeros_like(rp[k])
-            tol = 5e-2 if k.endswith('_g') else 2e-2
-            close_bf16(q.grad if q.grad is not None else torch.zeros_like(q), r, k, elem=tol, l2=tol)
+            close_bf16(q.grad if q.grad is not None else torch.zeros_like(q), r, k, elem=5e-2,
+                       l2=5e-2 if k.endswith('_g') else 2e-2)
     assert rel_l2(x, x32) <= 3e-2 and rel_l2(l, l32) <= 3e-2
     assert rel_l2(x, x32) > 1e-5          # (and the mode is really on)
 
@@ -193,3 +193,52 @@ def test_train_step_bf16_vs_rounded_oracle(K, bf16):
     l2, f, _ = train.g_step(g, d, opt_g, cu(c), cu(z), cu(nf), 0.1, check=True)
     close_bf16(cd, cdo, 'D(real)'); close_bf16(cg, cgo, 'D(fake)'); close_bf16(f, fo, 'fake')
     np.testing.assert_allclose([float(l), float(l2)], [float(lo), float(lo2)], rtol=2e-3)
+
+
+@pytest.mark.parametrize('B', [40, 70])
+def test_bf16_mfma_persistent_recurrent_kernels(K, bf16, B):
+    """shapes that take the bf16-MFMA forms of the persistent launches (H = 512 per direction: v_mfma_f32_32x32x16_bf16
+    forward with the W_hh slice in LDS as bf16, v_mfma_f32_16x16x32_bf16 backward; S = 1024 / frame 256 generator
+    front) vs the bf16-rounded oracle: critic logits, generated frames and all gradients"""
+    import audiogan_amd as A
+    dcfg = dict(state_size=1024, embed_size=8, num_layers=1, cnn_struct=[[7, 2, 8], [7, 2, 16]])
+    gcfg = dict(frame_size=256, embed_size=8, noise_size=8, state_size=1024, num_layers=1, struct=[[9, 4, 8, 4]])
+    torch.manual_seed(41)
+    do, go = O.Discriminator(**dcfg), O.Generator(**gcfg)
+    d, g = A.Discriminator(**dcfg), A.Generator(**gcfg)
+    d.load_state_dict(do.state_dict()); g.load_state_dict(go.state_dict())
+    d.cuda(); g.cuda()
+    gen = torch.Generator().manual_seed(42)
+    L = 64
+    x, c = torch.randn(B, L, generator=gen), torch.randn(B, 8, generator=gen)
+    lens = torch.randint(20, L + 1, (B,), generator=gen)
+    lens[0] = L
+    wl = torch.randn(B, L // 4, generator=gen)
+    with O.bf16_mode():
+        lo = do(x, lens, c)[0]
+        (lo * wl).sum().backward()
+    l = d(x.cuda(), lens.cuda(), c.cuda())[0]
+    (l * wl.cuda()).sum().backward()
+    assert K.lstm_persist_status() == 0
+    close_bf16(l, lo, 'logits')
+    rp = dict(do.named_parameters())
+    for k, q in d.named_parameters():
+        if k.split('.')[-1].startswith('bias') and k.endswith('_v'):
+            continue
+        close_bf16(q.grad, rp[k].grad, k, elem=5e-2, l2=5e-2 if k.endswith('_g') else 2e-2)
+    if B <= 64:
+        T = 3
+        z = torch.randn(B, T, 8, generator=gen)
+        wx = torch.randn(B, T * 256, generator=gen)
+        with O.bf16_mode():
+            xo = go(z=z, c=c, stop=torch.zeros(B, T, dtype=torch.long))[0]
+            (xo * wx).sum().backward()
+        xg = g(z=z.cuda(), c=c.cuda(), stop='never')[0]
+        (xg * wx.cuda()).sum().backward()
+        assert K.lstm_persist_status() == 0
+        close_bf16(xg, xo, 'waveform')
+        rp = dict(go.named_parameters())
+        for k, q in g.named_parameters():
+            if (k.split('.')[-1].startswith('bias') and k.endswith('_v')) or rp[k].grad is None:
+                continue
+            close_bf16(q.grad, rp[k].grad, k, elem=5e-2, l2=5e-2 if k.endswith('_g') else 2e-2)
