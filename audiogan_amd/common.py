@@ -8,6 +8,24 @@ from . import kernels as K
 PARAM_EPOCH = [0]
 
 
+# Weight materialisations are cached on the HOST (a key of parameter versions).  Under hipGraph capture that decision is
+# frozen into the graph, so a graph captured while the cache happened to be warm would never re-materialise its weights
+# on replay.  ``new_capture()`` (call it right before every ``torch.cuda.graph`` capture) makes the first use of each
+# weight group inside that capture materialise unconditionally.
+CAPTURE_EPOCH = [0]
+
+
+def new_capture():
+    CAPTURE_EPOCH[0] += 1
+    return CAPTURE_EPOCH[0]
+
+
+def capture_tag(dev):
+    if torch.device(dev).type == 'cuda' and torch.cuda.is_current_stream_capturing():
+        return CAPTURE_EPOCH[0]
+    return None
+
+
 def param_epoch(p):
     return getattr(p, '_ag_epoch', 0)
 
@@ -100,8 +118,8 @@ class WNGroup(object):
         dev = self.items[0]['v'].device
         if self._bufs is None or self._bufs[0].w.device != dev:
             self._alloc(dev)
-        key = tuple((it['v'].data_ptr(), it['v']._version, param_epoch(it['v']), it['g'].data_ptr(),
-                     it['g']._version, param_epoch(it['g'])) for it in self.items)
+        key = (capture_tag(dev),) + tuple((it['v'].data_ptr(), it['v']._version, param_epoch(it['v']), it['g'].data_ptr(),
+                                           it['g']._version, param_epoch(it['g'])) for it in self.items)
         if key != self._key:
             ents = []
             for it, p in zip(self.items, self._bufs):

@@ -44,7 +44,8 @@ class PlainGroup(object):
                 self._bufs.append(Prepared(w=None, wpa=torch.zeros(K.wpa_numel(d0, d1, kk), device=dev),
                                            wpb=torch.zeros(K.wpb_numel(d0, d1, kk, it['stride']), device=dev)))
             self._key = None
-        key = tuple((it['w'].data_ptr(), it['w']._version, param_epoch(it['w'])) for it in self.items)
+        from .common import capture_tag
+        key = (capture_tag(dev),) + tuple((it['w'].data_ptr(), it['w']._version, param_epoch(it['w'])) for it in self.items)
         if key != self._key:
             for it, p in zip(self.items, self._bufs):
                 K.prep_conv_weight(it['w'].data.contiguous(), p.wpa, p.wpb, it['stride'])
@@ -82,7 +83,7 @@ class ConvChainFn(torch.autograd.Function):
             conv_fwd(sp, prep[i], a, y, bias=params[2 * i + 1].data, act=act)
             acts.append(y)
             a = y
-        ctx.chain, ctx.key = chain, chain.group._key
+        ctx.chain, ctx.key = chain, chain.group._key[1:]
         ctx.save_for_backward(x, *acts)
         return a
 
@@ -91,7 +92,7 @@ class ConvChainFn(torch.autograd.Function):
         chain = ctx.chain
         x, acts = ctx.saved_tensors[0], ctx.saved_tensors[1:]
         prep = chain.group.prepare()
-        assert chain.group._key == ctx.key, 'parameters changed between forward and backward'
+        assert chain.group._key[1:] == ctx.key, 'parameters changed between forward and backward'
         wg = any(ctx.needs_input_grad[2:])
         d = dy.contiguous().clone()
         grads = []
@@ -241,7 +242,7 @@ class CriticGPFn(torch.autograd.Function):
         g0 = v.view(B, -1)
         nrm = g0.norm(dim=1)
         pen = (nrm - 1) ** 2
-        ctx.chain, ctx.key = chain, chain.group._key
+        ctx.chain, ctx.key = chain, chain.group._key[1:]
         ctx.save_for_backward(x, hw.data, g0, nrm, *(acts + ms))
         ctx.nl = len(chain.layers)
         return d.view(B), pen
@@ -250,7 +251,7 @@ class CriticGPFn(torch.autograd.Function):
     def backward(ctx, dd, dpen):
         chain, nl = ctx.chain, ctx.nl
         prep = chain.group.prepare()
-        assert chain.group._key == ctx.key, 'parameters changed between forward and backward'
+        assert chain.group._key[1:] == ctx.key, 'parameters changed between forward and backward'
         sv = ctx.saved_tensors
         x, hw, g0, nrm = sv[0], sv[1], sv[2], sv[3]
         acts, ms = sv[4:4 + nl], sv[4 + nl:4 + 2 * nl]

@@ -106,7 +106,7 @@ class GTrunkFn(torch.autograd.Function):
         y = torch.empty(B, 1, L, device=x0.device)
         conv_fwd(trunk.final, fw, slab, y, bias=fb.w, act=ACT_NONE)
         ctx.trunk = trunk
-        ctx.key = trunk.group._key
+        ctx.key = trunk.group._key[1:]
         ctx.save_for_backward(slab, *hids)
         return y.view(B, L)
 
@@ -115,7 +115,7 @@ class GTrunkFn(torch.autograd.Function):
         trunk = ctx.trunk
         slab, hids = ctx.saved_tensors[0], ctx.saved_tensors[1:]
         prep = trunk.group.prepare()
-        assert trunk.group._key == ctx.key, 'parameters changed between forward and backward'
+        assert trunk.group._key[1:] == ctx.key, 'parameters changed between forward and backward'
         B, ctot, L = slab.shape
         dy = dy.contiguous().view(B, 1, L)
         wg = any(ctx.needs_input_grad[2:])
@@ -174,7 +174,7 @@ class DConvStackFn(torch.autograd.Function):
             conv_fwd(sp, prep[2 * i], a, y, bias=prep[2 * i + 1].w, lens=lens_list[i], act=ACT_LEAKY)
             acts.append(y)
             a = y
-        ctx.stack, ctx.lens_list, ctx.key = stack, lens_list, stack.group._key
+        ctx.stack, ctx.lens_list, ctx.key = stack, lens_list, stack.group._key[1:]
         ctx.save_for_backward(x, *acts)
         return tuple(acts)
 
@@ -183,7 +183,7 @@ class DConvStackFn(torch.autograd.Function):
         stack = ctx.stack
         x, acts = ctx.saved_tensors[0], ctx.saved_tensors[1:]
         prep = stack.group.prepare()
-        assert stack.group._key == ctx.key, 'parameters changed between forward and backward'
+        assert stack.group._key[1:] == ctx.key, 'parameters changed between forward and backward'
         B, L = x.shape
         wg = any(ctx.needs_input_grad[3:])
         dws = _zeros_like_list([it['v'] for it in stack.group.items]) if wg else None
@@ -246,7 +246,7 @@ class DHeadFn(torch.autograd.Function):
         out = torch.empty(M, w1.size(0), device=a.device)
         K.gemm(hmid, w1, out, tb=True, bias=b1)
         saved.append(hmid)
-        ctx.head, ctx.key = head, head.group._key
+        ctx.head, ctx.key = head, head.group._key[1:]
         ctx.save_for_backward(*saved)
         return out
 
@@ -254,7 +254,7 @@ class DHeadFn(torch.autograd.Function):
     def backward(ctx, dout):
         head = ctx.head
         prep = head.group.prepare()
-        assert head.group._key == ctx.key, 'parameters changed between forward and backward'
+        assert head.group._key[1:] == ctx.key, 'parameters changed between forward and backward'
         saved = ctx.saved_tensors
         hmid = saved[-1]
         acts = saved[:-1]          # acts[0] = input rows, acts[i] = output of residual i

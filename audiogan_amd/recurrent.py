@@ -249,7 +249,7 @@ class GFrontFn(torch.autograd.Function):
             _small(hs[-1][t], pw, x[:, t * fs:(t + 1) * fs], tb=True, bias=pb, act=ACT_TANH)
         s = torch.empty(T * B, 1, device=dev)
         K.gemm(hs[-1].view(T * B, S), sw, s, tb=True, bias=sb)
-        ctx.front, ctx.key = front, front.group._key
+        ctx.front, ctx.key = front, front.group._key[1:]
         ctx.dims = (T, B, Fz)
         ctx.save_for_backward(zc, x, *(gates + hs + cs))
         return x, s.view(T, B).t()
@@ -319,7 +319,7 @@ class GFrontFn(torch.autograd.Function):
         fs, nl, S = front.fs, front.nl, front.ss
         T, B, Fz = ctx.dims
         prep = front.group.prepare()
-        assert front.group._key == ctx.key, 'parameters changed between forward and backward'
+        assert front.group._key[1:] == ctx.key, 'parameters changed between forward and backward'
         sv = ctx.saved_tensors
         zc, x = sv[0], sv[1]
         gates, hs, cs = sv[2:2 + nl], sv[2 + nl:2 + 2 * nl], sv[2 + 2 * nl:2 + 3 * nl]
@@ -416,7 +416,7 @@ class GRUFrontFn(torch.autograd.Function):
             _small(hs[t + 1], pw, x[:, t * fs:(t + 1) * fs], tb=True, bias=pb, act=ACT_TANH)
         s = torch.empty(T * B, 1, device=dev)
         K.gemm(hs[1:].view(T * B, S), sw, s, tb=True, bias=sb)
-        ctx.front, ctx.key, ctx.dims = front, front.group._key, (T, B, Fz)
+        ctx.front, ctx.key, ctx.dims = front, front.group._key[1:], (T, B, Fz)
         ctx.save_for_backward(zc, x, gi, gh, hs)
         return x, s.view(T, B).t()
 
@@ -426,7 +426,7 @@ class GRUFrontFn(torch.autograd.Function):
         fs, S = front.fs, front.ss
         T, B, Fz = ctx.dims
         prep = front.group.prepare()
-        assert front.group._key == ctx.key, 'parameters changed between forward and backward'
+        assert front.group._key[1:] == ctx.key, 'parameters changed between forward and backward'
         w_ih, w_hh, _, _, pw, _, sw, _ = [p.w for p in prep]
         wx = w_ih[:, :fs]
         zc, x, gi, gh, hs = ctx.saved_tensors

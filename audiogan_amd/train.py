@@ -291,3 +291,113 @@ def wgan_gp_step(g, critic, opt_g, opt_d, real, c, z, eps, lam=10.0, dgradclip=0
         loss_g.backward()
     opt_g.step(clip_norm=ggradclip, grad_scale=hook_g() if hook_g is not None else 1.0, check=check)
     return loss_d.detach(), loss_g.detach()
+
+
+# --------------------------------------------------------------------------------------
+# The canonical step as replayed hipGraphs (what bench.py times).  ~1000 launches per step would otherwise be paced by
+# the Python interpreter, not by the GPU.
+#   single     one graph for the whole G+D step (one GPU)
+#   phased     six graphs - critic forward + backward of heads / biLSTM | critic conv-stack backward | opt_d | generator
+#              forward + backward down to the front's frames | front backward | opt_g - with the gradient all-reduces
+#              (``ddp.GradBucket``) as ordinary stream operations between them; the first all-reduce of each network
+#              runs on RCCL's stream WHILE the next graph does the rest of that network's backward
+# --------------------------------------------------------------------------------------
+class GraphedStep(object):
+    def __init__(self, g, d, opt_g, opt_d, batch, phased=False, bucket_d=None, bucket_g=None, world=1, overlap=True,
+                 dgradclip=1.0, ggradclip=0.1):
+        """``batch``: dict(real, real_len, c, z, noise_real, noise_fake) of device tensors that stay where they are (a
+        replay re-reads them: refill them in place for new data).  Capturing records the step WITHOUT executing it: the
+        model and optimiser state are untouched, and every lazily created resource (optimiser state, persistent-kernel
+        workspace, gradient buckets) must exist already - run at least one eager ``gd_step`` with the same shapes first.
+        Raises whatever the capture raises; the caller may then fall back to ``gd_step``."""
+        from . import common, kernels as K
+        self.g, self.d, self.opt_g, self.opt_d, self.b = g, d, opt_g, opt_d, batch
+        self.phased, self.bd, self.bg = phased, bucket_d, bucket_g
+        self.losses, self.keep, self.gkeep = {}, {}, {}
+        self.graph = self.phases = None
+        b = batch
+        dev = b['real'].device
+        K.reserve_table_arena()
+        mark = K.capture_mark()
+
+        def capture(fn):
+            torch.cuda.synchronize()
+            gr = torch.cuda.CUDAGraph()
+            common.new_capture()      # every weight group materialises at its first use INSIDE this graph
+            # thread_local: other threads (e.g. the RCCL watchdog) may keep calling HIP while we capture
+            with torch.cuda.graph(gr, capture_error_mode='thread_local'):
+                fn()
+            return gr
+
+        try:
+            if not phased:
+                def whole():
+                    self.losses['d'], self.losses['g'] = gd_step(
+                        g, d, opt_g, opt_d, b['real'], b['real_len'], b['c'], b['z'], b['noise_real'], b['noise_fake'],
+                        dgradclip, ggradclip, overlap=overlap)
+                self.graph = capture(whole)
+            else:
+                scale = 1.0 / world
+                # (no second stream when the generator's frame loop is a persistent launch: one at a time per device)
+                side_ok = overlap and not g.front_is_persistent(b['z'].size(0), dev)
+                self.side_ok = side_ok
+                keep, gkeep = self.keep, self.gkeep
+
+                def critic_early():
+                    # the G forward of the generator iteration as a parallel branch of this graph: G's weights are
+                    # materialised on the main stream, then fork, run it beside the critic, join before the capture ends
+                    if side_ok:
+                        side = _SIDE.get(dev)
+                        if side is None:
+                            side = _SIDE[dev] = torch.cuda.Stream(device=dev)
+                        g.prepare_weights()
+                        side.wait_stream(torch.cuda.current_stream())
+                        with torch.cuda.stream(side):
+                            keep['pre'] = g(z=b['z'], c=b['c'], stop='never', cut=gkeep)
+                    else:
+                        keep['pre'] = None
+                    self.losses['d'] = d_backward_early(g, d, opt_d, b['real'], b['real_len'], b['c'], b['z'],
+                                                        b['noise_real'], b['noise_fake'], keep)
+                    if side_ok:
+                        torch.cuda.current_stream().wait_stream(_SIDE[dev])
+
+                def gen_early():
+                    self.losses['g'] = g_backward_early(g, d, opt_g, b['c'], b['z'], b['noise_fake'], gkeep,
+                                                        pre=keep.get('pre'))
+
+                g1a = capture(critic_early)
+                g1b = capture(lambda: d_backward_late(keep))
+                g2 = capture(lambda: opt_d.step(clip_norm=dgradclip, grad_scale=scale))
+                g3a = capture(gen_early)
+                g3b = capture(lambda: g_backward_late(gkeep))
+                g4 = capture(lambda: opt_g.step(clip_norm=ggradclip, grad_scale=scale))
+                self.phases = (g1a, g1b, g2, g3a, g3b, g4)
+            torch.cuda.synchronize()
+        except Exception:
+            K.drop_captured_tables(mark)      # their device copies were never executed
+            torch.cuda.synchronize()
+            raise
+
+    def step(self):
+        """one G+D step; returns (loss_d, loss_g) - device scalars overwritten by the next step"""
+        if self.graph is not None:
+            self.graph.replay()
+        else:
+            ph, bd, bg = self.phases, self.bd, self.bg
+            ph[0].replay()                                  # critic fwd + bwd of heads / biLSTM
+            if bd is not None:
+                bd.all_reduce(async_op=True, part='early')  # overlaps ...
+            ph[1].replay()                                  # ... the conv-stack backward
+            if bd is not None:
+                bd.wait()
+                bd.all_reduce(part='late')
+            ph[2].replay()                                  # opt_d
+            ph[3].replay()                                  # generator fwd + bwd down to the front's frames
+            if bg is not None:
+                bg.all_reduce(async_op=True, part='early')  # conv trunk's gradients; overlaps ...
+            ph[4].replay()                                  # ... the recurrent front's backward
+            if bg is not None:
+                bg.wait()
+                bg.all_reduce(part='late')
+            ph[5].replay()                                  # opt_g
+        return self.losses['d'], self.losses['g']

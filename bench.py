@@ -163,6 +163,28 @@ def cpu_baseline(batch, steps, opt_kind, threads=0, budget_s=110.0, warm=2, work
                                                          cores, opt_kind))
 
 
+class _AltGraph(object):
+    """the c4 / c5 step as one replayed hipGraph (same capture recipe as train.GraphedStep)"""
+
+    def __init__(self, train, g, d, opt_g, opt_d, batch):
+        from audiogan_amd import common, kernels as K
+        self.losses, self.phases = {}, None
+        K.reserve_table_arena()
+
+        def whole():
+            self.losses['d'], self.losses['g'] = one_step(train, g, d, opt_g, opt_d, batch)
+
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        common.new_capture()
+        with torch.cuda.graph(self.graph, capture_error_mode='thread_local'):
+            whole()
+
+    def step(self):
+        self.graph.replay()
+        return self.losses['d'], self.losses['g']
+
+
 class _StdoutToStderr(object):
     """RCCL prints a version banner on fd 1 when a communicator is created; the bench's stdout must stay
     ONE JSON line, so fd 1 points at fd 2 while the process group comes up"""
@@ -274,100 +296,29 @@ def main():
     # interpreter, not by the GPU.  One GPU: the whole G+D step is ONE graph.  N GPUs: five graphs
     # (critic fwd + head/biLSTM bwd | critic conv-stack bwd | opt_d | generator fwd+bwd | opt_g) with the RCCL
     # gradient all-reduces as ordinary stream operations between them.
-    graph = None
-    phases = None
+    gs = None
     capture_error = None
-    keep, gkeep, losses = {}, {}, {}
-
-    def capture(fn, warm=True):
-        if warm:
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                fn()
-            torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        gr = torch.cuda.CUDAGraph()
-        # thread_local: other threads (e.g. the RCCL watchdog) may keep calling HIP while we capture
-        with torch.cuda.graph(gr, capture_error_mode='thread_local'):
-            fn()
-        return gr
-
-    b_ = batch
+    losses = {}
     if not args.no_graph and not (alt and multi):
-        table_mark = K.capture_mark()
         try:
-            K.reserve_table_arena()
-            if not multi:
-                def whole():
-                    losses['d'], losses['g'] = one_step(train, g, d, opt_g, opt_d, batch,
-                                                        overlap=not args.no_overlap and not alt)
-
-                graph = capture(whole)
-                graph.replay()
+            if alt:
+                gs = _AltGraph(train, g, d, opt_g, opt_d, batch)
             else:
-                scale = 1.0 / world
-                # (no second stream when the generator's frame loop is a persistent launch: one at a time per device)
-                side_ok = not args.no_overlap and not g.front_is_persistent(args.batch, dev)
-                # critic: graph 1a ends where the gradients of heads + biLSTM are final; their all-reduce
-                # (93 % of D's bytes) then runs on RCCL's stream WHILE graph 1b does the conv-stack backward.
-                # generator: graph 3a ends where the conv trunk's gradients are final; their all-reduce runs
-                # while graph 3b does the recurrent front's frame-by-frame backward.
-                def critic_early():
-                    # the G forward of the generator iteration is a parallel branch of this graph (as in the
-                    # single-graph step): G's weights are materialised on the main stream, then fork, run it
-                    # beside the critic, join before the capture ends
-                    if side_ok:
-                        if _SIDE[0] is None:
-                            _SIDE[0] = torch.cuda.Stream()
-                        g.prepare_weights()
-                        _SIDE[0].wait_stream(torch.cuda.current_stream())
-                        with torch.cuda.stream(_SIDE[0]):
-                            keep['pre'] = g(z=b_['z'], c=b_['c'], stop='never', cut=gkeep)
-                    else:
-                        keep['pre'] = None
-                    keep['loss_d'] = train.d_backward_early(g, d, opt_d, b_['real'], b_['real_len'], b_['c'], b_['z'],
-                                                            b_['noise_real'], b_['noise_fake'], keep)
-                    if side_ok:
-                        torch.cuda.current_stream().wait_stream(_SIDE[0])
-
-                def gen_early():
-                    keep['loss_g'] = train.g_backward_early(g, d, opt_g, b_['c'], b_['z'], b_['noise_fake'], gkeep,
-                                                            pre=keep.get('pre'))
-
-                g1a = capture(critic_early)
-                g1b = capture(lambda: train.d_backward_late(keep), warm=False)
-                bd.all_reduce()
-                g2 = capture(lambda: opt_d.step(clip_norm=1.0, grad_scale=scale))
-                g3a = capture(gen_early, warm=not side_ok)
-                g3b = capture(lambda: train.g_backward_late(gkeep), warm=False)
-                bg.all_reduce()
-                g4 = capture(lambda: opt_g.step(clip_norm=0.1, grad_scale=scale))
-                phases = (g1a, g1b, g2, g3a, g3b, g4)
+                gs = train.GraphedStep(g, d, opt_g, opt_d, batch, phased=multi, bucket_d=bd if multi else None,
+                                       bucket_g=bg if multi else None, world=world, overlap=not args.no_overlap)
+            gs.step()
             torch.cuda.synchronize()
         except Exception as e:  # noqa: BLE001
             sys.stderr.write('hipGraph capture failed (%s: %s); running eagerly\n' % (type(e).__name__, e))
-            graph = phases = None
-            K.drop_captured_tables(table_mark)      # their device copies were never executed
+            gs = None
             capture_error = '%s: %s' % (type(e).__name__, str(e)[:200])
             torch.cuda.synchronize()
+    graph = gs if (gs is not None and gs.graph is not None) else None
+    phases = gs.phases if (gs is not None and gs.graph is None) else None
 
     def run_step():
-        if graph is not None:
-            graph.replay()
-        elif phases is not None:
-            phases[0].replay()                         # critic fwd + bwd of heads / biLSTM
-            bd.all_reduce(async_op=True, part='early') # overlaps ...
-            phases[1].replay()                         # ... the conv-stack backward
-            bd.wait()
-            bd.all_reduce(part='late')
-            phases[2].replay()                         # opt_d
-            phases[3].replay()                         # generator fwd + bwd down to the front's frames
-            bg.all_reduce(async_op=True, part='early') # conv trunk's gradients; overlaps ...
-            phases[4].replay()                         # ... the recurrent front's backward
-            bg.wait()
-            bg.all_reduce(part='late')
-            phases[5].replay()                         # opt_g
+        if gs is not None:
+            losses['d'], losses['g'] = gs.step()
         else:
             losses['d'], losses['g'] = one_step(train, g, d, opt_g, opt_d, batch, hook_d, hook_g)
 
@@ -393,8 +344,7 @@ def main():
         sog, sod = opt_g.state_dict(), opt_d.state_dict()
         run_step()
         torch.cuda.synchronize()
-        src = losses if graph is not None else {'d': keep['loss_d'], 'g': keep['loss_g']}
-        got = (float(src['d']), float(src['g']))
+        got = (float(losses['d']), float(losses['g']))
         with torch.no_grad():
             for p_, s_ in zip(nets, snap):
                 p_.copy_(s_)
