@@ -129,6 +129,23 @@ class WNGroup(object):
             self._key = key
         return self._bufs
 
+    def zero_dws(self):
+        """zero-filled scratch for the gradients wrt the materialised weights, one tensor per item (views of ONE
+        persistent flat buffer: a single memset, and - unlike a fresh allocation per backward - stable addresses, so the
+        descriptor table of the weight-norm backward is built once and a captured graph needs no upload node for it:
+        under replay such an upload runs as ~24 serial 64-byte blits per table, 0.35 ms per step)"""
+        dev = self.items[0]['v'].device
+        if getattr(self, '_dws', None) is None or self._dws[0].device != dev:
+            n = sum(it['v'].numel() for it in self.items)
+            flat = torch.empty(n, device=dev, dtype=torch.float32)
+            views, o = [], 0
+            for it in self.items:
+                views.append(flat[o:o + it['v'].numel()].view(it['v'].shape))
+                o += it['v'].numel()
+            self._dws, self._dws_flat = views, flat
+        self._dws_flat.zero_()
+        return list(self._dws)
+
     def backward(self, dws):
         """dws[i]: gradient wrt the materialised w of item i (same shape as v), or None.
         Returns the flat list [dv0, dg0, dv1, dg1, ...]."""

@@ -119,7 +119,7 @@ class GTrunkFn(torch.autograd.Function):
         B, ctot, L = slab.shape
         dy = dy.contiguous().view(B, 1, L)
         wg = any(ctx.needs_input_grad[2:])
-        dws = _zeros_like_list([it['v'] for it in trunk.group.items]) if wg else None
+        dws = trunk.group.zero_dws() if wg else None
         dslab = torch.empty_like(slab)
         # final conv (no activation)
         if wg:
@@ -186,7 +186,7 @@ class DConvStackFn(torch.autograd.Function):
         assert stack.group._key[1:] == ctx.key, 'parameters changed between forward and backward'
         B, L = x.shape
         wg = any(ctx.needs_input_grad[3:])
-        dws = _zeros_like_list([it['v'] for it in stack.group.items]) if wg else None
+        dws = stack.group.zero_dws() if wg else None
         n = len(stack.specs)
         d = None
         for i in reversed(range(n)):
@@ -260,7 +260,7 @@ class DHeadFn(torch.autograd.Function):
         acts = saved[:-1]          # acts[0] = input rows, acts[i] = output of residual i
         nr = head.n_res
         wg = any(ctx.needs_input_grad[2:])
-        dws = _zeros_like_list([it['v'] for it in head.group.items]) if wg else None
+        dws = head.group.zero_dws() if wg else None
         dout = dout.contiguous()
         w0, w1 = prep[2 * nr].w, prep[2 * nr + 2].w
         # classifier[2]: out = hmid @ w1^T + b1

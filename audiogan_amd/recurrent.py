@@ -341,7 +341,7 @@ class GFrontFn(torch.autograd.Function):
             K.gemm(ds_tb, hs[-1].view(T * B, S), dws[4 * nl + 2], ta=True)
             K.col_sum(ds_tb, dws[4 * nl + 3])
             return (None, None) + tuple(front.group.backward(dws))
-        dws = _zeros_like_list([it['v'] for it in front.group.items]) if wg else None
+        dws = front.group.zero_dws() if wg else None
         fused = (nl == 1 and T > 0 and (S + fs) % 4 == 0
                  and K.lstm_front_bwd_ok(B, S, fs, x[:, :fs], x[:, :fs]) and K.skinny_ok(gates[0][0], lw[0][1], False))
         if fused:
@@ -432,7 +432,7 @@ class GRUFrontFn(torch.autograd.Function):
         zc, x, gi, gh, hs = ctx.saved_tensors
         dev = zc.device
         wg = any(ctx.needs_input_grad[2:])
-        dws = _zeros_like_list([it['v'] for it in front.group.items]) if wg else None
+        dws = front.group.zero_dws() if wg else None
         dxa = dx.contiguous().clone() if dx is not None else torch.zeros(B, T * fs, device=dev)
         dha = torch.zeros(T + 1, B, S, device=dev)     # dha[t+1] accumulates dL/dh_t
         if ds is not None:
