@@ -48,6 +48,16 @@ __device__ __forceinline__ unsigned ag_pack_bf16(float a, float b) {
   const ag_f2 v = {a, b};
   return __builtin_bit_cast(unsigned, __builtin_convertvector(v, ag_bf2));
 }
+// Every prepared conv weight layout [Cp2][taps][Mpad] (fp32, conv_engine.hip) is followed, in the same buffer, by its bf16
+// image in the order the bf16 conv kernel keeps it in LDS: [ceil(Cp2/16)][taps][2][Mpad][8 x bf16] (8 consecutive channels
+// of one row per 16-byte slot; channels beyond Cp2 stay zero).  Offsets / sizes in floats:
+__host__ __device__ inline int64_t ag_wq_offset(int cp2, int taps, int mpad) { return (int64_t)cp2 * taps * mpad; }
+__host__ __device__ inline int64_t ag_wq_floats(int cp2, int taps, int mpad) {
+  return (int64_t)((cp2 + 15) / 16) * 16 * taps * mpad / 2;
+}
+__host__ __device__ inline int64_t ag_wq_index(int c, int tap, int row, int taps, int mpad) {   // in bf16 elements
+  return ((((int64_t)(c >> 4) * taps + tap) * 2 + ((c >> 3) & 1)) * mpad + row) * 8 + (c & 7);
+}
 __device__ __forceinline__ float ag_rbf(float x) { return __uint_as_float(ag_pack_bf16(x, x) << 16); }
 __device__ __forceinline__ float ag_rbf_if(float x, int rb) { return rb ? ag_rbf(x) : x; }
 __device__ __forceinline__ f32x4 ag_rbf4_if(f32x4 v, int rb) {

@@ -37,6 +37,7 @@ struct ConvP {
   int n_cnt;      // number of columns
   int xvec;       // input rows may be read with aligned 16-byte loads
   int aligned;    // mode 1: aligned scatter layout (common.h) - phase r's outputs are shifted by -s * shift_r
+  int nbuf;       // bf16 kernel: LDS buffers (1 when the whole reduction is one chunk)
   int rb;         // AG_PREC_BF16: both operands rounded to bf16 while staging (fp32 MFMA on rounded values)
   int tapoff[MAX_TAPS];
 };
@@ -45,6 +46,130 @@ struct ConvP {
 // guaranteed to be 4-byte aligned (gfx950 global accesses need dword alignment only)
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
+
+// Epilogue shared by the fp32 and the bf16 kernels (same 32x32 accumulator layout): bias + residual + activation +
+// length mask (+ accumulate).
+template <int TILES_O, int TILES_T>
+__device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[TILES_O][TILES_T], const float* bias_s,
+                                              int b, int row0, int n0, int wrow0, int wcol0, int l31, int h) {
+  const ag_conv_args& a = p.a;
+  const int64_t lenb = a.lens_i64 ? a.lens_i64[b] : (int64_t)1 << 60;
+  float* yb = a.y + (int64_t)b * a.y_bs;
+  const float* rb = a.res ? a.res + (int64_t)b * a.res_bs : nullptr;
+  if (a.mode == 0) {
+#pragma unroll
+    for (int i = 0; i < TILES_O; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int o = row0 + wrow0 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (o >= p.Mrows) continue;
+        const float bo = bias_s[o - row0];
+#pragma unroll
+        for (int j = 0; j < TILES_T; ++j) {
+          const int t = n0 + wcol0 + 32 * j + l31;
+          if (t >= a.Lout) continue;
+          float v = acc[i][j][e] + bo;
+          if (rb) v += rb[(int64_t)o * a.res_cs + t];
+          v = ag_apply_act(v, a.act, a.slope);
+          if (t >= lenb) v = 0.f;
+          float* dst = yb + (int64_t)o * a.y_cs + t;
+          if (a.accumulate) v += *dst;
+          *dst = v;
+        }
+      }
+    }
+    return;
+  }
+  // mode 1: row = o*s + r, output position u = s*n + r - pad.  A lane holds 4 consecutive rows in
+  // registers 4g..4g+3, i.e. VW consecutive output positions of one channel -> vector stores.
+  const int s = a.stride;
+  // Aligned layout (common.h): with rho = pad % s, phases r >= rho sit one column earlier, so the s rows of a channel
+  // are the contiguous window [s*(n-a-1), +s) ROTATED by rho (pad = s*a + rho).  s == 2 (the critic's convs): the
+  // two phases of a channel are a swapped pair -> still one 8-byte store; other strides: one row at a time.
+  const int rho = a.pad % s;
+  const int VW = p.aligned ? (s == 2 ? 2 : 1) : ((s % 4 == 0) ? 4 : ((s % 2 == 0) ? 2 : 1));
+  const bool swap2 = p.aligned && s == 2;
+  // stride % 4 == 0 (the generator's transposed convs and the backward of its strided convs): the residual - or
+  // for `accumulate` the old output - of a whole row tile is requested up front, one 16-byte load per group.
+  // Inside the per-group branches below every such load is followed by its own wait: 16 dependent round trips
+  // per workgroup, more than the MFMA loop of these thin layers takes.
+  const bool pre_res = VW == 4 && rb != nullptr;
+  const bool pre_acc = VW == 4 && !pre_res && a.accumulate;
+#pragma unroll
+  for (int i = 0; i < TILES_O; ++i) {
+    f32x4u pre[4][TILES_T];
+    if (pre_res || pre_acc) {
+      const float* pb = pre_res ? rb : yb;
+      const int64_t pcs = pre_res ? a.res_cs : a.y_cs;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int rowb = row0 + wrow0 + 32 * i + 8 * g + 4 * h;
+        const int o = rowb / s, r = rowb - o * s;
+#pragma unroll
+        for (int j = 0; j < TILES_T; ++j) {
+          const int u0 = s * (n0 + wcol0 + 32 * j + l31) + r - a.pad;
+          const bool ok = rowb < p.Mrows && u0 >= 0 && u0 + 4 <= a.Lout;
+          pre[g][j] = *reinterpret_cast<const f32x4u*>(ok ? pb + (int64_t)o * pcs + u0 : pb);
+        }
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int rowb = row0 + wrow0 + 32 * i + 8 * g + 4 * h;
+      if (rowb >= p.Mrows) continue;
+#pragma unroll
+      for (int j = 0; j < TILES_T; ++j) {
+        const int n = n0 + wcol0 + 32 * j + l31;
+        const float v4[4] = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+        for (int sub = 0; sub < 4; sub += VW) {
+          const int row = rowb + sub;
+          if (row >= p.Mrows) break;
+          const int o = row / s, r = row - o * s;
+          const int u0 = swap2 ? (2 * n - a.pad - 1)
+                               : (s * (n - ((p.aligned && r >= rho) ? 1 : 0)) + r - a.pad);
+          const float bo = bias_s[row - row0];
+          float* dst = yb + (int64_t)o * a.y_cs + u0;
+          const float* rsrc = rb ? rb + (int64_t)o * a.res_cs + u0 : nullptr;
+          float v[4];
+          if (VW == 4) { v[0] = v4[0] + bo; v[1] = v4[1] + bo; v[2] = v4[2] + bo; v[3] = v4[3] + bo; }
+          else if (VW == 2) {
+            const float e0 = sub ? v4[2] : v4[0], e1 = sub ? v4[3] : v4[1];      // phases 0, 1 of channel o
+            v[0] = (swap2 ? e1 : e0) + bo; v[1] = (swap2 ? e0 : e1) + bo; v[2] = v[3] = 0.f;
+          }
+          else { v[0] = (sub == 0 ? v4[0] : sub == 1 ? v4[1] : sub == 2 ? v4[2] : v4[3]) + bo; v[1] = v[2] = v[3] = 0.f; }
+          const bool full = u0 >= 0 && u0 + VW <= a.Lout;
+          if (full && VW == 4) {
+            if (pre_res) { const f32x4u rv = pre[g][j]; v[0] += rv[0]; v[1] += rv[1]; v[2] += rv[2]; v[3] += rv[3]; }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { v[q] = ag_apply_act(v[q], a.act, a.slope); if (u0 + q >= lenb) v[q] = 0.f; }
+            if (pre_acc) { const f32x4u ov = pre[g][j]; v[0] += ov[0]; v[1] += ov[1]; v[2] += ov[2]; v[3] += ov[3]; }
+            else if (a.accumulate) { const f32x4u ov = *reinterpret_cast<const f32x4u*>(dst); v[0] += ov[0]; v[1] += ov[1]; v[2] += ov[2]; v[3] += ov[3]; }
+            f32x4u out = {v[0], v[1], v[2], v[3]};
+            *reinterpret_cast<f32x4u*>(dst) = out;
+          } else if (full && VW == 2) {
+            if (rsrc) { const f32x2u rv = *reinterpret_cast<const f32x2u*>(rsrc); v[0] += rv[0]; v[1] += rv[1]; }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) { v[q] = ag_apply_act(v[q], a.act, a.slope); if (u0 + q >= lenb) v[q] = 0.f; }
+            if (a.accumulate) { const f32x2u ov = *reinterpret_cast<const f32x2u*>(dst); v[0] += ov[0]; v[1] += ov[1]; }
+            f32x2u out = {v[0], v[1]};
+            *reinterpret_cast<f32x2u*>(dst) = out;
+          } else {
+            for (int q = 0; q < VW; ++q) {
+              const int u = u0 + q;
+              if (u < 0 || u >= a.Lout) continue;
+              float w = v[q];
+              if (rsrc) w += rsrc[q];
+              w = ag_apply_act(w, a.act, a.slope);
+              if (u >= lenb) w = 0.f;
+              if (a.accumulate) w += dst[q];
+              dst[q] = w;
+            }
+          }
+        }
+      }
+    }
+  }
+}
 
 // TAPS/S0 > 0: taps and polyphase factor known at compile time (tap loop fully unrolled, LDS
 // offsets are immediates).  S0 = stride for mode 0, 0 for mode 1.  TAPS == 0: generic runtime loop.
@@ -336,123 +461,186 @@ __global__ __launch_bounds__(512) void conv_engine_kernel(const ConvP p) {
     __syncthreads();
   }
 
-  // ---- epilogue: bias + residual + activation + length mask (+ accumulate)
-  const int64_t lenb = a.lens_i64 ? a.lens_i64[b] : (int64_t)1 << 60;
-  float* yb = a.y + (int64_t)b * a.y_bs;
-  const float* rb = a.res ? a.res + (int64_t)b * a.res_bs : nullptr;
-  if (a.mode == 0) {
+  conv_epilogue<TILES_O, TILES_T>(p, acc, bias_s, b, row0, n0, wrow0, wcol0, l31, h);
+}
+
+// ------------------------------------------------------------------------------------------
+// AG_PREC_BF16: the same implicit GEMM on v_mfma_f32_32x32x16_bf16 (8x the fp32 MFMA rate).
+//
+// One MFMA k-step = 16 input channels at one tap: lane (l31, h) supplies the 8 channels 8h..8h+7, so both LDS images
+// keep 8 channels of one (row | position) in one 16-byte slot:
+//   XB[group][h][polyphase row][position][8 x bf16]       (input window, de-interleaved like the fp32 kernel's)
+//   WB[group][tap][h][row][8 x bf16]                      (weights of the row tile)
+// Weights come from the bf16 image behind the prepared fp32 layout (common.h ag_wq_*, written by the weight-norm /
+// prep kernels in exactly this order): a straight 16-byte copy.  Activations are fp32 in HBM; a staging lane gathers
+// 8 channels x 4 consecutive positions with 8 16-byte loads, rounds (RNE, v_cvt_pk_bf16_f32) and writes 4 slots.
+// The MFMAs of a chunk are short (a few hundred cycles), a memory round trip is not: the staging waves keep the loads
+// of chunk i+2 in flight (in registers) while chunk i+1 sits in the second LDS buffer and chunk i is being multiplied.
+// Results equal the rounding emulation in the fp32 kernel up to fp32 summation order (products of bf16 values are exact
+// in fp32; the MFMA accumulates in fp32).
+typedef short cbf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned cu32x4 __attribute__((ext_vector_type(4)));
+// Per staging lane and chunk: NW weight slots and CB_NX input tasks (8 channels x 4 positions).  NW = 16 is the deep-reduction
+// variant (>= 8 channel groups, 128-row tiles): one workgroup per CU, two 16-channel groups per chunk - the chunk in
+// flight, not a co-resident workgroup, covers the memory latency.
+#define CB_NX 2
+
+template <int TILES_O, int TILES_T, int WAVES_O, int WAVES_T, int NW>
+__global__ __launch_bounds__(512) void conv_engine_bf16_kernel(const ConvP p) {
+  static_assert(WAVES_O * WAVES_T == 4, "4 compute waves per workgroup");
+  constexpr int OT = 32 * TILES_O * WAVES_O;
+  constexpr int TT = 32 * TILES_T * WAVES_T;
+  extern __shared__ float smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wid = tid >> 6;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int cw = wid & 3;
+  const int wo = cw / WAVES_T, wt = cw % WAVES_T;
+  const int wrow0 = wo * (32 * TILES_O), wcol0 = wt * (32 * TILES_T);
+
+  const int b = blockIdx.z;
+  const int row0 = blockIdx.y * OT;
+  const int n0 = p.n_lo + blockIdx.x * TT;
+  const ag_conv_args& a = p.a;
+  const int taps = p.taps;
+  const int base = (a.mode == 0) ? (a.stride * n0 - a.pad) : (n0 - (taps - 1));
+
+  const int span = p.sp * p.ncols;
+  const int rowlen = p.rowlen;                     // positions (16-byte slots) per polyphase row
+  const int ngr = p.CC >> 4;                       // 16-channel groups per chunk
+  const int xslots = 2 * p.chs;                    // slots per group of the input image (chs = sp * rowlen)
+  const int wslots = taps * 2 * OT;                // slots per group of the weight image
+  const size_t bufsl = (size_t)ngr * (xslots + wslots);   // 16-byte slots per LDS buffer
+  const int nchunk = (p.Cpad + p.CC - 1) / p.CC;
+  cu32x4* lds = reinterpret_cast<cu32x4*>(smem);
+
+  float* bias_s = smem + p.nbuf * bufsl * 4;
+  if (tid < OT) {
+    const int row = row0 + tid;
+    bias_s[tid] = (a.bias && row < p.Mrows) ? a.bias[a.mode == 0 ? row : row / a.stride] : 0.f;
+  }
+
+  if (__builtin_amdgcn_readfirstlane(threadIdx.x) >= 256) {
+    // ---------------- staging waves
+    __builtin_amdgcn_s_setprio(2);
+    const int sl = cw * 64 + lane;                 // 0 .. 255
+    // Buffer loads: one 32-bit offset register per load instead of a 64-bit address, and every piece that must read
+    // as zero (halo outside the signal, channels >= C, rows >= Mpad, groups beyond the image) simply carries an
+    // offset past num_records.  (Host side guarantees: 16-byte pieces lie entirely inside or outside the signal.)
+    const unsigned OOB = 0x80000000u;
+    __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.x + (int64_t)b * a.x_bs), 0, (int)((int64_t)a.C * a.x_cs * 4), 0x00020000);
+    const int ngroups = (p.Cpad + 15) >> 4;        // groups in the weight image
+    __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.wp + ag_wq_offset(p.Cpad, taps, p.Mpad)), 0, (int)((int64_t)ngroups * taps * 2 * p.Mpad * 16), 0x00020000);
+    const int base4 = base - (((base % 4) + 4) % 4);
+    const int nq = (base - base4 + span + 3) / 4;
+    const int xtot = ngr * 2 * nq, wtot = ngr * wslots;
+    // chunk-invariant part of this lane's tasks
+    int xgh[CB_NX], xg[CB_NX];
+    unsigned xo[CB_NX], wof[NW];
 #pragma unroll
-    for (int i = 0; i < TILES_O; ++i) {
+    for (int u = 0; u < CB_NX; ++u) {
+      const int e = sl + u * 256;
+      const int gh = e < xtot ? e / nq : -1;
+      xgh[u] = gh;
+      xg[u] = base4 + 4 * (e - max(gh, 0) * nq);
+      xo[u] = (gh >= 0 && xg[u] >= 0 && xg[u] + 3 < a.Lin) ? (unsigned)((gh * 8 * (int)a.x_cs + xg[u]) * 4) : OOB;
+    }
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int o = row0 + wrow0 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
-        if (o >= p.Mrows) continue;
-        const float bo = bias_s[o - row0];
+    for (int u = 0; u < NW; ++u) {
+      const int idx = sl + u * 256;                // = gth * OT + row
+      const int gth = idx / OT, row = row0 + (idx % OT);
+      wof[u] = (idx < wtot && row < p.Mpad) ? (unsigned)((gth * p.Mpad + row) * 16) : OOB;
+    }
+    const unsigned xcs4 = (unsigned)a.x_cs * 4u;
+    cu32x4 wv[NW];
+    cu32x4 xv[CB_NX][8];
+    auto load = [&](int ci) {
+      const unsigned wadd = (unsigned)(ci * ngr * taps * 2 * p.Mpad * 16);
+      const unsigned xadd = (unsigned)(ci * p.CC) * xcs4;
 #pragma unroll
-        for (int j = 0; j < TILES_T; ++j) {
-          const int t = n0 + wcol0 + 32 * j + l31;
-          if (t >= a.Lout) continue;
-          float v = acc[i][j][e] + bo;
-          if (rb) v += rb[(int64_t)o * a.res_cs + t];
-          v = ag_apply_act(v, a.act, a.slope);
-          if (t >= lenb) v = 0.f;
-          float* dst = yb + (int64_t)o * a.y_cs + t;
-          if (a.accumulate) v += *dst;
-          *dst = v;
+      for (int u = 0; u < NW; ++u) wv[u] = __builtin_amdgcn_raw_buffer_load_b128(wr, wof[u] + wadd, 0, 0);
+#pragma unroll
+      for (int u = 0; u < CB_NX; ++u)
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          xv[u][j] = __builtin_amdgcn_raw_buffer_load_b128(xr, xo[u] + xadd + (unsigned)j * xcs4, 0, 0);
+    };
+    auto write = [&](int buf) {
+      cu32x4* xs = lds + buf * bufsl;                  // [ngr][2][sp][rowlen]
+      cu32x4* ws = xs + (size_t)ngr * xslots;          // [ngr][taps][2][OT]
+#pragma unroll
+      for (int u = 0; u < NW; ++u) {
+        const int idx = sl + u * 256;
+        if (idx < wtot) ws[idx] = wv[u];
+      }
+#pragma unroll
+      for (int u = 0; u < CB_NX; ++u) {
+        if (xgh[u] < 0) continue;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int rem = xg[u] + q - base;
+          if (rem < 0 || rem >= span) continue;
+          int r, qq;
+          if (p.sp_shift >= 0) {
+            r = rem & (p.sp - 1);
+            qq = rem >> p.sp_shift;
+          } else {
+            qq = rem / p.sp;
+            r = rem - qq * p.sp;
+          }
+#define XF(j) __uint_as_float(xv[u][j][q])
+          const cu32x4 w = {ag_pack_bf16(XF(0), XF(1)), ag_pack_bf16(XF(2), XF(3)), ag_pack_bf16(XF(4), XF(5)),
+                            ag_pack_bf16(XF(6), XF(7))};
+#undef XF
+          xs[(size_t)xgh[u] * p.chs + r * rowlen + qq] = w;
         }
       }
+    };
+    load(0);
+    write(0);
+    if (nchunk > 1) load(1);
+    __syncthreads();
+    for (int ci = 0; ci < nchunk; ++ci) {
+      if (ci + 1 < nchunk) write((ci + 1) & 1);
+      if (ci + 2 < nchunk) load(ci + 2);
+      __syncthreads();
     }
     return;
   }
-  // mode 1: row = o*s + r, output position u = s*n + r - pad.  A lane holds 4 consecutive rows in
-  // registers 4g..4g+3, i.e. VW consecutive output positions of one channel -> vector stores.
-  const int s = a.stride;
-  // Aligned layout (common.h): with rho = pad % s, phases r >= rho sit one column earlier, so the s rows of a channel
-  // are the contiguous window [s*(n-a-1), +s) ROTATED by rho (pad = s*a + rho).  s == 2 (the critic's convs): the
-  // two phases of a channel are a swapped pair -> still one 8-byte store; other strides: one row at a time.
-  const int rho = a.pad % s;
-  const int VW = p.aligned ? (s == 2 ? 2 : 1) : ((s % 4 == 0) ? 4 : ((s % 2 == 0) ? 2 : 1));
-  const bool swap2 = p.aligned && s == 2;
-  // stride % 4 == 0 (the generator's transposed convs and the backward of its strided convs): the residual - or
-  // for `accumulate` the old output - of a whole row tile is requested up front, one 16-byte load per group.
-  // Inside the per-group branches below every such load is followed by its own wait: 16 dependent round trips
-  // per workgroup, more than the MFMA loop of these thin layers takes.
-  const bool pre_res = VW == 4 && rb != nullptr;
-  const bool pre_acc = VW == 4 && !pre_res && a.accumulate;
+  // ---------------- MFMA waves
+  f32x16 acc[TILES_O][TILES_T];
 #pragma unroll
-  for (int i = 0; i < TILES_O; ++i) {
-    f32x4u pre[4][TILES_T];
-    if (pre_res || pre_acc) {
-      const float* pb = pre_res ? rb : yb;
-      const int64_t pcs = pre_res ? a.res_cs : a.y_cs;
+  for (int i = 0; i < TILES_O; ++i)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int rowb = row0 + wrow0 + 32 * i + 8 * g + 4 * h;
-        const int o = rowb / s, r = rowb - o * s;
+    for (int j = 0; j < TILES_T; ++j)
 #pragma unroll
-        for (int j = 0; j < TILES_T; ++j) {
-          const int u0 = s * (n0 + wcol0 + 32 * j + l31) + r - a.pad;
-          const bool ok = rowb < p.Mrows && u0 >= 0 && u0 + 4 <= a.Lout;
-          pre[g][j] = *reinterpret_cast<const f32x4u*>(ok ? pb + (int64_t)o * pcs + u0 : pb);
-        }
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  __syncthreads();
+  for (int ci = 0; ci < nchunk; ++ci) {
+    const cu32x4* xs = lds + (ci & 1) * bufsl;
+    const cu32x4* ws = xs + (size_t)ngr * xslots;
+    for (int g = 0; g < ngr; ++g) {
+      const cu32x4* wg = ws + (size_t)(g * taps * 2 + h) * OT + wrow0 + l31;
+      const cu32x4* xg = xs + (size_t)(g * 2 + h) * p.chs + wcol0 + l31;
+      for (int tau = 0; tau < taps; ++tau) {
+        cbf16x8 av[TILES_O], bv[TILES_T];
+#pragma unroll
+        for (int i = 0; i < TILES_O; ++i) av[i] = *reinterpret_cast<const cbf16x8*>(wg + (size_t)tau * 2 * OT + 32 * i);
+        const int off = p.tapoff[tau];
+#pragma unroll
+        for (int j = 0; j < TILES_T; ++j) bv[j] = *reinterpret_cast<const cbf16x8*>(xg + off + 32 * j);
+#pragma unroll
+        for (int i = 0; i < TILES_O; ++i)
+#pragma unroll
+          for (int j = 0; j < TILES_T; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
       }
     }
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int rowb = row0 + wrow0 + 32 * i + 8 * g + 4 * h;
-      if (rowb >= p.Mrows) continue;
-#pragma unroll
-      for (int j = 0; j < TILES_T; ++j) {
-        const int n = n0 + wcol0 + 32 * j + l31;
-        const float v4[4] = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-        for (int sub = 0; sub < 4; sub += VW) {
-          const int row = rowb + sub;
-          if (row >= p.Mrows) break;
-          const int o = row / s, r = row - o * s;
-          const int u0 = swap2 ? (2 * n - a.pad - 1)
-                               : (s * (n - ((p.aligned && r >= rho) ? 1 : 0)) + r - a.pad);
-          const float bo = bias_s[row - row0];
-          float* dst = yb + (int64_t)o * a.y_cs + u0;
-          const float* rsrc = rb ? rb + (int64_t)o * a.res_cs + u0 : nullptr;
-          float v[4];
-          if (VW == 4) { v[0] = v4[0] + bo; v[1] = v4[1] + bo; v[2] = v4[2] + bo; v[3] = v4[3] + bo; }
-          else if (VW == 2) {
-            const float e0 = sub ? v4[2] : v4[0], e1 = sub ? v4[3] : v4[1];      // phases 0, 1 of channel o
-            v[0] = (swap2 ? e1 : e0) + bo; v[1] = (swap2 ? e0 : e1) + bo; v[2] = v[3] = 0.f;
-          }
-          else { v[0] = (sub == 0 ? v4[0] : sub == 1 ? v4[1] : sub == 2 ? v4[2] : v4[3]) + bo; v[1] = v[2] = v[3] = 0.f; }
-          const bool full = u0 >= 0 && u0 + VW <= a.Lout;
-          if (full && VW == 4) {
-            if (pre_res) { const f32x4u rv = pre[g][j]; v[0] += rv[0]; v[1] += rv[1]; v[2] += rv[2]; v[3] += rv[3]; }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { v[q] = ag_apply_act(v[q], a.act, a.slope); if (u0 + q >= lenb) v[q] = 0.f; }
-            if (pre_acc) { const f32x4u ov = pre[g][j]; v[0] += ov[0]; v[1] += ov[1]; v[2] += ov[2]; v[3] += ov[3]; }
-            else if (a.accumulate) { const f32x4u ov = *reinterpret_cast<const f32x4u*>(dst); v[0] += ov[0]; v[1] += ov[1]; v[2] += ov[2]; v[3] += ov[3]; }
-            f32x4u out = {v[0], v[1], v[2], v[3]};
-            *reinterpret_cast<f32x4u*>(dst) = out;
-          } else if (full && VW == 2) {
-            if (rsrc) { const f32x2u rv = *reinterpret_cast<const f32x2u*>(rsrc); v[0] += rv[0]; v[1] += rv[1]; }
-#pragma unroll
-            for (int q = 0; q < 2; ++q) { v[q] = ag_apply_act(v[q], a.act, a.slope); if (u0 + q >= lenb) v[q] = 0.f; }
-            if (a.accumulate) { const f32x2u ov = *reinterpret_cast<const f32x2u*>(dst); v[0] += ov[0]; v[1] += ov[1]; }
-            f32x2u out = {v[0], v[1]};
-            *reinterpret_cast<f32x2u*>(dst) = out;
-          } else {
-            for (int q = 0; q < VW; ++q) {
-              const int u = u0 + q;
-              if (u < 0 || u >= a.Lout) continue;
-              float w = v[q];
-              if (rsrc) w += rsrc[q];
-              w = ag_apply_act(w, a.act, a.slope);
-              if (u >= lenb) w = 0.f;
-              if (a.accumulate) w += dst[q];
-              dst[q] = w;
-            }
-          }
-        }
-      }
-    }
+    __syncthreads();
   }
+  conv_epilogue<TILES_O, TILES_T>(p, acc, bias_s, b, row0, n0, wrow0, wcol0, l31, h);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -464,12 +652,18 @@ static int ilog2_exact(int v) {
   return -1;
 }
 
+// fp32 layout + its bf16 image (common.h ag_wq_*)
 extern "C" int64_t ag_wpa_numel(int d0, int d1, int K) {
-  return (int64_t)ag_roundup(d1, 2) * K * ag_roundup(d0, 32);
+  const int cp2 = ag_roundup(d1, 2), mp = ag_roundup(d0, 32);
+  return ag_wq_offset(cp2, K, mp) + ag_wq_floats(cp2, K, mp);
 }
 extern "C" int64_t ag_wpb_numel(int d0, int d1, int K, int stride) {
-  return (int64_t)ag_roundup(d0, 2) * ag_cdiv(K, stride) * ag_roundup(d1 * stride, 32);
+  const int cp2 = ag_roundup(d0, 2), mt = ag_cdiv(K, stride), mp = ag_roundup(d1 * stride, 32);
+  return ag_wq_offset(cp2, mt, mp) + ag_wq_floats(cp2, mt, mp);
 }
+
+// AG_CONV_BF16_MFMA=0 keeps the fp32-MFMA rounding emulation in bf16 mode (A/B measurements)
+static const bool g_conv_bf16_mfma = [] { const char* e = getenv("AG_CONV_BF16_MFMA"); return !(e && e[0] == '0'); }();
 
 template <int TO, int TTL, int WO, int WT, int TAPS, int S0>
 static int launch_one(ConvP& p, size_t lds, dim3 grid, hipStream_t st) {
@@ -481,9 +675,62 @@ static int launch_one(ConvP& p, size_t lds, dim3 grid, hipStream_t st) {
   return AG_OK;
 }
 
+// bf16 MFMA variant (AG_PREC_BF16, >= 16 input channels): chunks of whole 16-channel groups
+template <int TO, int TTL, int WO, int WT, int NW>
+static int launch_bf16_nw(ConvP& p, hipStream_t st) {
+  constexpr int OT = 32 * TO * WO, TT = 32 * TTL * WT;
+  const ag_conv_args& a = p.a;
+  const size_t per_g = (size_t)(2 * p.chs + p.taps * 2 * OT) * 16;     // bytes per 16-channel group
+  int ng = (int)(((NW > 8 ? 74 : 36) * 1024) / per_g);
+  if (ng < 1) ng = 1;
+  if (ng > 4) ng = 4;
+  const int groups = ag_cdiv(p.Cpad, 16);
+  if (ng > groups) ng = groups;
+  // what the 256 staging lanes hold in registers per chunk: NW weight slots and CB_NX input tasks each
+  const int nq = (p.sp * p.ncols + 6) / 4 + 1;
+  while (ng > 1 && (ng * p.taps * 2 * OT > NW * 256 || ng * 2 * nq > CB_NX * 256)) --ng;
+  if (p.taps * 2 * OT > NW * 256 || 2 * nq > CB_NX * 256) return -1;
+  p.CC = 16 * ng;
+  p.nbuf = ng >= groups ? 1 : 2;                     // a single chunk needs no second buffer
+  const size_t lds = p.nbuf * (size_t)ng * per_g + (size_t)OT * sizeof(float);
+  if (lds > 160 * 1024) return -1;                   // (many taps x wide polyphase window) -> caller keeps the fp32-MFMA path
+  dim3 grid(ag_cdiv(p.n_cnt, TT), ag_cdiv(p.Mrows, OT), a.B);
+  auto kern = conv_engine_bf16_kernel<TO, TTL, WO, WT, NW>;
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, p);
+  AG_CHECK_LAUNCH("ag_conv1d_engine(bf16)");
+  return AG_OK;
+}
+
+template <int TO, int TTL, int WO, int WT>
+static int launch_bf16(ConvP& p, hipStream_t st) {
+  constexpr int OT = 32 * TO * WO, TT = 32 * TTL * WT;
+  const ag_conv_args& a = p.a;
+  const int dmax = (a.mode == 0) ? (a.K - 1) / a.stride : (p.taps - 1);
+  p.ncols = TT + dmax;
+  p.rowlen = p.ncols;
+  p.chs = p.sp * p.rowlen;
+  for (int t = 0; t < p.taps; ++t)
+    p.tapoff[t] = (a.mode == 0) ? ((t % a.stride) * p.rowlen + t / a.stride) : (p.taps - 1 - t);
+  // buffer-addressed staging: 16-byte input pieces entirely inside or outside the signal, 31-bit byte offsets
+  if (!p.xvec || a.Lin % 4 != 0 || (int64_t)a.C * a.x_cs * 4 >= ((int64_t)1 << 31) ||
+      ag_wq_floats(p.Cpad, p.taps, p.Mpad) * 4 >= ((int64_t)1 << 31))
+    return -1;
+  if (OT >= 128 && ag_cdiv(p.Cpad, 16) * p.taps >= 32) {      // deep reduction
+    const int rc = launch_bf16_nw<TO, TTL, WO, WT, (OT >= 128 ? 16 : 8)>(p, st);
+    if (rc != -1) return rc;
+  }
+  return launch_bf16_nw<TO, TTL, WO, WT, 8>(p, st);
+}
+
 template <int TO, int TTL, int WO, int WT>
 static int launch_cfg(ConvP& p, hipStream_t st) {
   constexpr int OT = 32 * TO * WO, TT = 32 * TTL * WT;
+  if (p.rb && p.a.C >= 16 && g_conv_bf16_mfma) {
+    const int rc = launch_bf16<TO, TTL, WO, WT>(p, st);
+    if (rc != -1) return rc;
+  }
   const ag_conv_args& a = p.a;
   // input tile geometry
   const int dmax = (a.mode == 0) ? (a.K - 1) / a.stride : (p.taps - 1);
@@ -603,14 +850,16 @@ extern "C" int ag_conv1d_engine(const ag_conv_args* args, void* stream) {
   if (p.n_cnt <= 64) return launch_cfg<2, 1, 2, 2>(p, st);   // 128 x 64
   // fewer than two 128x128 workgroups per CU: one MFMA wave per SIMD cannot keep the matrix pipe fed, take
   // half-width tiles (twice the workgroups, two co-resident per CU)
-  if ((int64_t)ag_cdiv(p.n_cnt, 128) * ag_cdiv(p.Mrows, 128) * a.B < 512) return launch_cfg<2, 1, 2, 2>(p, st);
+  // (the bf16 kernel runs one workgroup per CU and wants the full tile's reuse of the staged weights)
+  const bool bfp = p.rb && ag_cdiv(p.Cpad, 16) * p.taps >= 32 && g_conv_bf16_mfma;      // (the deep-reduction variant)
+  if (!bfp && (int64_t)ag_cdiv(p.n_cnt, 128) * ag_cdiv(p.Mrows, 128) * a.B < 512) return launch_cfg<2, 1, 2, 2>(p, st);
   if (tail > 0 && tail <= 32 && main_cols > 0) {
     ConvP qm = p, qt = p;
     qm.n_cnt = main_cols;
     qt.n_lo += main_cols;
     qt.n_cnt = tail;
     // (main: half-width tiles when there would be fewer than two 128x128 workgroups per CU, as above)
-    const bool half = (int64_t)(main_cols / 128) * ag_cdiv(p.Mrows, 128) * a.B < 512;
+    const bool half = !bfp && (int64_t)(main_cols / 128) * ag_cdiv(p.Mrows, 128) * a.B < 512;
     return main_and_tail(st, [&](hipStream_t s_) { return half ? launch_cfg<2, 1, 2, 2>(qm, s_)
                                                                 : launch_cfg<2, 2, 2, 2>(qm, s_); },
                          [&](hipStream_t s_) { return launch_cfg<1, 1, 4, 1>(qt, s_); });     // 128 x 32
@@ -636,7 +885,9 @@ __global__ void prep_conv_weight_kernel(const float* __restrict__ w, float* __re
     const int64_t ck = i / d0p32;
     const int k = (int)(ck % K);
     const int c = (int)(ck / K);
-    wpa[i] = (a0 < d0 && c < d1) ? w[((int64_t)a0 * d1 + c) * K + k] : 0.f;
+    const float val = (a0 < d0 && c < d1) ? w[((int64_t)a0 * d1 + c) * K + k] : 0.f;
+    wpa[i] = val;
+    reinterpret_cast<unsigned short*>(wpa + na)[ag_wq_index(c, k, a0, K, d0p32)] = (unsigned short)ag_pack_bf16(val, val);
   }
   if (wpb && i < nb) {
     const int row = (int)(i % mp);
@@ -646,7 +897,9 @@ __global__ void prep_conv_weight_kernel(const float* __restrict__ w, float* __re
     const int o = row / s, r = row - o * s;
     const int mm = m - (ag_scatter_aligned(K, s, pad) ? ag_scatter_shift(s, pad, r) : 0);   // slot -> tap
     const int k = r + s * mm;
-    wpb[i] = (a0 < d0 && o < d1 && mm >= 0 && k < K) ? w[((int64_t)a0 * d1 + o) * K + k] : 0.f;
+    const float val = (a0 < d0 && o < d1 && mm >= 0 && k < K) ? w[((int64_t)a0 * d1 + o) * K + k] : 0.f;
+    wpb[i] = val;
+    reinterpret_cast<unsigned short*>(wpb + nb)[ag_wq_index(a0, m, row, mt, mp)] = (unsigned short)ag_pack_bf16(val, val);
   }
 }
 
@@ -654,9 +907,10 @@ extern "C" int ag_prep_conv_weight(const float* w, float* wpa, float* wpb, int d
                                    int stride, int pad, void* stream) {
   AG_REQUIRE(w && (wpa || wpb), "ag_prep_conv_weight: null tensor");
   AG_REQUIRE(d0 > 0 && d1 > 0 && K > 0 && stride > 0, "ag_prep_conv_weight: bad shape");
-  int64_t n = 0;
-  if (wpa) n = ag_wpa_numel(d0, d1, K);
-  if (wpb && ag_wpb_numel(d0, d1, K, stride) > n) n = ag_wpb_numel(d0, d1, K, stride);
+  int64_t n = 0;     // threads: one per fp32 layout element (each also writes its bf16 image element)
+  if (wpa) n = ag_wq_offset(ag_roundup(d1, 2), K, ag_roundup(d0, 32));
+  const int64_t nbw = ag_wq_offset(ag_roundup(d0, 2), ag_cdiv(K, stride), ag_roundup(d1 * stride, 32));
+  if (wpb && nbw > n) n = nbw;
   hipLaunchKernelGGL(prep_conv_weight_kernel, dim3((unsigned)ag_cdiv64(n, 256)), dim3(256), 0,
                      (hipStream_t)stream, w, wpa, wpb, d0, d1, K, stride, pad);
   AG_CHECK_LAUNCH("ag_prep_conv_weight");

@@ -26,16 +26,25 @@ __global__ __launch_bounds__(256) void weight_norm_fwd_kernel(const ag_wn_desc* 
   const int mt = (d.K + s - 1) / s;
   const int mp = (d.d1 * s + 31) / 32 * 32;
   const bool aligned = d.wpb && ag_scatter_aligned(d.K, s, d.pad);
+  // bf16 images behind the fp32 layouts (common.h ag_wq_*): what the bf16 conv kernel stages
+  unsigned short* qa = d.wpa ? reinterpret_cast<unsigned short*>(d.wpa + ag_wq_offset((d.d1 + 1) & ~1, d.K, d0p32)) : nullptr;
+  unsigned short* qb = d.wpb ? reinterpret_cast<unsigned short*>(d.wpb + ag_wq_offset((d.rows + 1) & ~1, mt, mp)) : nullptr;
   for (int i = lane; i < d.cols; i += 64) {
     const float w = v[i] * sc;
+    const unsigned short wq = (unsigned short)ag_pack_bf16(w, w);
     if (d.w) d.w[(int64_t)r * d.cols + i] = w;
-    if (d.wpa) d.wpa[(int64_t)i * d0p32 + r] = w;  // i = c*K + k
+    const int kk = d.K > 0 ? d.K : 1;
+    const int o = i / kk, k = i - o * kk;          // i = c*K + k
+    if (d.wpa) {
+      d.wpa[(int64_t)i * d0p32 + r] = w;
+      qa[ag_wq_index(o, k, r, d.K, d0p32)] = wq;
+    }
     if (d.wpb) {
-      const int o = i / d.K, k = i - o * d.K;
       int m = k / s;
       const int rr = k - m * s;
       if (aligned) m += ag_scatter_shift(s, d.pad, rr);
       d.wpb[((int64_t)r * mt + m) * mp + o * s + rr] = w;
+      qb[ag_wq_index(r, m, o * s + rr, mt, mp)] = wq;
     }
   }
 }

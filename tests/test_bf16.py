@@ -91,7 +91,9 @@ def test_gemm_bf16_splitk_weight_gradient(K, bf16):
 
 LAYERS = [('conv', 1, 128, 17, 8, 8, 2048), ('convT', 128, 16, 16, 8, 4, 256), ('conv', 49, 64, 9, 4, 4, 2048),
           ('convT', 64, 32, 8, 4, 2, 512), ('conv', 113, 1, 3, 1, 1, 2048), ('conv', 64, 128, 7, 2, 3, 1024),
-          ('conv', 256, 512, 7, 2, 3, 256)]
+          ('conv', 256, 512, 7, 2, 3, 256), ('conv', 17, 64, 9, 4, 4, 2048), ('conv', 256, 256, 7, 2, 3, 250),
+          ('convT', 32, 32, 8, 4, 2, 2048), ('conv', 81, 32, 9, 4, 4, 4096), ('conv', 24, 40, 5, 3, 2, 301),
+          ('convT', 40, 24, 6, 3, 1, 99)]
 
 
 @pytest.mark.parametrize('layer', LAYERS)

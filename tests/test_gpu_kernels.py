@@ -55,6 +55,19 @@ def _mk(kind, cin, cout, k, s, p, lin, B, seed):
     return w, x
 
 
+def _check_bf16_image(wp, n32, cp2, taps):
+    """behind the fp32 layout [cp2][taps][mpad] sits its bf16 image [ceil(cp2/16)][taps][2][mpad][8] (common.h ag_wq_*)"""
+    wp = wp.cpu()
+    mpad = n32 // (cp2 * taps)
+    G = (cp2 + 15) // 16
+    assert wp.numel() == n32 + G * 16 * taps * mpad // 2
+    full = torch.zeros(G * 16, taps, mpad)
+    full[:cp2] = wp[:n32].view(cp2, taps, mpad)
+    want = full.to(torch.bfloat16).view(torch.int16).view(G, 2, 8, taps, mpad).permute(0, 3, 1, 4, 2).contiguous()
+    got = wp[n32:].view(torch.int16).view(G, taps, 2, mpad, 8)
+    assert torch.equal(got, want)
+
+
 @pytest.mark.parametrize('layer', G_LAYERS + D_LAYERS + EDGE_LAYERS)
 def test_conv_forward_backward_data(K, layer):
     kind, cin, cout, k, s, p, lin = layer
@@ -68,10 +81,13 @@ def test_conv_forward_backward_data(K, layer):
     d0, d1, _ = w.shape
     wpa, wpb = torch.zeros(K.wpa_numel(d0, d1, k)).cuda(), torch.zeros(K.wpb_numel(d0, d1, k, s)).cuda()
     K.prep_conv_weight(dev(w), wpa, wpb, s)
-    ra, rb = torch.zeros(wpa.numel()), torch.zeros(wpb.numel())
+    na, nb = KM.wpa_numel(d0, d1, k), KM.wpb_numel(d0, d1, k, s)      # the fp32 layouts; their bf16 images follow
+    ra, rb = torch.zeros(na), torch.zeros(nb)
     KM.prep_conv_weight(w, ra, rb, s)
-    close(wpa, ra, rtol=0, atol=0)
-    close(wpb, rb, rtol=0, atol=0)
+    close(wpa[:na], ra, rtol=0, atol=0)
+    close(wpb[:nb], rb, rtol=0, atol=0)
+    _check_bf16_image(wpa, na, (d1 + 1) // 2 * 2, k)
+    _check_bf16_image(wpb, nb, (d0 + 1) // 2 * 2, (k + s - 1) // s)
     fwd_mode = 0 if kind == 'conv' else 1
     fwd_wp, bwd_wp = (wpa, wpb) if kind == 'conv' else (wpb, wpa)
     # forward, full epilogue
@@ -96,9 +112,10 @@ def test_conv_forward_backward_data(K, layer):
     # the scatter layout prepared FOR this padding (aligned phases, one column range): same results
     wpb2 = torch.zeros(wpb.numel()).cuda()
     K.prep_conv_weight(dev(w), None, wpb2, s, pad=p)
-    rb2 = torch.zeros(wpb.numel())
+    rb2 = torch.zeros(nb)
     KM.prep_conv_weight(w, None, rb2, s, pad=p)
-    close(wpb2, rb2, rtol=0, atol=0)
+    close(wpb2[:nb], rb2, rtol=0, atol=0)
+    _check_bf16_image(wpb2, nb, (d0 + 1) // 2 * 2, (k + s - 1) // s)
     if kind == 'conv':
         dx2 = dev(torch.randn(B, cin, lin, generator=gen))
         base = dx2.clone()
@@ -228,17 +245,23 @@ def test_weight_norm(K):
         v = torch.randn(sh, generator=gen)
         g = torch.rand(sh[0], generator=gen) + 0.5
         e = dict(v=v, g=g, w=torch.empty(sh), stride=s)
+        d = {k: (dev(t) if torch.is_tensor(t) else t) for k, t in e.items()}
         if len(sh) == 3:
-            e['wpa'] = torch.zeros(K.wpa_numel(sh[0], sh[1], sh[2]))
-            e['wpb'] = torch.zeros(K.wpb_numel(sh[0], sh[1], sh[2], s))
+            e['wpa'] = torch.zeros(KM.wpa_numel(sh[0], sh[1], sh[2]))
+            e['wpb'] = torch.zeros(KM.wpb_numel(sh[0], sh[1], sh[2], s))
+            d['wpa'] = torch.zeros(K.wpa_numel(sh[0], sh[1], sh[2])).cuda()      # fp32 layout + its bf16 image
+            d['wpb'] = torch.zeros(K.wpb_numel(sh[0], sh[1], sh[2], s)).cuda()
         ents_c.append(e)
-        ents_d.append({k: (dev(t) if torch.is_tensor(t) else t) for k, t in e.items()})
+        ents_d.append(d)
     KM.weight_norm_fwd(ents_c)
     K.weight_norm_fwd(ents_d)
-    for a, b in zip(ents_d, ents_c):
+    for a, b, sh, s in zip(ents_d, ents_c, shapes, strides):
         for k in ('w', 'wpa', 'wpb'):
             if k in b:
-                close(a[k], b[k], rtol=1e-5, msg=k)
+                close(a[k][:b[k].numel()], b[k], rtol=1e-5, msg=k)
+        if len(sh) == 3:
+            _check_bf16_image(a['wpa'], b['wpa'].numel(), (sh[1] + 1) // 2 * 2, sh[2])
+            _check_bf16_image(a['wpb'], b['wpb'].numel(), (sh[0] + 1) // 2 * 2, (sh[2] + s - 1) // s)
     bd, bc = [], []
     for e in ents_c:
         dw = torch.randn(e['v'].shape, generator=gen)

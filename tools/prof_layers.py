@@ -6,6 +6,8 @@ import sys, torch
 sys.path.insert(0, '.')
 import audiogan_amd.kernels as K
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+PREC = sys.argv[2] if len(sys.argv) > 2 else 'f32'
+K.set_precision(PREC)
 LAYERS = [('G1.conv', 'conv', 1, 128, 17, 8, 8, 8192), ('G1.deconv', 'convt', 128, 16, 16, 8, 4, 1024),
           ('G2.conv', 'conv', 17, 64, 9, 4, 4, 8192), ('G2.deconv', 'convt', 64, 32, 8, 4, 2, 2048),
           ('G3.conv', 'conv', 49, 64, 9, 4, 4, 8192), ('G3.deconv', 'convt', 64, 32, 8, 4, 2, 2048),
@@ -28,7 +30,7 @@ def timed(fn):
     return best
 
 
-print('batch %d, fp32; TF = algorithmic TFLOP/s (peak %.1f), GB/s = algorithmic bytes / time (peak %.0f)' % (B, PEAK_TF, PEAK_GBS))
+print('batch %d, %s; TF = algorithmic TFLOP/s (peak %.1f), GB/s = algorithmic bytes / time (peak %.0f)' % (B, PREC, PEAK_TF, PEAK_GBS))
 print('%-10s %-5s %9s %7s %7s %8s' % ('layer', 'pass', 'us', 'TF', 'GB/s', 'bound'))
 tot = {}
 for name, kind, cin, cout, k, s, p, lin in LAYERS:
