@@ -18,6 +18,7 @@
 //   y[o, u] = sum_{c, m} W[c, o, r + s*m] * x[c, q - m]
 // i.e. a stride-1 gather over ceil(K/s) taps whose "rows" are (o, r) pairs.
 #include "common.h"
+#include <type_traits>
 
 #define MAX_TAPS 32
 
@@ -37,6 +38,7 @@ struct ConvP {
   int n_cnt;      // number of columns
   int xvec;       // input rows may be read with aligned 16-byte loads
   int aligned;    // mode 1: aligned scatter layout (common.h) - phase r's outputs are shifted by -s * shift_r
+  int pipe;       // fp32 kernel: register-pipelined staging (see the kernel)
   int nbuf;       // bf16 kernel: LDS buffers (1 when the whole reduction is one chunk)
   int rb;         // AG_PREC_BF16: both operands rounded to bf16 while staging (fp32 MFMA on rounded values)
   int tapoff[MAX_TAPS];
@@ -46,6 +48,7 @@ struct ConvP {
 // guaranteed to be 4-byte aligned (gfx950 global accesses need dword alignment only)
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
+typedef unsigned cu32x4 __attribute__((ext_vector_type(4)));
 
 // Epilogue shared by the fp32 and the bf16 kernels (same 32x32 accumulator layout): bias + residual + activation +
 // length mask (+ accumulate).
@@ -87,8 +90,19 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[TILE
   // are the contiguous window [s*(n-a-1), +s) ROTATED by rho (pad = s*a + rho).  s == 2 (the critic's convs): the
   // two phases of a channel are a swapped pair -> still one 8-byte store; other strides: one row at a time.
   const int rho = a.pad % s;
-  const int VW = p.aligned ? (s == 2 ? 2 : 1) : ((s % 4 == 0) ? 4 : ((s % 2 == 0) ? 2 : 1));
+  // Aligned layout with s % 4 == 0 (the generator's transposed convs): a lane's 4 consecutive rows are 4 consecutive
+  // positions of one channel again - directly when rho % 4 == 0 (all four on the same side of rho), and for s == 4 as
+  // the 16-byte window [4*(n-1) - (pad-rho), +4) rotated by rho.  Either way ONE aligned 16-byte store.
+  const bool rot4 = p.aligned && s == 4;
+  const bool al4 = p.aligned && s % 4 == 0 && rho % 4 == 0;
+  const int rot = rot4 ? rho : 0;
+  const int VW = p.aligned ? (s == 2 ? 2 : ((rot4 || al4) ? 4 : 1)) : ((s % 4 == 0) ? 4 : ((s % 2 == 0) ? 2 : 1));
   const bool swap2 = p.aligned && s == 2;
+  auto u0_of = [&](int r, int n) {
+    if (swap2) return 2 * n - a.pad - 1;
+    if (rot4) return 4 * (n - 1) - (a.pad - rho);
+    return s * (n - ((p.aligned && r >= rho) ? 1 : 0)) + r - a.pad;
+  };
   // stride % 4 == 0 (the generator's transposed convs and the backward of its strided convs): the residual - or
   // for `accumulate` the old output - of a whole row tile is requested up front, one 16-byte load per group.
   // Inside the per-group branches below every such load is followed by its own wait: 16 dependent round trips
@@ -107,7 +121,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[TILE
         const int o = rowb / s, r = rowb - o * s;
 #pragma unroll
         for (int j = 0; j < TILES_T; ++j) {
-          const int u0 = s * (n0 + wcol0 + 32 * j + l31) + r - a.pad;
+          const int u0 = u0_of(r, n0 + wcol0 + 32 * j + l31);
           const bool ok = rowb < p.Mrows && u0 >= 0 && u0 + 4 <= a.Lout;
           pre[g][j] = *reinterpret_cast<const f32x4u*>(ok ? pb + (int64_t)o * pcs + u0 : pb);
         }
@@ -125,13 +139,17 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[TILE
           const int row = rowb + sub;
           if (row >= p.Mrows) break;
           const int o = row / s, r = row - o * s;
-          const int u0 = swap2 ? (2 * n - a.pad - 1)
-                               : (s * (n - ((p.aligned && r >= rho) ? 1 : 0)) + r - a.pad);
+          const int u0 = u0_of(r, n);
           const float bo = bias_s[row - row0];
           float* dst = yb + (int64_t)o * a.y_cs + u0;
           const float* rsrc = rb ? rb + (int64_t)o * a.res_cs + u0 : nullptr;
           float v[4];
-          if (VW == 4) { v[0] = v4[0] + bo; v[1] = v4[1] + bo; v[2] = v4[2] + bo; v[3] = v4[3] + bo; }
+          if (VW == 4) {
+            if (rot == 0) { v[0] = v4[0] + bo; v[1] = v4[1] + bo; v[2] = v4[2] + bo; v[3] = v4[3] + bo; }
+            else if (rot == 1) { v[0] = v4[1] + bo; v[1] = v4[2] + bo; v[2] = v4[3] + bo; v[3] = v4[0] + bo; }
+            else if (rot == 2) { v[0] = v4[2] + bo; v[1] = v4[3] + bo; v[2] = v4[0] + bo; v[3] = v4[1] + bo; }
+            else { v[0] = v4[3] + bo; v[1] = v4[0] + bo; v[2] = v4[1] + bo; v[3] = v4[2] + bo; }
+          }
           else if (VW == 2) {
             const float e0 = sub ? v4[2] : v4[0], e1 = sub ? v4[3] : v4[1];      // phases 0, 1 of channel o
             v[0] = (swap2 ? e1 : e0) + bo; v[1] = (swap2 ? e0 : e1) + bo; v[2] = v[3] = 0.f;
@@ -174,7 +192,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[TILE
 // TAPS/S0 > 0: taps and polyphase factor known at compile time (tap loop fully unrolled, LDS
 // offsets are immediates).  S0 = stride for mode 0, 0 for mode 1.  TAPS == 0: generic runtime loop.
 template <int TILES_O, int TILES_T, int WAVES_O, int WAVES_T, int TAPS, int S0>
-__global__ __launch_bounds__(512) void conv_engine_kernel(const ConvP p) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void conv_engine_kernel(const ConvP p) {
   // 8 waves: waves 0-3 run the MFMAs of chunk i out of LDS buffer i&1 while waves 4-7 stage
   // chunk i+1 (global -> LDS, polyphase de-interleave) into the other buffer; one barrier per
   // chunk.  Staging VALU/VMEM work co-issues with the MFMA pipe of the compute waves.
@@ -304,113 +322,136 @@ __global__ __launch_bounds__(512) void conv_engine_kernel(const ConvP p) {
     const int row = row0 + tid;
     bias_s[tid] = (a.bias && row < p.Mrows) ? a.bias[a.mode == 0 ? row : row / a.stride] : 0.f;
   }
-  stage(0, 0, wid, 8);
-  __syncthreads();
+  // p.pipe (host: 16-byte input pieces lie entirely inside or outside the signal, a chunk is one round of loads per
+  // staging lane, 31-bit byte offsets): the staging waves run a register pipeline - the loads of chunk i+2 are in
+  // flight while chunk i+1 is written to LDS and chunk i is multiplied.  Otherwise: generic staging, chunk 0 by all
+  // 8 waves.
+  if (!p.pipe) {
+    stage(0, 0, wid, 8);
+    __syncthreads();
+  }
   // Both waves of a SIMD share its VALU issue, arbitrated by priority, then age: the staging waves (4-7, the
   // younger half) would only get the slots the MFMA waves leave over and a chunk's staging would take
   // longer than its MFMAs.  Their instruction count is small, so give them priority for the whole loop.
   if (__builtin_amdgcn_readfirstlane(threadIdx.x) >= 256) {
     __builtin_amdgcn_s_setprio(2);
-    // staging waves: their own loop (one barrier per chunk, like the MFMA waves), so that no accumulator
-    // register is live here and a whole chunk's loads fit in flight at once
-    // Fast path: with 16-byte pieces that are entirely inside or entirely outside the signal (Lin % 4 == 0) and a
-    // chunk that fits one round of loads, every lane's source offsets, LDS targets and predicates are the same
-    // for every chunk.  They are computed ONCE here; per chunk the staging waves then issue plain loads off two
-    // moving base pointers and masked LDS writes - the integer divisions of the generic path (which compete with
-    // the MFMA waves for the SIMD's issue slots) leave the loop.
-    // 16-byte pieces per lane (one round of loads): input / weights.  Narrow row tiles stage mostly input
-    // (wide time tile, stride-s window), wide ones mostly weights (launch_cfg trims the chunk to these).
+    if (!p.pipe) {
+      for (int ci = 0; ci < nchunk; ++ci) {
+        if (ci + 1 < nchunk) stage((ci + 1) * p.CC, (ci + 1) & 1, cw, 4);
+        __syncthreads();
+      }
+      return;
+    }
+    // 16-byte pieces per lane and chunk: input / weights.  Narrow row tiles stage mostly input (wide time tile,
+    // stride-s window), wide ones mostly weights (launch_cfg sizes the chunk to these).
     constexpr int FX = OT <= 32 ? 7 : 4, FW = OT <= 32 ? 3 : 8;
+    // Buffer loads: a 32-bit offset per piece, and everything that must read as zero (halo outside the signal,
+    // channels >= C, rows >= Mpad) carries an offset past num_records.  Every lane's offsets, LDS targets and
+    // predicates are the same for every chunk up to a uniform per-chunk increment: computed once.
+    const unsigned OOB = 0x80000000u;
+    __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, (int)((int64_t)a.C * a.x_cs * 4), 0x00020000);
+    __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wp), 0, (int)((int64_t)p.Cpad * taps * p.Mpad * 4), 0x00020000);
+    const int sl = cw * 64 + lane;
     const int base4 = base - (((base % 4) + 4) % 4);
     const int nq = (base - base4 + span + 3) / 4;
     const int xtot = p.CC * nq, wtot = p.CC * taps * (OT / 4);
-    int nfast = 0;                      // full chunks after chunk 0 (all CC channels exist)
-    while (nfast + 1 < nchunk && (nfast + 2) * p.CC <= a.C) ++nfast;
-    // (the per-lane set-up below is not worth a single chunk)
-    const bool fastp = nfast >= 2 && p.xvec && (a.Lin % 4 == 0) && a.Lin >= 4 && xtot <= FX * 256 && wtot <= FW * 256 &&
-                       (int64_t)p.CC * a.x_cs < (1 << 30);
-    int xsrc[FX], wsrc[FW];       // source offsets (xsrc < 0: piece outside the signal -> zeros)
-    int xl[FX][4], wl[FW];        // LDS targets (-1: no write)
-    if (fastp) {
+    unsigned xoff[FX], woff[FW];
+    unsigned xlp[FX][2];          // LDS targets of a piece's 4 samples, two 16-bit float indices per register (0xffff: no write)
 #pragma unroll
-      for (int u = 0; u < FX; ++u) {
-        const int e = cw * 64 + lane + u * 256;
-        const bool valid = e < xtot;
-        const int cc = valid ? e / nq : 0, i4 = valid ? e - cc * nq : 0;
-        const int g = base4 + 4 * i4;
-        const bool inr = g >= 0 && g + 3 < a.Lin;
-        xsrc[u] = (valid && inr) ? (int)(cc * a.x_cs) + g : -1;
+    for (int u = 0; u < FX; ++u) {
+      const int e = sl + u * 256;
+      const bool valid = e < xtot;
+      const int cc = valid ? e / nq : 0, i4 = valid ? e - cc * nq : 0;
+      const int g = base4 + 4 * i4;
+      xoff[u] = (valid && g >= 0 && g + 3 < a.Lin) ? (unsigned)((cc * (int)a.x_cs + g) * 4) : OOB;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int rem = g + q - base;
-          int off = -1;
-          if (valid && rem >= 0 && rem < span) {
-            int r, qq;
-            if (S0 > 0) {
-              r = rem % SD;
-              qq = rem / SD;
-            } else if (TAPS > 0) {
-              r = 0;
-              qq = rem;
-            } else if (p.sp_shift >= 0) {
-              r = rem & (p.sp - 1);
-              qq = rem >> p.sp_shift;
-            } else {
-              qq = rem / p.sp;
-              r = rem - qq * p.sp;
-            }
-            off = cc * chs + r * rowlen + qq;
+      for (int q = 0; q < 4; ++q) {
+        const int rem = g + q - base;
+        int off = -1;
+        if (valid && rem >= 0 && rem < span) {
+          int r, qq;
+          if (S0 > 0) {
+            r = rem % SD;
+            qq = rem / SD;
+          } else if (TAPS > 0) {
+            r = 0;
+            qq = rem;
+          } else if (p.sp_shift >= 0) {
+            r = rem & (p.sp - 1);
+            qq = rem >> p.sp_shift;
+          } else {
+            qq = rem / p.sp;
+            r = rem - qq * p.sp;
           }
-          xl[u][q] = off;
+          off = cc * chs + r * rowlen + qq;
         }
-      }
-#pragma unroll
-      for (int u = 0; u < FW; ++u) {
-        const int idx = cw * 64 + lane + u * 256;
-        const int r4 = idx % (OT / 4), ct = idx / (OT / 4);
-        const int row = row0 + r4 * 4;
-        const bool ok = idx < wtot && row < p.Mpad;
-        wsrc[u] = ok ? ct * p.Mpad + row : 0;
-        wl[u] = ok ? ct * OT + r4 * 4 : -1;
+        if (q & 1) xlp[u][q >> 1] |= (unsigned)(off & 0xffff) << 16;
+        else xlp[u][q >> 1] = (unsigned)(off & 0xffff);
       }
     }
-    // chunks 1 .. nfast are full (all CC channels exist) and take the fast path; the generic path finishes
-    // (at most the last, partial chunk - in a loop of its own so that the state above is dead there)
-    if (!fastp) nfast = 0;
-    int ci = 0;
-    for (; ci < nfast; ++ci) {
-      const int c0 = (ci + 1) * p.CC;
-      float* xs = smem + ((ci + 1) & 1) * bufsz;
+#pragma unroll
+    for (int u = 0; u < FW; ++u) {
+      const int idx = sl + u * 256;
+      const int r4 = idx % (OT / 4), ct = idx / (OT / 4);
+      const int row = row0 + r4 * 4;
+      woff[u] = (idx < wtot && row < p.Mpad) ? (unsigned)((ct * p.Mpad + row) * 4) : OOB;
+    }
+    const unsigned xstep = (unsigned)p.CC * (unsigned)a.x_cs * 4u, wstep = (unsigned)(p.CC * taps * p.Mpad) * 4u;
+    cu32x4 xv[FX], wv[FW];
+    auto load = [&](int ci) {
+#pragma unroll
+      for (int u = 0; u < FX; ++u) xv[u] = __builtin_amdgcn_raw_buffer_load_b128(xr, xoff[u] + (unsigned)ci * xstep, 0, 0);
+#pragma unroll
+      for (int u = 0; u < FW; ++u) wv[u] = __builtin_amdgcn_raw_buffer_load_b128(wr, woff[u] + (unsigned)ci * wstep, 0, 0);
+    };
+    auto write_t = [&](int buf, auto rbtag) {
+      constexpr bool RB = decltype(rbtag)::value;
+      float* xs = smem + buf * bufsz;
       float* ws = xs + (size_t)p.CC * chs;
-      const float* xc0 = xb + (int64_t)c0 * a.x_cs;
-      const float* wc0 = a.wp + (int64_t)c0 * taps * p.Mpad;
-      f32x4 xv[FX], wv[FW];
+      f32x4 xf[FX], wf[FW];
 #pragma unroll
-      for (int u = 0; u < FX; ++u) xv[u] = *reinterpret_cast<const f32x4*>(xc0 + max(xsrc[u], 0));
+      for (int u = 0; u < FX; ++u) xf[u] = __builtin_bit_cast(f32x4, xv[u]);
 #pragma unroll
-      for (int u = 0; u < FW; ++u) wv[u] = *reinterpret_cast<const f32x4*>(wc0 + wsrc[u]);
-      if (p.rb) {      // AG_PREC_BF16 (uniform branch)
+      for (int u = 0; u < FW; ++u) wf[u] = __builtin_bit_cast(f32x4, wv[u]);
+      if (RB) {      // AG_PREC_BF16
 #pragma unroll
-        for (int u = 0; u < FX; ++u) xv[u] = ag_rbf4_if(xv[u], 1);
+        for (int u = 0; u < FX; ++u) xf[u] = ag_rbf4_if(xf[u], 1);
 #pragma unroll
-        for (int u = 0; u < FW; ++u) wv[u] = ag_rbf4_if(wv[u], 1);
+        for (int u = 0; u < FW; ++u) wf[u] = ag_rbf4_if(wf[u], 1);
       }
 #pragma unroll
       for (int u = 0; u < FX; ++u)
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-          if (xl[u][q] >= 0) xs[xl[u][q]] = xsrc[u] < 0 ? 0.f : xv[u][q];
+        for (int q = 0; q < 4; ++q) {
+          const unsigned off = (xlp[u][q >> 1] >> (16 * (q & 1))) & 0xffffu;
+          if (off != 0xffffu) xs[off] = xf[u][q];
+        }
 #pragma unroll
-      for (int u = 0; u < FW; ++u)
-        if (wl[u] >= 0) *reinterpret_cast<f32x4*>(ws + wl[u]) = wv[u];
-      __syncthreads();
-    }
-    for (; ci < nchunk; ++ci) {
-      if (ci + 1 < nchunk) stage((ci + 1) * p.CC, (ci + 1) & 1, cw, 4);
+      for (int u = 0; u < FW; ++u) {
+        const int idx = sl + u * 256;                    // LDS target ct * OT + 4 * r4 == 4 * idx
+        if (idx < wtot) *reinterpret_cast<f32x4*>(ws + 4 * idx) = wf[u];
+      }
+    };
+    // (two instantiations under one uniform branch: rounding in place under `if (p.rb)` made the allocator keep both
+    // versions of every piece live - 48 more registers, one wave per SIMD less)
+    auto write = [&](int buf) {
+      if (p.rb) write_t(buf, std::true_type{});
+      else write_t(buf, std::false_type{});
+    };
+    load(0);
+    write(0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (nchunk > 1) load(1);
+    __syncthreads();
+    for (int ci = 0; ci < nchunk; ++ci) {
+      if (ci + 1 < nchunk) write((ci + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);      // (the loads below reuse the registers just written out: no hoisting)
+      if (ci + 2 < nchunk) load(ci + 2);
       __syncthreads();
     }
     return;
   }
+  if (p.pipe) __syncthreads();      // chunk 0 staged
   f32x16 acc[TILES_O][TILES_T];
 #pragma unroll
   for (int i = 0; i < TILES_O; ++i)
@@ -479,7 +520,6 @@ __global__ __launch_bounds__(512) void conv_engine_kernel(const ConvP p) {
 // Results equal the rounding emulation in the fp32 kernel up to fp32 summation order (products of bf16 values are exact
 // in fp32; the MFMA accumulates in fp32).
 typedef short cbf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned cu32x4 __attribute__((ext_vector_type(4)));
 // Per staging lane and chunk: NW weight slots and CB_NX input tasks (8 channels x 4 positions).  NW = 16 is the deep-reduction
 // variant (>= 8 channel groups, 128-row tiles): one workgroup per CU, two 16-channel groups per chunk - the chunk in
 // flight, not a co-resident workgroup, covers the memory latency.
@@ -662,6 +702,7 @@ extern "C" int64_t ag_wpb_numel(int d0, int d1, int K, int stride) {
   return ag_wq_offset(cp2, mt, mp) + ag_wq_floats(cp2, mt, mp);
 }
 
+static const bool g_conv_pipe = [] { const char* e = getenv("AG_CONV_PIPE"); return !(e && e[0] == '0'); }();
 // AG_CONV_BF16_MFMA=0 keeps the fp32-MFMA rounding emulation in bf16 mode (A/B measurements)
 static const bool g_conv_bf16_mfma = [] { const char* e = getenv("AG_CONV_BF16_MFMA"); return !(e && e[0] == '0'); }();
 
@@ -751,14 +792,21 @@ static int launch_cfg(ConvP& p, hipStream_t st) {
   if (cc < 2) cc = 2;
   if (cc > 32) cc = 32;
   if (cc > p.Cpad) cc = p.Cpad;
-  // the staging waves' fast path holds FX input and FW weight 16-byte pieces per lane (256 lanes; 7/3 for 32-row tiles, else 4/8
-  // by row-tile height): trim the chunk to that when it costs at most a third of the channels
-  {
+  // Register-pipelined staging: a chunk is one round of loads for the 256 staging lanes (FX input and FW weight
+  // 16-byte pieces each: 7/3 for 32-row tiles, else 4/8), pieces lie entirely inside or outside the signal, offsets
+  // fit 31 bits.  The chunk is trimmed to that round.
+  p.pipe = 0;
+  if (p.xvec && a.Lin % 4 == 0 && a.Lin >= 4 && (int64_t)a.C * a.x_cs * 4 < ((int64_t)1 << 31) &&
+      (int64_t)p.Cpad * p.taps * p.Mpad * 4 < ((int64_t)1 << 31) && g_conv_pipe) {
     const int nq = (p.sp * p.ncols + 6) / 4 + 1;
     int cf = cc;
     constexpr int FXH = OT <= 32 ? 7 : 4, FWH = OT <= 32 ? 3 : 8;   // = the kernel's FX, FW
     while (cf > 2 && (cf * nq > FXH * 256 || cf * p.taps * (OT / 4) > FWH * 256)) cf -= 2;
-    if (3 * cf >= 2 * cc) cc = cf;
+    // (a reduction that is a single chunk has nothing to overlap: chunk 0 by all 8 waves is quicker)
+    if (cf * nq <= FXH * 256 && cf * p.taps * (OT / 4) <= FWH * 256 && cf < p.Cpad) {
+      cc = cf;
+      p.pipe = 1;
+    }
   }
   p.CC = cc;
   const size_t lds = 2 * (size_t)cc * per_c + (size_t)OT * sizeof(float);   // two buffers + the bias of the row tile
