@@ -38,6 +38,9 @@ struct ConvP {
   int n_cnt;      // number of columns
   int xvec;       // input rows may be read with aligned 16-byte loads
   int aligned;    // mode 1: aligned scatter layout (common.h) - phase r's outputs are shifted by -s * shift_r
+  int efast;      // the buffer-addressed epilogue applies (31-bit byte offsets)
+  int s_shift;    // log2(stride) or -1
+  int ncols_tile; // columns of the workgroup's tile (TT)
   int pipe;       // fp32 kernel: register-pipelined staging (see the kernel)
   int nbuf;       // bf16 kernel: LDS buffers (1 when the whole reduction is one chunk)
   int rb;         // AG_PREC_BF16: both operands rounded to bf16 while staging (fp32 MFMA on rounded values)
@@ -52,141 +55,218 @@ typedef unsigned cu32x4 __attribute__((ext_vector_type(4)));
 
 // Epilogue shared by the fp32 and the bf16 kernels (same 32x32 accumulator layout): bias + residual + activation +
 // length mask (+ accumulate).
+//
+// conv_epilogue_fast is the path almost every tile takes.  It is written for instruction count (an earlier general
+// version spent ~850 instructions per 16-byte store on 64-bit addresses, divisions by the stride and bounds branches:
+// 12-16 us per 128x128 tile, more than the tile's MFMAs): buffer addressing with 32-bit offsets - anything out of
+// range gets an offset past num_records and is dropped / reads 0, no branches -, stride by shift, rows resolved
+// outside the column loop.  It covers mode 0, and mode 1 with s % 4 == 0 (one 16-byte store per lane and group) or the
+// aligned s == 2 layout (8-byte stores) on tiles whose columns all map inside the signal; it returns false when the
+// tile needs conv_epilogue_any - the plain element-by-element form (edge tiles of transposed convs, odd strides,
+// tensors beyond 31-bit offsets).
 template <int TILES_O, int TILES_T>
-__device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[TILES_O][TILES_T], const float* bias_s,
-                                              int b, int row0, int n0, int wrow0, int wcol0, int l31, int h) {
+__device__ __forceinline__ bool conv_epilogue_fast(const ConvP& p, f32x16 (&acc)[TILES_O][TILES_T], const float* bias_s,
+                                                   int b, int row0, int n0, int wrow0, int wcol0, int l31, int h) {
   const ag_conv_args& a = p.a;
-  const int64_t lenb = a.lens_i64 ? a.lens_i64[b] : (int64_t)1 << 60;
-  float* yb = a.y + (int64_t)b * a.y_bs;
-  const float* rb = a.res ? a.res + (int64_t)b * a.res_bs : nullptr;
+  if (!p.efast) return false;
+  const unsigned OOB = 0x80000000u;
+  const int ycs = (int)a.y_cs, rcs = (int)a.res_cs;
+  int lenb = 0x7fffffff;
+  if (a.lens_i64) {
+    const int64_t l = a.lens_i64[b];
+    lenb = l > 0x7fffffff ? 0x7fffffff : (int)l;
+  }
+  __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(a.y + (int64_t)b * a.y_bs, 0, (int)((int64_t)a.O * a.y_cs * 4), 0x00020000);
+  __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.res ? a.res + (int64_t)b * a.res_bs : a.y), 0, a.res ? (int)((int64_t)a.O * a.res_cs * 4) : 0, 0x00020000);
+  const bool has_res = a.res != nullptr;
   if (a.mode == 0) {
 #pragma unroll
     for (int i = 0; i < TILES_O; ++i) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const int o = row0 + wrow0 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
-        if (o >= p.Mrows) continue;
-        const float bo = bias_s[o - row0];
+        const int ro = wrow0 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
+        const int o = row0 + ro;
+        const bool valid = o < p.Mrows;
+        const float bo = bias_s[ro];
+        const int rowy = o * ycs, rowr = o * rcs;
 #pragma unroll
         for (int j = 0; j < TILES_T; ++j) {
           const int t = n0 + wcol0 + 32 * j + l31;
-          if (t >= a.Lout) continue;
+          const bool ok = valid && t < a.Lout;
+          const unsigned yo = ok ? (unsigned)((rowy + t) * 4) : OOB;
           float v = acc[i][j][e] + bo;
-          if (rb) v += rb[(int64_t)o * a.res_cs + t];
+          if (has_res) v += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rr, ok ? (unsigned)((rowr + t) * 4) : OOB, 0, 0));
           v = ag_apply_act(v, a.act, a.slope);
           if (t >= lenb) v = 0.f;
-          float* dst = yb + (int64_t)o * a.y_cs + t;
-          if (a.accumulate) v += *dst;
-          *dst = v;
+          if (a.accumulate) v += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(yr, yo, 0, 0));
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), yr, yo, 0, 0);
         }
       }
     }
-    return;
+    return true;
   }
-  // mode 1: row = o*s + r, output position u = s*n + r - pad.  A lane holds 4 consecutive rows in
-  // registers 4g..4g+3, i.e. VW consecutive output positions of one channel -> vector stores.
-  const int s = a.stride;
+  // mode 1: row = o*s + r, output position u = s*n + r - pad; a lane holds 4 consecutive rows in registers 4g..4g+3.
   // Aligned layout (common.h): with rho = pad % s, phases r >= rho sit one column earlier, so the s rows of a channel
-  // are the contiguous window [s*(n-a-1), +s) ROTATED by rho (pad = s*a + rho).  s == 2 (the critic's convs): the
-  // two phases of a channel are a swapped pair -> still one 8-byte store; other strides: one row at a time.
+  // are the contiguous window [s*(n-a-1), +s) ROTATED by rho (pad = s*a + rho).
+  const int s = a.stride;
   const int rho = a.pad % s;
-  // Aligned layout with s % 4 == 0 (the generator's transposed convs): a lane's 4 consecutive rows are 4 consecutive
-  // positions of one channel again - directly when rho % 4 == 0 (all four on the same side of rho), and for s == 4 as
-  // the 16-byte window [4*(n-1) - (pad-rho), +4) rotated by rho.  Either way ONE aligned 16-byte store.
-  const bool rot4 = p.aligned && s == 4;
-  const bool al4 = p.aligned && s % 4 == 0 && rho % 4 == 0;
-  const int rot = rot4 ? rho : 0;
-  const int VW = p.aligned ? (s == 2 ? 2 : ((rot4 || al4) ? 4 : 1)) : ((s % 4 == 0) ? 4 : ((s % 2 == 0) ? 2 : 1));
-  const bool swap2 = p.aligned && s == 2;
-  auto u0_of = [&](int r, int n) {
-    if (swap2) return 2 * n - a.pad - 1;
-    if (rot4) return 4 * (n - 1) - (a.pad - rho);
-    return s * (n - ((p.aligned && r >= rho) ? 1 : 0)) + r - a.pad;
-  };
-  // stride % 4 == 0 (the generator's transposed convs and the backward of its strided convs): the residual - or
-  // for `accumulate` the old output - of a whole row tile is requested up front, one 16-byte load per group.
-  // Inside the per-group branches below every such load is followed by its own wait: 16 dependent round trips
-  // per workgroup, more than the MFMA loop of these thin layers takes.
-  const bool pre_res = VW == 4 && rb != nullptr;
-  const bool pre_acc = VW == 4 && !pre_res && a.accumulate;
+  const bool rot4 = p.aligned && s == 4;                          // 16-byte window rotated by rho
+  const bool al4 = p.aligned && s % 4 == 0 && rho % 4 == 0;       // 4 rows on the same side of rho: plain
+  const bool sw2 = p.aligned && s == 2;                           // the critic's convs: swapped pairs, 8-byte stores
+  if (!sw2 && (s % 4 != 0 || (p.aligned && !rot4 && !al4))) return false;
+  {   // every column of the workgroup's tile inside the signal?  (uniform)
+    const int nlo = n0, nhi = n0 + p.ncols_tile - 1;
+    int lo, hi;
+    if (sw2) { lo = 2 * nlo - a.pad - 1; hi = 2 * nhi - a.pad + 1; }
+    else if (rot4) { lo = 4 * (nlo - 1) - (a.pad - rho); hi = 4 * nhi - (a.pad - rho); }
+    else if (p.aligned) { lo = s * (nlo - 1) + rho - a.pad; hi = s * nhi + rho - a.pad; }
+    else { lo = s * nlo - a.pad; hi = s * (nhi + 1) - a.pad; }
+    if (lo < 0 || hi > a.Lout) return false;
+  }
+  const bool need_pre = has_res || a.accumulate;
+  if (sw2) {
 #pragma unroll
-  for (int i = 0; i < TILES_O; ++i) {
-    f32x4u pre[4][TILES_T];
-    if (pre_res || pre_acc) {
-      const float* pb = pre_res ? rb : yb;
-      const int64_t pcs = pre_res ? a.res_cs : a.y_cs;
+    for (int i = 0; i < TILES_O; ++i) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int rowb = row0 + wrow0 + 32 * i + 8 * g + 4 * h;
-        const int o = rowb / s, r = rowb - o * s;
+        const int ro = wrow0 + 32 * i + 8 * g + 4 * h;      // rows ro..ro+3 = (o, phase 0), (o, 1), (o+1, 0), (o+1, 1)
+        const int o = (row0 + ro) >> 1;
 #pragma unroll
-        for (int j = 0; j < TILES_T; ++j) {
-          const int u0 = u0_of(r, n0 + wcol0 + 32 * j + l31);
-          const bool ok = rowb < p.Mrows && u0 >= 0 && u0 + 4 <= a.Lout;
-          pre[g][j] = *reinterpret_cast<const f32x4u*>(ok ? pb + (int64_t)o * pcs + u0 : pb);
+        for (int c2 = 0; c2 < 2; ++c2) {
+          const bool valid = row0 + ro + 2 * c2 < p.Mrows;
+          const float bo = bias_s[ro + 2 * c2];
+          const int rowy = (o + c2) * ycs, rowr = (o + c2) * rcs;
+#pragma unroll
+          for (int j = 0; j < TILES_T; ++j) {
+            const int u0 = 2 * (n0 + wcol0 + 32 * j + l31) - a.pad - 1;
+            const unsigned yo = valid ? (unsigned)((rowy + u0) * 4) : OOB;
+            float v0 = acc[i][j][4 * g + 2 * c2 + 1] + bo, v1 = acc[i][j][4 * g + 2 * c2] + bo;     // swapped pair
+            if (has_res) {
+              const unsigned ro_ = valid ? (unsigned)((rowr + u0) * 4) : OOB;
+              v0 += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rr, ro_, 0, 0));
+              v1 += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rr, ro_ + 4u, 0, 0));
+            }
+            v0 = ag_apply_act(v0, a.act, a.slope);
+            v1 = ag_apply_act(v1, a.act, a.slope);
+            if (u0 >= lenb) v0 = 0.f;
+            if (u0 + 1 >= lenb) v1 = 0.f;
+            if (a.accumulate) {
+              v0 += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(yr, yo, 0, 0));
+              v1 += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(yr, yo + 4u, 0, 0));
+            }
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v0), yr, yo, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v1), yr, yo + 4u, 0, 0);
+          }
         }
+      }
+    }
+    return true;
+  }
+  const int rot = rot4 ? rho : 0;
+#pragma unroll
+  for (int i = 0; i < TILES_O; ++i) {
+    // the residual - or for `accumulate` the old output - of a whole row tile is requested up front (one round trip
+    // instead of 16 dependent ones)
+    unsigned yo[4][TILES_T];
+    cu32x4 pre[4][TILES_T];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int rowb = row0 + wrow0 + 32 * i + 8 * g + 4 * h;
+      const bool valid = rowb < p.Mrows;
+      const int o = p.s_shift >= 0 ? (rowb >> p.s_shift) : rowb / s;
+      const int r = rowb - o * s;
+      const int rowy = o * ycs, rowr = o * rcs;
+#pragma unroll
+      for (int j = 0; j < TILES_T; ++j) {
+        const int n = n0 + wcol0 + 32 * j + l31;
+        const int u0 = rot4 ? 4 * (n - 1) - (a.pad - rho) : s * (n - ((p.aligned && r >= rho) ? 1 : 0)) + r - a.pad;
+        yo[g][j] = valid ? (unsigned)((rowy + u0) * 4) : OOB;
+        if (need_pre)
+          pre[g][j] = has_res ? __builtin_amdgcn_raw_buffer_load_b128(rr, valid ? (unsigned)((rowr + u0) * 4) : OOB, 0, 0)
+                              : __builtin_amdgcn_raw_buffer_load_b128(yr, yo[g][j], 0, 0);
       }
     }
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const int rowb = row0 + wrow0 + 32 * i + 8 * g + 4 * h;
-      if (rowb >= p.Mrows) continue;
+      const int ro = wrow0 + 32 * i + 8 * g + 4 * h;
+      const int rowb = row0 + ro;
+      const int o = p.s_shift >= 0 ? (rowb >> p.s_shift) : rowb / s;
+      const int r = rowb - o * s;
+      const float bo = bias_s[ro];
 #pragma unroll
       for (int j = 0; j < TILES_T; ++j) {
         const int n = n0 + wcol0 + 32 * j + l31;
+        const int u0 = rot4 ? 4 * (n - 1) - (a.pad - rho) : s * (n - ((p.aligned && r >= rho) ? 1 : 0)) + r - a.pad;
         const float v4[4] = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-        for (int sub = 0; sub < 4; sub += VW) {
-          const int row = rowb + sub;
-          if (row >= p.Mrows) break;
-          const int o = row / s, r = row - o * s;
-          const int u0 = u0_of(r, n);
-          const float bo = bias_s[row - row0];
-          float* dst = yb + (int64_t)o * a.y_cs + u0;
-          const float* rsrc = rb ? rb + (int64_t)o * a.res_cs + u0 : nullptr;
-          float v[4];
-          if (VW == 4) {
-            if (rot == 0) { v[0] = v4[0] + bo; v[1] = v4[1] + bo; v[2] = v4[2] + bo; v[3] = v4[3] + bo; }
-            else if (rot == 1) { v[0] = v4[1] + bo; v[1] = v4[2] + bo; v[2] = v4[3] + bo; v[3] = v4[0] + bo; }
-            else if (rot == 2) { v[0] = v4[2] + bo; v[1] = v4[3] + bo; v[2] = v4[0] + bo; v[3] = v4[1] + bo; }
-            else { v[0] = v4[3] + bo; v[1] = v4[0] + bo; v[2] = v4[1] + bo; v[3] = v4[2] + bo; }
-          }
-          else if (VW == 2) {
-            const float e0 = sub ? v4[2] : v4[0], e1 = sub ? v4[3] : v4[1];      // phases 0, 1 of channel o
-            v[0] = (swap2 ? e1 : e0) + bo; v[1] = (swap2 ? e0 : e1) + bo; v[2] = v[3] = 0.f;
-          }
-          else { v[0] = (sub == 0 ? v4[0] : sub == 1 ? v4[1] : sub == 2 ? v4[2] : v4[3]) + bo; v[1] = v[2] = v[3] = 0.f; }
-          const bool full = u0 >= 0 && u0 + VW <= a.Lout;
-          if (full && VW == 4) {
-            if (pre_res) { const f32x4u rv = pre[g][j]; v[0] += rv[0]; v[1] += rv[1]; v[2] += rv[2]; v[3] += rv[3]; }
+        float v[4];
+        if (rot == 0) { v[0] = v4[0]; v[1] = v4[1]; v[2] = v4[2]; v[3] = v4[3]; }
+        else if (rot == 1) { v[0] = v4[1]; v[1] = v4[2]; v[2] = v4[3]; v[3] = v4[0]; }
+        else if (rot == 2) { v[0] = v4[2]; v[1] = v4[3]; v[2] = v4[0]; v[3] = v4[1]; }
+        else { v[0] = v4[3]; v[1] = v4[0]; v[2] = v4[1]; v[3] = v4[2]; }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { v[q] = ag_apply_act(v[q], a.act, a.slope); if (u0 + q >= lenb) v[q] = 0.f; }
-            if (pre_acc) { const f32x4u ov = pre[g][j]; v[0] += ov[0]; v[1] += ov[1]; v[2] += ov[2]; v[3] += ov[3]; }
-            else if (a.accumulate) { const f32x4u ov = *reinterpret_cast<const f32x4u*>(dst); v[0] += ov[0]; v[1] += ov[1]; v[2] += ov[2]; v[3] += ov[3]; }
-            f32x4u out = {v[0], v[1], v[2], v[3]};
-            *reinterpret_cast<f32x4u*>(dst) = out;
-          } else if (full && VW == 2) {
-            if (rsrc) { const f32x2u rv = *reinterpret_cast<const f32x2u*>(rsrc); v[0] += rv[0]; v[1] += rv[1]; }
-#pragma unroll
-            for (int q = 0; q < 2; ++q) { v[q] = ag_apply_act(v[q], a.act, a.slope); if (u0 + q >= lenb) v[q] = 0.f; }
-            if (a.accumulate) { const f32x2u ov = *reinterpret_cast<const f32x2u*>(dst); v[0] += ov[0]; v[1] += ov[1]; }
-            f32x2u out = {v[0], v[1]};
-            *reinterpret_cast<f32x2u*>(dst) = out;
-          } else {
-            for (int q = 0; q < VW; ++q) {
-              const int u = u0 + q;
-              if (u < 0 || u >= a.Lout) continue;
-              float w = v[q];
-              if (rsrc) w += rsrc[q];
-              w = ag_apply_act(w, a.act, a.slope);
-              if (u >= lenb) w = 0.f;
-              if (a.accumulate) w += dst[q];
-              dst[q] = w;
-            }
-          }
+        for (int q = 0; q < 4; ++q) {
+          v[q] += bo;
+          if (has_res) v[q] += __uint_as_float(pre[g][j][q]);
+          v[q] = ag_apply_act(v[q], a.act, a.slope);
+          if (u0 + q >= lenb) v[q] = 0.f;
+          if (!has_res && a.accumulate) v[q] += __uint_as_float(pre[g][j][q]);
         }
+        cu32x4 out = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+        if (has_res && a.accumulate) {
+          const cu32x4 ov = __builtin_amdgcn_raw_buffer_load_b128(yr, yo[g][j], 0, 0);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) out[q] = __float_as_uint(__uint_as_float(out[q]) + __uint_as_float(ov[q]));
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(out, yr, yo[g][j], 0, 0);
       }
     }
   }
+  return true;
+}
+
+// Element by element, every case (see above).  Deliberately plain: it runs on the few tiles the fast form declines.
+template <int TILES_O, int TILES_T>
+__device__ __forceinline__ void conv_epilogue_any(const ConvP& p, f32x16 (&acc)[TILES_O][TILES_T], const float* bias_s,
+                                                  int b, int row0, int n0, int wrow0, int wcol0, int l31, int h) {
+  const ag_conv_args& a = p.a;
+  const int64_t lenb = a.lens_i64 ? a.lens_i64[b] : (int64_t)1 << 60;
+  float* yb = a.y + (int64_t)b * a.y_bs;
+  const float* rb = a.res ? a.res + (int64_t)b * a.res_bs : nullptr;
+  const int s = a.stride;
+  const int rho = a.pad % s;
+#pragma unroll
+  for (int i = 0; i < TILES_O; ++i) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int ro = wrow0 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
+      const int row = row0 + ro;
+      if (row >= p.Mrows) continue;
+      const float bo = bias_s[ro];
+      const int o = a.mode == 0 ? row : row / s;
+      const int r = row - o * s;
+#pragma unroll
+      for (int j = 0; j < TILES_T; ++j) {
+        const int n = n0 + wcol0 + 32 * j + l31;
+        const int u = a.mode == 0 ? n : s * (n - ((p.aligned && r >= rho) ? 1 : 0)) + r - a.pad;
+        if (u < 0 || u >= a.Lout) continue;
+        float v = acc[i][j][e] + bo;
+        if (rb) v += rb[(int64_t)o * a.res_cs + u];
+        v = ag_apply_act(v, a.act, a.slope);
+        if (u >= lenb) v = 0.f;
+        float* dst = yb + (int64_t)o * a.y_cs + u;
+        if (a.accumulate) v += *dst;
+        *dst = v;
+      }
+    }
+  }
+}
+
+template <int TILES_O, int TILES_T>
+__device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[TILES_O][TILES_T], const float* bias_s,
+                                              int b, int row0, int n0, int wrow0, int wcol0, int l31, int h) {
+  if (!conv_epilogue_fast<TILES_O, TILES_T>(p, acc, bias_s, b, row0, n0, wrow0, wcol0, l31, h))
+    conv_epilogue_any<TILES_O, TILES_T>(p, acc, bias_s, b, row0, n0, wrow0, wcol0, l31, h);
 }
 
 // TAPS/S0 > 0: taps and polyphase factor known at compile time (tap loop fully unrolled, LDS
@@ -702,6 +782,7 @@ extern "C" int64_t ag_wpb_numel(int d0, int d1, int K, int stride) {
   return ag_wq_offset(cp2, mt, mp) + ag_wq_floats(cp2, mt, mp);
 }
 
+static const bool g_conv_efast = [] { const char* e = getenv("AG_CONV_EFAST"); return !(e && e[0] == '0'); }();
 static const bool g_conv_pipe = [] { const char* e = getenv("AG_CONV_PIPE"); return !(e && e[0] == '0'); }();
 // AG_CONV_BF16_MFMA=0 keeps the fp32-MFMA rounding emulation in bf16 mode (A/B measurements)
 static const bool g_conv_bf16_mfma = [] { const char* e = getenv("AG_CONV_BF16_MFMA"); return !(e && e[0] == '0'); }();
@@ -749,6 +830,7 @@ static int launch_bf16(ConvP& p, hipStream_t st) {
   constexpr int OT = 32 * TO * WO, TT = 32 * TTL * WT;
   const ag_conv_args& a = p.a;
   const int dmax = (a.mode == 0) ? (a.K - 1) / a.stride : (p.taps - 1);
+  p.ncols_tile = TT;
   p.ncols = TT + dmax;
   p.rowlen = p.ncols;
   p.chs = p.sp * p.rowlen;
@@ -775,6 +857,7 @@ static int launch_cfg(ConvP& p, hipStream_t st) {
   const ag_conv_args& a = p.a;
   // input tile geometry
   const int dmax = (a.mode == 0) ? (a.K - 1) / a.stride : (p.taps - 1);
+  p.ncols_tile = TT;
   p.ncols = TT + dmax;
   int rl = p.ncols;
   if (p.sp_shift >= 0 && p.sp > 1 && p.sp <= 32) {
@@ -815,7 +898,11 @@ static int launch_cfg(ConvP& p, hipStream_t st) {
     return AG_ERR_UNSUPPORTED;
   }
   dim3 grid(ag_cdiv(p.n_cnt, TT), ag_cdiv(p.Mrows, OT), a.B);
-  const int key = a.mode == 0 ? p.taps * 100 + a.stride : p.taps * 100;
+  // (the 64x64 / 128x32 tiles only run the ragged tail columns of transposed convs: no specialisations for them)
+  constexpr bool SPEC = !(TO == 1 && TTL == 1);
+  const int key = !SPEC ? -1 : (a.mode == 0 ? p.taps * 100 + a.stride : p.taps * 100);
+  if constexpr (!SPEC) return launch_one<TO, TTL, WO, WT, 0, 0>(p, lds, grid, st);
+  else
   switch (key) {
     case 1708: return launch_one<TO, TTL, WO, WT, 17, 8>(p, lds, grid, st);  // G1.conv
     case 904:  return launch_one<TO, TTL, WO, WT, 9, 4>(p, lds, grid, st);   // G2-4.conv
@@ -875,6 +962,8 @@ extern "C" int ag_conv1d_engine(const ag_conv_args* args, void* stream) {
   }
   AG_REQUIRE(p.taps <= MAX_TAPS, "ag_conv1d_engine: more than %d taps", MAX_TAPS);
   p.sp_shift = ilog2_exact(p.sp);
+  p.s_shift = ilog2_exact(a.stride);
+  p.efast = g_conv_efast && (int64_t)a.O * a.y_cs * 4 < ((int64_t)1 << 31) && (!a.res || (int64_t)a.O * a.res_cs * 4 < ((int64_t)1 << 31));
   p.xvec = (((uintptr_t)a.x & 15) == 0) && (a.x_bs % 4 == 0) && (a.x_cs % 4 == 0);
   p.Cpad = ag_roundup(a.C, 2);
   p.Mpad = ag_roundup(p.Mrows, 32);
