@@ -497,6 +497,11 @@ def _cdiv(a, b):
     return (a + b - 1) // b
 
 
+def _bf16_tag():
+    """bf16 mode: the persistent recurrent kernels run their v_mfma_f32_*_bf16 instantiation"""
+    return '<bf16>' if lib.ag_get_precision() == 1 else ''
+
+
 def _work_gemm(A, B, Cm, ta=False, tb=False, *a_, **kw):
     M, N = Cm.shape
     Kd = A.size(0) if ta else A.size(1)
@@ -534,8 +539,18 @@ def _work_conv(x, wp, y, K_, stride, pad, mode, *a_, **kw):
     ts = (taps, stride if mode == 0 else 0)
     if ts not in ((17, 8), (9, 4), (7, 2), (3, 1), (16, 8), (8, 4), (2, 0), (3, 0), (4, 0)):
         ts = (0, 0)
-    return 'conv_engine_kernel<%s,%d,%d>' % (tile, ts[0], ts[1]), 2.0 * macs, \
-        4.0 * (x.numel() + y.numel() + wp.numel())
+    nbytes = 4.0 * (x.numel() + y.numel() + O * Cc * K_)
+    if lib.ag_get_precision() == 1 and Cc >= 16 and Lin % 4 == 0:
+        # mirrors launch_bf16 (conv_engine.hip): the bf16-MFMA kernel takes the launch when a chunk's staging fits
+        ot = {'1,2,1,4': 32, '2,1,1,4': 64, '2,1,2,2': 128, '2,2,2,2': 128}[tile]
+        tt = {'1,2,1,4': 256, '2,1,1,4': 128, '2,1,2,2': 64, '2,2,2,2': 128}[tile]
+        sp = stride if mode == 0 else 1
+        ncols = tt + ((K_ - 1) // stride if mode == 0 else taps - 1)
+        nq = (sp * ncols + 6) // 4 + 1
+        deep = ot >= 128 and (-(-Cc // 16)) * taps >= 32
+        if 2 * nq <= 512 and taps * 2 * ot <= (16 if deep else 8) * 256:
+            return 'conv_engine_bf16_kernel<%s>' % tile, 2.0 * macs, nbytes
+    return 'conv_engine_kernel<%s,%d,%d>' % (tile, ts[0], ts[1]), 2.0 * macs, nbytes
 
 
 def _work_wgrad(sh, lg, dw, K_, stride, pad):
@@ -782,7 +797,7 @@ def gfront_fwd_persist(gates, wx, whh, wp, bp, hs, cs, x):
 def _work_gfront(gates, wx, whh, wp, *a_, **kw):
     T, B, S4 = gates.shape
     S, fs = S4 // 4, wp.size(0)
-    return 'gfront_persist_fwd_kernel', T * 2.0 * B * (S4 * (S + fs) + fs * S), \
+    return 'gfront_persist_fwd_kernel' + _bf16_tag(), T * 2.0 * B * (S4 * (S + fs) + fs * S), \
         4.0 * (S4 * (S + fs) + fs * S + T * B * (2 * S4 + 2 * S + fs)), 1
 
 
@@ -811,7 +826,7 @@ def _lstm_seq_bwd_persist_call(gates, whh, c_all, dy, dgates, valid):
 def _work_seq_bwd_persist(gates, whh, c_all, dy, dgates, valid):
     T, B, H4 = gates[0].shape
     nd = len(gates)
-    return 'lstm_persist_bwd_kernel', T * 2.0 * nd * B * H4 * (H4 // 4), \
+    return 'lstm_persist_bwd_kernel' + _bf16_tag(), T * 2.0 * nd * B * H4 * (H4 // 4), \
         4.0 * nd * (H4 * (H4 // 4) + T * 5.5 * B * H4), 1
 
 
@@ -885,7 +900,7 @@ def _work_seq_fwd_persist(pre, whh, c_all, y, valid, static=None):
     nd = len(pre)
     # one launch = the whole layer pass: T steps of 2*B*4H*H flops per direction; algorithmic bytes: W_hh ONCE
     # + gates in/out, cells, outputs per step
-    return 'lstm_persist_fwd_kernel', T * 2.0 * nd * B * H4 * (H4 // 4), \
+    return 'lstm_persist_fwd_kernel' + _bf16_tag(), T * 2.0 * nd * B * H4 * (H4 // 4), \
         4.0 * nd * (H4 * (H4 // 4) + T * 3 * B * H4), 1
 
 
