@@ -53,6 +53,10 @@ typedef struct ag_wn_desc {
   float* w;        /* [rows, cols] standard layout (may be NULL)        */
   float* wpa;      /* gather layout  [pad2(d1)][K][pad32(d0)]  or NULL  */
   float* wpb;      /* scatter layout [d0][ceil(K/s)][pad32(d1*s)] or NULL */
+                   /* Each layout [Cp2][taps][rows] is followed IN THE SAME BUFFER by its bf16 image
+                    * [ceil(Cp2/16)][taps][2][rows][8 x bf16] (what the bf16-MFMA conv kernel stages in AG_PREC_BF16
+                    * mode); ag_wpa_numel / ag_wpb_numel return the size of both parts, the buffers must start
+                    * zero-filled (padding is never written).                                                  */
   float* inv_norm; /* [rows] 1/||v||, saved for backward (may be NULL)  */
   int32_t rows;    /* d0                                                */
   int32_t cols;    /* d1*K                                              */
@@ -120,7 +124,7 @@ int ag_conv1d_engine(const ag_conv_args* args, void* stream);
 /* plain (non weight-normed) weights -> engine layouts; w is [d0][d1][K] */
 int ag_prep_conv_weight(const float* w, float* wpa, float* wpb, int d0, int d1, int K, int stride, int pad,
                         void* stream);
-/* sizes (in floats) of the two layouts, so the host can allocate them */
+/* sizes (in floats) of the two layouts - fp32 part + bf16 image, see ag_wn_desc - so the host can allocate them */
 int64_t ag_wpa_numel(int d0, int d1, int K);
 int64_t ag_wpb_numel(int d0, int d1, int K, int stride);
 
