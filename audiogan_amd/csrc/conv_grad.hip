@@ -266,6 +266,189 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgP p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// AG_PREC_BF16: the same weight gradient on v_mfma_f32_32x32x16_bf16.  The reduction runs over time, so one MFMA
+// k-step = 16 consecutive output positions t: lane (l31, h) supplies t = tb + 8h .. +7.
+//   A operand (sh = the gradient side, [a][t] in memory): LDS image [AT rows][TC x bf16] (+16 B pad per row) - staged
+//     with plain 16-byte loads, rounded, written 8 bytes at a time; a fragment is ONE ds_read_b128.
+//   B operand (lg window): LDS rows [channel][span x bf16]; column (c, k) at step t reads lg[c][s*t + k - p], i.e. 8
+//     ds_read_u16 at stride s per fragment (an im2col image would cost K times the LDS).
+// Same chunk / slab / fixed-order second stage as the fp32 kernel; staging waves run the register pipeline of the conv
+// engine (loads of chunk i+2 in flight while chunk i+1 is written).  Results equal the rounding emulation in the fp32
+// kernel up to fp32 summation order.
+typedef short wbf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned wu32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned wu32x2 __attribute__((ext_vector_type(2)));
+#define WB_FS 8   // sh pieces (16 bytes of fp32) per staging lane and chunk
+#define WB_FL 5   // lg pieces per staging lane and chunk
+
+template <int TA, int TN, int WA, int WN>
+__global__ __launch_bounds__(512) void conv_wgrad_bf16_kernel(const WgP p) {
+  static_assert(WA * WN == 4, "4 compute waves");
+  constexpr int AT = 32 * TA * WA, NT = 32 * TN * WN;
+  extern __shared__ float smem[];
+  char* lds = reinterpret_cast<char*>(smem);
+  const int SPB = p.TC * 2 + 16;                       // bytes per sh row
+  const int LGPB = p.lgp;                              // bytes per lg channel row (multiple of 4)
+  const size_t bufb = ((size_t)AT * SPB + (size_t)p.maxch * LGPB + 15) & ~(size_t)15;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int cw = wid & 3;
+  const int wa = cw / WN, wn = cw % WN;
+  const int a0 = blockIdx.y * AT, ck0 = blockIdx.x * NT;
+  const int c_lo = ck0 / p.K;
+  int c_hi = (ck0 + NT - 1) / p.K;
+  if (c_hi >= p.C) c_hi = p.C - 1;
+  const int nch = c_hi - c_lo + 1;
+  const int span = p.s * (p.TC - 1) + p.K;
+  const int total = p.B * p.nchunk;
+  const int nmine = (total - (int)blockIdx.z + (int)gridDim.z - 1) / (int)gridDim.z;   // chunks of this block
+
+  if (__builtin_amdgcn_readfirstlane(threadIdx.x) >= 256) {
+    // ---------------- staging waves
+    __builtin_amdgcn_s_setprio(2);
+    const int sl_ = cw * 64 + lane;
+    const int shift = (((-p.p) % 4) + 4) % 4;            // (s*t0 - p) mod 4, the same for every chunk
+    const int PR = (shift + span + 3) / 4;               // aligned pieces per lg row
+    const int q4 = p.TC >> 2;
+    const int stot = AT * q4, ltot4 = nch * PR;
+    int ssrc[WB_FS], sdst[WB_FS], lsrc[WB_FL], li0[WB_FL], lrow[WB_FL];
+#pragma unroll
+    for (int u = 0; u < WB_FS; ++u) {
+      const int e = sl_ + u * 256;
+      const int r = e / q4, q = e - r * q4;
+      const bool ok = e < stot && a0 + r < p.A;
+      ssrc[u] = ok ? (int)((a0 + r) * p.sh_cs) + 4 * q : -1;      // -1: zeros (rows past A)
+      sdst[u] = e < stot ? r * SPB + 8 * q : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < WB_FL; ++u) {
+      const int e = sl_ + u * 256;
+      const int r = e / PR, m = e - r * PR;
+      const bool ok = e < ltot4;
+      lsrc[u] = ok ? (int)((c_lo + r) * p.lg_cs) + 4 * m : 0;
+      li0[u] = ok ? 4 * m - shift : -(1 << 20);          // window index of the piece's first element
+      lrow[u] = r * LGPB;
+    }
+    f32x4 sv[WB_FS], lv[WB_FL];
+    bool lok[WB_FL];
+    auto loadc = [&](int cix) __attribute__((always_inline)) {
+      const int ch = blockIdx.z + cix * gridDim.z;
+      const int b = ch / p.nchunk;
+      const int t0 = (ch - b * p.nchunk) * p.TC;
+      const int g0 = p.s * t0 - p.p;
+      const float* sbase = p.sh + (int64_t)b * p.sh_bs + t0;
+      const float* lrow0 = p.lg + (int64_t)b * p.lg_bs;
+#pragma unroll
+      for (int u = 0; u < WB_FS; ++u) sv[u] = *reinterpret_cast<const f32x4*>(sbase + max(ssrc[u], 0));
+#pragma unroll
+      for (int u = 0; u < WB_FL; ++u) {
+        const int gp = g0 + li0[u];                    // global index of the piece's first element
+        lok[u] = gp >= 0 && gp + 3 < p.Llg;
+        lv[u] = *reinterpret_cast<const f32x4*>(lrow0 + (lok[u] ? lsrc[u] + (g0 - shift) : 0));
+      }
+    };
+    auto writec = [&](int buf) __attribute__((always_inline)) {
+      char* shs = lds + buf * bufb;
+      char* lgs = shs + (size_t)AT * SPB;
+#pragma unroll
+      for (int u = 0; u < WB_FS; ++u)
+        if (sdst[u] >= 0) {
+          wu32x2 w = {ag_pack_bf16(sv[u][0], sv[u][1]), ag_pack_bf16(sv[u][2], sv[u][3])};
+          if (ssrc[u] < 0) w = wu32x2{0u, 0u};
+          *reinterpret_cast<wu32x2*>(shs + sdst[u]) = w;
+        }
+#pragma unroll
+      for (int u = 0; u < WB_FL; ++u)
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+          const int i = li0[u] + x;
+          if (i >= 0 && i < span)
+            *reinterpret_cast<unsigned short*>(lgs + lrow[u] + 2 * i) = lok[u] ? (unsigned short)ag_pack_bf16(lv[u][x], lv[u][x]) : (unsigned short)0;
+        }
+    };
+    if (nmine > 0) {
+      loadc(0);
+      writec(0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (nmine > 1) loadc(1);
+    __syncthreads();
+    for (int ci = 0; ci < nmine; ++ci) {
+      if (ci + 1 < nmine) writec((ci + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);        // (the loads below reuse the registers just written out)
+      if (ci + 2 < nmine) loadc(ci + 2);
+      __syncthreads();
+    }
+    return;
+  }
+
+  // ---------------- MFMA waves: per-lane column constants (byte offsets into the lg image)
+  int joff[TN];
+  bool jok[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int ck = ck0 + wn * 32 * TN + 32 * j + l31;
+    jok[j] = ck < p.CK;
+    const int c = jok[j] ? ck / p.K : c_lo;
+    const int k = jok[j] ? ck - c * p.K : 0;
+    joff[j] = (c - c_lo) * LGPB + 2 * (k + p.s * 8 * h);
+  }
+  f32x16 acc[TA][TN];
+#pragma unroll
+  for (int i = 0; i < TA; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  __syncthreads();      // chunk 0 staged
+  const int s2 = 2 * p.s;
+  for (int ci = 0; ci < nmine; ++ci) {
+    const char* shs = lds + (ci & 1) * bufb;
+    const char* lgs = shs + (size_t)AT * SPB;
+    const char* arow = shs + (size_t)(wa * 32 * TA + l31) * SPB + 16 * h;
+    for (int tb = 0; tb < p.TC; tb += 16) {
+      wbf16x8 av[TA], bv[TN];
+#pragma unroll
+      for (int i = 0; i < TA; ++i) av[i] = *reinterpret_cast<const wbf16x8*>(arow + (size_t)32 * i * SPB + 2 * tb);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const char* bp = lgs + joff[j] + s2 * tb;
+        wu32x4 w;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const unsigned lo = *reinterpret_cast<const unsigned short*>(bp + s2 * (2 * e));
+          const unsigned hi = *reinterpret_cast<const unsigned short*>(bp + s2 * (2 * e + 1));
+          w[e] = jok[j] ? (lo | (hi << 16)) : 0u;
+        }
+        bv[j] = __builtin_bit_cast(wbf16x8, w);
+      }
+#pragma unroll
+      for (int i = 0; i < TA; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int i = 0; i < TA; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int a = a0 + wa * 32 * TA + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
+      if (a >= p.A) continue;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int ck = ck0 + wn * 32 * TN + 32 * j + l31;
+        if (ck >= p.CK) continue;
+        if (p.part) p.part[((int64_t)blockIdx.z * p.A + a) * p.CK + ck] = acc[i][j][e];
+        else atomicAdd(p.dw + (int64_t)a * p.CK + ck, acc[i][j][e]);
+      }
+    }
+}
+
 // reduction slices (grid.z) of the MFMA kernel for an [A x CK] gradient tiled AT x NT
 static int wgrad_slices(int A, int CK, int AT, int NT, int total) {
   const int gx = ag_cdiv(CK, NT), gy = ag_cdiv(A, AT);
@@ -278,9 +461,53 @@ static int wgrad_slices(int A, int CK, int AT, int NT, int total) {
   return gz;
 }
 
+// AG_CONV_BF16_MFMA=0 keeps the fp32-MFMA rounding emulation in bf16 mode (A/B measurements)
+static const bool g_wgrad_bf16_mfma = [] { const char* e = getenv("AG_CONV_BF16_MFMA"); return !(e && e[0] == '0'); }();
+
+// bf16-MFMA variant; -1 = the shape does not fit its staging scheme (caller takes the fp32 kernel)
+template <int TA, int TN, int WA, int WN>
+static int launch_wgrad_bf16(WgP& p, hipStream_t st, AgWs ws) {
+  constexpr int AT = 32 * TA * WA, NT = 32 * TN * WN;
+  p.TC = 64;
+  if (p.Lsh % p.TC != 0 || !p.vec || (p.s * p.TC) % 4 != 0 || p.Llg % 4 != 0 || p.Llg < 4 || p.lg_cs % 4 != 0 ||
+      p.lg_bs % 4 != 0 || (((uintptr_t)p.lg) & 15) != 0)
+    return -1;
+  p.nchunk = p.Lsh / p.TC;
+  const int span = p.s * (p.TC - 1) + p.K;
+  p.lgp = ag_roundup(2 * span, 4) + 4;             // bytes per lg channel row
+  p.maxch = (NT - 1) / p.K + 2;
+  if (p.maxch > p.C) p.maxch = p.C;
+  const int shift = (((-p.p) % 4) + 4) % 4;
+  const int PR = (shift + span + 3) / 4;
+  if (AT * (p.TC / 4) > WB_FS * 256 || p.maxch * PR > WB_FL * 256) return -1;
+  if ((int64_t)AT * p.sh_cs >= (1 << 30) || (int64_t)p.C * p.lg_cs >= (1 << 30)) return -1;
+  const size_t lds = 2 * (((size_t)AT * (p.TC * 2 + 16) + (size_t)p.maxch * p.lgp + 15) & ~(size_t)15);
+  if (lds > 160 * 1024) return -1;
+  const int gx = ag_cdiv(p.CK, NT), gy = ag_cdiv(p.A, AT);
+  const int total = p.B * p.nchunk;
+  int gz = wgrad_slices(p.A, p.CK, AT, NT, total);
+  const int64_t n_out = (int64_t)p.A * p.CK;
+  p.part = nullptr;
+  if (ws.p && ws.numel >= n_out) {         // two-stage, fixed-order reduction
+    if ((int64_t)gz * n_out > ws.numel) gz = (int)(ws.numel / n_out);
+    p.part = ws.p;
+  }
+  auto kern = conv_wgrad_bf16_kernel<TA, TN, WA, WN>;
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(kern, dim3(gx, gy, gz), dim3(512), lds, st, p);
+  AG_CHECK_LAUNCH("ag_conv1d_wgrad(bf16)");
+  if (p.part) return ag_slab_reduce(p.part, gz, n_out, p.dw, 1, st);
+  return AG_OK;
+}
+
 template <int TA, int TN, int WA, int WN>
 static int launch_wgrad(WgP& p, hipStream_t st, AgWs ws) {
   constexpr int AT = 32 * TA * WA, NT = 32 * TN * WN;
+  if (p.rb && g_wgrad_bf16_mfma) {
+    const int rc = launch_wgrad_bf16<TA, TN, WA, WN>(p, st, ws);
+    if (rc != -1) return rc;
+  }
   p.TC = AT >= 128 ? 32 : 64;   // keeps two LDS buffers of the 128x128 tile under 48 KiB (>= 2 workgroups per CU)
   if (p.Lsh < p.TC) p.TC = ag_roundup(p.Lsh, 4);
   p.nchunk = ag_cdiv(p.Lsh, p.TC);
