@@ -105,15 +105,17 @@ def one_step(train, g, d, opt_g, opt_d, b, hook_d=None, hook_g=None, overlap=Fal
                          b['noise_fake'], 1.0, 0.1, overlap=overlap, hook_d=hook_d, hook_g=hook_g)
 
 
-def pmc_traffic(kernel):
+def pmc_traffic(kernel, dtype='f32'):
     """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes
-    (profiles/r02_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE in separate passes, gfx950 x2 read
-    correction applied); None when that kernel was not profiled."""
-    path = os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json')
+    (profiles/r02_pmc_traffic.json, for --dtype bf16 profiles/r02_pmc_traffic_bf16.json: FETCH_SIZE and WRITE_SIZE in
+    separate passes, gfx950 x2 read correction applied); the instantiation if it was profiled under that name, else
+    the kernel class; None when neither was."""
+    path = os.path.join(ROOT, 'profiles', 'r02_pmc_traffic_bf16.json' if dtype == 'bf16' else 'r02_pmc_traffic.json')
     if not os.path.exists(path):
         return None
     tab = json.load(open(path))
-    ent = tab.get(kernel.replace(' ', ''))
+    name = kernel.replace(' ', '')
+    ent = tab.get(name) or tab.get(name.split('<')[0])
     return ent['bytes_per_launch'] if ent else None
 
 
@@ -414,7 +416,7 @@ def main():
                 'peak': peak_tf if mfma_bound else PEAK_HBM_GBS,
                 'unit': 'TFLOP/s' if mfma_bound else 'GB/s',
                 'frac': (tf / peak_tf) if mfma_bound else (gbs / PEAK_HBM_GBS),
-                'traffic': pmc_traffic(dominant), 'launches_per_step': r['n'] / r.get('per_step_div', args.steps),
+                'traffic': pmc_traffic(dominant, args.dtype), 'launches_per_step': r['n'] / r.get('per_step_div', args.steps),
                 'avg_launch_us': avg_ms * 1e3,
                 'share_of_gpu_time': share,
                 'algorithmic_per_launch': {'flops': r['flops'] / r['n'], 'bytes': r['bytes'] / r['n']},

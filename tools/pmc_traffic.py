@@ -45,8 +45,9 @@ def main():
         wk = w_tot.get(k, 0.0) / max(w_cnt.get(k, 1), 1)
         out[k] = {'launches': n, 'fetch_kb': round(fk, 1), 'write_kb': round(wk, 1),
                   'bytes_per_launch': int(1024 * (2 * fk + wk))}
-    json.dump(out, open('profiles/r02_pmc_traffic.json', 'w'), indent=1)
-    print('wrote profiles/r02_pmc_traffic.json with %d kernels' % (len(out) - 1))
+    dst = sys.argv[3] if len(sys.argv) > 3 else 'profiles/r02_pmc_traffic.json'
+    json.dump(out, open(dst, 'w'), indent=1)
+    print('wrote %s with %d kernels' % (dst, len(out) - 1))
 
 
 if __name__ == '__main__':
