@@ -240,7 +240,12 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgP p) {
 #pragma unroll
       for (int i = 0; i < TA; ++i) av[i] = arow[t * SP + 32 * i];
 #pragma unroll
-      for (int j = 0; j < TN; ++j) bv[j] = jok[j] ? lgs[joff[j] + p.s * t] : 0.f;
+      for (int j = 0; j < TN; ++j) {
+        // (unconditional read of a valid address + select: a conditional load compiles to an exec-masked branch per
+        // operand inside the MFMA loop)
+        const float bval = lgs[joff[j] + p.s * t];
+        bv[j] = jok[j] ? bval : 0.f;
+      }
 #pragma unroll
       for (int i = 0; i < TA; ++i)
 #pragma unroll
