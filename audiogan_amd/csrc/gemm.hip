@@ -419,6 +419,9 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmP p) {
           for (int j = 0; j < 2; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][e], bv[j][e], acc[i][j], 0, 0, 0);
     }
+    // (without this the scheduler hoists the barrier - and its vmcnt(0) on the next tile's DMA - in front of the second
+    // half of the tile's MFMAs: the DMA then has half an iteration to land)
+    __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
     buf ^= 1;
   }
