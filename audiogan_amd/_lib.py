@@ -83,6 +83,7 @@ SIGNATURES = {
     'ag_conv1d_wgrad_ws_numel': (i64, [C.c_int] * 5),
     'ag_gemm_ws_numel': (i64, [C.c_int] * 4),
     'ag_skinny_ws_numel': (i64, [C.c_int] * 3),
+    'ag_persist_debug': (C.c_int, [i64, C.c_int]),
     'ag_lstm_persist_ok': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     'ag_lstm_persist_ws_bytes': (i64, [C.c_int, C.c_int, C.c_int]),
     'ag_lstm_seq_fwd_persist': (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),

@@ -37,29 +37,63 @@ def save(prefix, iteration, d=None, g=None, e_g=None, e_d=None, opt_d=None, opt_
     return written
 
 
-def load(prefix, iteration, d=None, g=None, e_g=None, e_d=None, opt_d=None, opt_g=None, strict=True, restore_rng=True):
+def _read(path, allow_pickle):
+    """state_dict files (what ``save`` writes) load with ``weights_only=True``.  The reference's whole-module pickles
+    execute code when unpickled: they are read only when the caller says so (``allow_pickle=True``)."""
+    try:
+        return torch.load(path, map_location='cpu', weights_only=True)
+    except Exception as e:  # noqa: BLE001  (pickle.UnpicklingError and friends)
+        if not allow_pickle:
+            raise RuntimeError('%s is not a plain state_dict checkpoint (%s: %s).  If it is a whole-module pickle written '
+                               'by the reference (audiogan.py:936-939) and you trust it, pass allow_pickle=True.'
+                               % (path, type(e).__name__, str(e)[:200]))
+        return torch.load(path, map_location='cpu', weights_only=False)
+
+
+def load(prefix, iteration, d=None, g=None, e_g=None, e_d=None, opt_d=None, opt_g=None, strict=True, restore_rng=None,
+         allow_pickle=False):
+    """``restore_rng``: None = restore the RNG streams when an optimiser is being restored (a resumed training run), leave
+    them alone for inference-only loads; True / False force it.  Returns ``extra``; ``load.last_rng`` says what happened
+    to the RNG state ('restored', 'cpu only ...', 'not restored')."""
+    import warnings
     mods = dict(d=d, g=g, e_g=e_g, e_d=e_d)
     for role, key in _ROLES:
         m = mods[key]
         if m is not None:
-            obj = torch.load(_path(prefix, role, iteration), map_location='cpu', weights_only=False)
+            obj = _read(_path(prefix, role, iteration), allow_pickle)
             sd = obj.state_dict() if isinstance(obj, torch.nn.Module) else obj      # reference-style module pickle
             m.load_state_dict(sd, strict=strict)
     extra = None
+    load.last_rng = 'not restored'
     p = _path(prefix, 'opt', iteration)
     if os.path.exists(p):
-        blob = torch.load(p, map_location='cpu', weights_only=False)
+        blob = _read(p, allow_pickle)
         for o, key in ((opt_d, 'opt_d'), (opt_g, 'opt_g')):
             if o is not None and blob.get(key) is not None:
                 o.load_state_dict(_to(blob[key], o.params[0].device))
+        if restore_rng is None:
+            restore_rng = opt_d is not None or opt_g is not None
         if restore_rng:
             if blob.get('torch_rng') is not None:
                 torch.set_rng_state(blob['torch_rng'])
-            if blob.get('cuda_rng') is not None and torch.cuda.is_available() and \
-                    len(blob['cuda_rng']) == torch.cuda.device_count():
-                torch.cuda.set_rng_state_all(blob['cuda_rng'])
+                load.last_rng = 'restored'
+            cr = blob.get('cuda_rng')
+            if cr is not None and torch.cuda.is_available():
+                if len(cr) == torch.cuda.device_count():
+                    torch.cuda.set_rng_state_all(cr)
+                else:
+                    # saved on a different number of devices: this process's device continues the stream of the saved
+                    # device with the same index (or the first one) - and the caller is told
+                    i = torch.cuda.current_device()
+                    torch.cuda.set_rng_state(cr[i] if i < len(cr) else cr[0], i)
+                    load.last_rng = 'cpu + current device only (checkpoint has %d device streams, this process sees %d)' % (
+                        len(cr), torch.cuda.device_count())
+                    warnings.warn('audiogan_amd.checkpoint.load: ' + load.last_rng)
         extra = blob.get('extra')
     return extra
+
+
+load.last_rng = 'not restored'
 
 
 def _cpu(sd):

@@ -605,6 +605,7 @@ __global__ __launch_bounds__(256) void conv_c1_wgrad_kernel(const float* __restr
 extern "C" int ag_conv1d_wgrad(const float* sh, int64_t sh_bs, int64_t sh_cs, const float* lg,
                                int64_t lg_bs, int64_t lg_cs, float* dw, int B, int A, int Lsh, int C,
                                int Llg, int K, int stride, int pad, void* stream) {
+  const AgWs ws = ag_ws_take();     // FIRST: an argument error below must not leave a stale binding behind
   AG_REQUIRE(sh && lg && dw, "ag_conv1d_wgrad: null tensor");
   AG_REQUIRE(B > 0 && A > 0 && Lsh > 0 && C > 0 && Llg > 0 && K > 0 && stride > 0 && pad >= 0,
              "ag_conv1d_wgrad: bad shape");
@@ -616,7 +617,6 @@ extern "C" int ag_conv1d_wgrad(const float* sh, int64_t sh_bs, int64_t sh_cs, co
   p.rb = ag_precision() == AG_PREC_BF16;
   p.vec = (((uintptr_t)sh & 15) == 0) && (sh_bs % 4 == 0) && (sh_cs % 4 == 0);
   hipStream_t st = (hipStream_t)stream;
-  const AgWs ws = ag_ws_take();
   if (C == 1 && K <= 8) {       // (K = 17, A = 128 - G1.conv - measured faster on the MFMA path: 43 vs 88 us)
     const int ag = 8;
     const int gx = ag_cdiv(Lsh, 256), gy = ag_cdiv(A, ag);
@@ -685,12 +685,12 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restric
 
 extern "C" int ag_channel_sum(const float* dy, int64_t bs, int64_t cs, float* db, int B, int C, int L,
                               void* stream) {
+  const AgWs ws = ag_ws_take();     // FIRST: an argument error below must not leave a stale binding behind
   AG_REQUIRE(dy && db && B > 0 && C > 0 && L > 0, "ag_channel_sum: bad args");
   int nsplit = (int)ag_cdiv64((int64_t)B * L, 256 * 16);
   const int cap = ag_cdiv(2048, C);
   if (nsplit > cap) nsplit = cap;
   if (nsplit < 1) nsplit = 1;
-  const AgWs ws = ag_ws_take();
   float* part = nullptr;
   if (ws.p && ws.numel >= C) {
     if ((int64_t)nsplit * C > ws.numel) nsplit = (int)(ws.numel / C);
@@ -751,12 +751,12 @@ extern "C" int ag_leaky_bwd(const float* dy, int64_t dy_bs, int64_t dy_cs, const
                             int64_t y_bs, int64_t y_cs, float* dpre, int64_t dp_bs, int64_t dp_cs,
                             float* add_into, int64_t ad_bs, int64_t ad_cs, const int64_t* lens_i64,
                             float* bias_grad, int B, int C, int L, float slope, void* stream) {
+  const AgWs ws = ag_ws_take();     // FIRST: an argument error below must not leave a stale binding behind
   AG_REQUIRE(dy && y && dpre && B > 0 && C > 0 && L > 0, "ag_leaky_bwd: bad args");
   AG_REQUIRE(B <= 65535 && C <= 65535, "ag_leaky_bwd: B or C > 65535");
   int gx = ag_cdiv(L, 256 * 4);
   if (gx < 1) gx = 1;
   int bper = 1;
-  const AgWs ws = ag_ws_take();
   float* part = nullptr;
   if (bias_grad) {
     bper = (int)(((int64_t)gx * C * B) / 2048);
@@ -1099,6 +1099,7 @@ __global__ __launch_bounds__(256) void conv_o1_wgrad_vec3_kernel(const float* __
 
 extern "C" int ag_conv1d_o1_wgrad(const float* dy, int64_t dy_bs, const float* x, int64_t x_bs, int64_t x_cs,
                                   float* dw, int B, int C, int L, int K, int pad, void* stream) {
+  const AgWs ws = ag_ws_take();     // FIRST: an argument error below must not leave a stale binding behind
   AG_REQUIRE(dy && x && dw && B > 0 && C > 0 && L > 0 && K > 0 && K <= O1_MAXK, "ag_conv1d_o1_wgrad: bad args");
   AG_REQUIRE(C <= 65535, "ag_conv1d_o1_wgrad: C > 65535");
   // enough workgroups to fill the chip (~8 per CU), the rest of the batch is looped inside
@@ -1106,7 +1107,6 @@ extern "C" int ag_conv1d_o1_wgrad(const float* dy, int64_t dy_bs, const float* x
   int gz = ag_cdiv(2048, gx * C);
   if (gz > B) gz = B;
   if (gz < 1) gz = 1;
-  const AgWs ws = ag_ws_take();
   float* part = nullptr;
   if (ws.p && ws.numel >= (int64_t)gx * C * K) {
     if ((int64_t)gz * gx * C * K > ws.numel) gz = (int)(ws.numel / ((int64_t)gx * C * K));

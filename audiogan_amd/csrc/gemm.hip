@@ -733,6 +733,7 @@ static bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 extern "C" int ag_gemm(const float* A, int lda, int ta, const float* B, int ldb, int tb, float* C,
                        int ldc, int M, int N, int K, float alpha, float beta, const float* bias,
                        const float* res, int ldres, int act, float slope, void* stream) {
+  const AgWs ws = ag_ws_take();     // FIRST: an argument error below must not leave a stale binding behind
   AG_REQUIRE(A && B && C, "ag_gemm: null tensor");
   AG_REQUIRE(M > 0 && N > 0 && K > 0, "ag_gemm: bad shape %d %d %d", M, N, K);
   AG_REQUIRE((ta == 0 || ta == 1) && (tb == 0 || tb == 1), "ag_gemm: bad transpose flag");
@@ -756,7 +757,6 @@ extern "C" int ag_gemm(const float* A, int lda, int ta, const float* B, int ldb,
   // workspace the slices' partial tiles are summed in a fixed order by a second kernel (deterministic); without one
   // they are combined with atomics.  Needs a linear epilogue.
   p.part = nullptr;
-  const AgWs ws = ag_ws_take();
   if (tiles < 192 && K >= 1024 && act == AG_ACT_NONE) {
     int ks = (int)(512 / tiles);
     if (ks > K / 256) ks = K / 256;
@@ -841,12 +841,12 @@ __global__ __launch_bounds__(256) void col_sum_kernel(const float* __restrict__ 
 }
 
 extern "C" int ag_col_sum(const float* X, int ldx, float* out, int M, int N, void* stream) {
+  const AgWs ws = ag_ws_take();     // FIRST: an argument error below must not leave a stale binding behind
   AG_REQUIRE(X && out && M > 0 && N > 0 && ldx >= N, "ag_col_sum: bad args");
   const int gx = ag_cdiv(N, 64);
   int gy = ag_cdiv(1024, gx);
   if (gy > ag_cdiv(M, 16)) gy = ag_cdiv(M, 16);
   if (gy < 1) gy = 1;
-  const AgWs ws = ag_ws_take();
   float* part = nullptr;
   if (gy > 1 && ws.p && ws.numel >= 2 * (int64_t)N) {   // (one row block: a single writer per column, nothing to order)
     if ((int64_t)gy * N > ws.numel) gy = (int)(ws.numel / N);

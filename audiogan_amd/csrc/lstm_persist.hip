@@ -26,9 +26,44 @@
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-#define PS_FLAG_OFF 16          // flags start at word 16 of the workspace; word 0 = status
-#define PS_HDR_BYTES 8192       // header (status + flags), zeroed by a memset node in front of every launch
+// Workspace layout: [sticky area PS_STICKY_BYTES][header PS_HDR_BYTES][exchange buffers].
+//   sticky word 0 : OR of every timeout since the workspace was allocated; NEVER cleared by a launch (a step issues many
+//                   persistent launches on one workspace, the host reads this word once per step / bench run)
+//   header word 0 : status of THIS launch ("somebody gave up": the other workgroups stop waiting too)
+//   header words PS_FLAG_OFF.. : flags.  The header is zeroed by a memset node in front of every launch.
+// A workgroup that gave up poisons everything it writes from then on with NaN, so the failure also reaches the loss and
+// the optimiser's check_grad flags instead of leaving plausible garbage.
+#define PS_STICKY_BYTES 256
+#define PS_FLAG_OFF 16
+#define PS_HDR_BYTES 8192
 #define PS_TIMEOUT_TICKS 300000000ull   // 3 s of the 100 MHz realtime counter
+
+// test hooks (ag_persist_debug): a shorter timeout and one workgroup that never publishes its flags, to exercise the
+// give-up path on purpose
+static unsigned long long g_ps_timeout = PS_TIMEOUT_TICKS;
+static int g_ps_mute = -1;
+
+extern "C" int ag_persist_debug(int64_t timeout_ticks, int mute_block) {
+  g_ps_timeout = timeout_ticks > 0 ? (unsigned long long)timeout_ticks : PS_TIMEOUT_TICKS;
+  g_ps_mute = mute_block;
+  return AG_OK;
+}
+
+struct PersistCtl {
+  unsigned* hdr;              // status + flags of this launch
+  unsigned* sticky;           // sticky status word
+  unsigned long long timeout; // ticks
+  int mute;                   // block that never publishes (-1: none)
+};
+
+static PersistCtl ps_ctl(void* ws) {
+  PersistCtl c;
+  c.sticky = (unsigned*)ws;
+  c.hdr = (unsigned*)((char*)ws + PS_STICKY_BYTES);
+  c.timeout = g_ps_timeout;
+  c.mute = g_ps_mute;
+  return c;
+}
 
 struct PersistDir {
   float* pre;          // [T,B,4H] in: x-projection (+ biases); out: activated gates
@@ -42,14 +77,15 @@ struct PersistFwdP {
   float* y;            // [T,B,ndir*H]
   const int64_t* valid;
   float* xbuf;         // exchange buffer
-  unsigned* hdr;       // status + flags
+  PersistCtl ctl;
   int T, B, H, ndir;
   int nbt;             // batch tiles
   int ntile;           // H / 8
   int rb;              // AG_PREC_BF16: both operands of the recurrent product rounded to bf16
 };
 
-__device__ __forceinline__ bool ps_wait_flags(unsigned* hdr, const unsigned* flags, int n, unsigned want, int lane) {
+__device__ __forceinline__ bool ps_wait_flags(const PersistCtl& ctl, const unsigned* flags, int n, unsigned want, int lane) {
+  unsigned* hdr = ctl.hdr;
   // ONE wave polls the group's flags (lane i <-> flags i, i + 64, ...), relaxed agent-scope loads
   unsigned long long t0 = 0;
   for (unsigned spins = 0;; ++spins) {
@@ -61,8 +97,11 @@ __device__ __forceinline__ bool ps_wait_flags(unsigned* hdr, const unsigned* fla
       if (__hip_atomic_load(hdr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;   // somebody gave up
       const unsigned long long now = __builtin_amdgcn_s_memrealtime();
       if (t0 == 0) t0 = now;
-      else if (now - t0 > PS_TIMEOUT_TICKS) {
-        if (lane == 0) __hip_atomic_store(hdr, 0x80000000u | want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else if (now - t0 > ctl.timeout) {
+        if (lane == 0) {
+          __hip_atomic_store(hdr, 0x80000000u | want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_fetch_or(ctl.sticky, 0x80000000u | want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         return false;
       }
     }
@@ -91,8 +130,10 @@ __global__ __launch_bounds__(512) void lstm_persist_fwd_kernel(const PersistFwdP
   const int H = p.H, B = p.B, T = p.T, ntile = p.ntile;
   float* wl = smem;                           // [ntile][2][32][4]
   float* red = smem + (size_t)32 * H;         // [8 waves][1024]
+  __shared__ int s_dead;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l31 = lane & 31, hh = lane >> 5;
+  if (tid == 0) s_dead = 0;
   const int ngroups = p.ndir * p.nbt;
   const int grp = blockIdx.x % ngroups, ut = blockIdx.x / ngroups;    // a group's blocks share blockIdx % ngroups
   const int dir = grp / p.nbt, bt = grp % p.nbt;
@@ -119,7 +160,7 @@ __global__ __launch_bounds__(512) void lstm_persist_fwd_kernel(const PersistFwdP
   }
   __syncthreads();
 
-  unsigned* flags = p.hdr + PS_FLAG_OFF + grp * ntile;
+  unsigned* flags = p.ctl.hdr + PS_FLAG_OFF + grp * ntile;
   const int64_t xg = (int64_t)ntile * ROWS * 8;                       // floats per (parity, group)
   __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(p.xbuf, 0, (int)(2 * (int64_t)ngroups * xg * 4), 0x00020000);
 
@@ -157,7 +198,10 @@ __global__ __launch_bounds__(512) void lstm_persist_fwd_kernel(const PersistFwdP
     bool sv_pad = false;
     float sv_ig = 0.f, sv_fg = 0.f, sv_gg = 0.f, sv_og = 0.f, sv_y = 0.f;
     if (k > 0) {
-      if (wid == 0 && alive) alive = ps_wait_flags(p.hdr, flags, ntile, (unsigned)k, lane);
+      if (wid == 0 && alive) {
+        alive = ps_wait_flags(p.ctl, flags, ntile, (unsigned)k, lane);
+        if (!alive) s_dead = 1;
+      }
       __syncthreads();
       const int par = (k - 1) & 1;
       // byte offset of (q, row, 4*hh) in the exchange buffer
@@ -229,6 +273,7 @@ __global__ __launch_bounds__(512) void lstm_persist_fwd_kernel(const PersistFwdP
         hreg = og * tanhf(creg);
         yv = hreg;
       }
+      if (s_dead) { creg = hreg = yv = ig = __builtin_nanf(""); }     // a wait timed out: poison instead of garbage
       // publish h_k FIRST (write-through); the stores nobody waits for (gates, cell, output) go out after the flag
       if (k + 1 < T) {
         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(hreg), xr,
@@ -244,7 +289,8 @@ __global__ __launch_bounds__(512) void lstm_persist_fwd_kernel(const PersistFwdP
     }
     if (k + 1 < T) {
       __syncthreads();
-      if (tid == 0) __hip_atomic_store(flags + ut, (unsigned)(k + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (tid == 0 && (int)blockIdx.x != p.ctl.mute)
+        __hip_atomic_store(flags + ut, (unsigned)(k + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (epi) {
       if (!sv_pad) {
@@ -280,7 +326,7 @@ extern "C" int ag_lstm_persist_ok(int B, int H, int ndir, int n_cu) {
 
 extern "C" int64_t ag_lstm_persist_ws_bytes(int B, int H, int ndir) {
   // header + 2 parities of the padded hidden state, both directions (64-clip padding covers both tilings)
-  return PS_HDR_BYTES + (int64_t)2 * ndir * ag_roundup(B, 64) * H * 4;
+  return PS_STICKY_BYTES + PS_HDR_BYTES + (int64_t)2 * ndir * ag_roundup(B, 64) * H * 4;
 }
 
 // Whole (bi)directional layer forward in ONE launch.  Same tensors as ag_lstm_seq_fwd (lstm_step.hip) minus the
@@ -301,7 +347,7 @@ extern "C" int ag_lstm_seq_fwd_persist(float* const* pre, const float* const* wh
              "ag_lstm_seq_fwd_persist: workspace too small or misaligned");
   for (int d = 0; d < ndir; ++d) AG_REQUIRE(((uintptr_t)whh[d] & 15) == 0, "ag_lstm_seq_fwd_persist: W_hh must be 16-B aligned");
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(ws, 0, PS_HDR_BYTES, st) != hipSuccess) {
+  if (hipMemsetAsync((char*)ws + PS_STICKY_BYTES, 0, PS_HDR_BYTES, st) != hipSuccess) {
     ag_set_error("ag_lstm_seq_fwd_persist: memset failed");
     return AG_ERR_LAUNCH;
   }
@@ -312,8 +358,8 @@ extern "C" int ag_lstm_seq_fwd_persist(float* const* pre, const float* const* wh
     p.d[d].cb = static_pre ? static_pre[s] : nullptr;
   }
   p.y = y; p.valid = valid_i64;
-  p.hdr = (unsigned*)ws;
-  p.xbuf = (float*)((char*)ws + PS_HDR_BYTES);
+  p.ctl = ps_ctl(ws);
+  p.xbuf = (float*)((char*)ws + PS_STICKY_BYTES + PS_HDR_BYTES);
   p.T = T; p.B = B; p.H = H; p.ndir = ndir; p.nbt = nbt; p.ntile = H / 8;
   p.rb = ag_precision() == AG_PREC_BF16;
   const size_t lds = ((size_t)32 * H + 8 * 1024) * sizeof(float);
@@ -358,7 +404,7 @@ struct PersistBwdP {
   PersistBwdDir d[2];
   const float* dy;      // [T,B,ndir*H]
   const int64_t* valid;
-  unsigned* hdr;
+  PersistCtl ctl;
   int T, B, H, ndir;
   int nbt;              // 16-clip tiles
   int ntile;            // H / 32
@@ -372,9 +418,12 @@ template <int NU, int PM>       // 16-k units per wave: 4H = 8 waves * NU * 16
 __global__ __launch_bounds__(512) void lstm_persist_bwd_kernel(const PersistBwdP p) {
   constexpr bool RB = false;
   __shared__ float red[8 * 512];
+  __shared__ int s_dead;
   const int H = p.H, B = p.B, T = p.T, ntile = p.ntile;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int li = lane & 15, g = lane >> 4;
+  if (tid == 0) s_dead = 0;
+  __syncthreads();
   const int ngroups = p.ndir * p.nbt;
   const int grp = blockIdx.x % ngroups, ut = blockIdx.x / ngroups;
   const int dir = grp / p.nbt, bt = grp % p.nbt;
@@ -409,7 +458,7 @@ __global__ __launch_bounds__(512) void lstm_persist_bwd_kernel(const PersistBwdP
       }
   }
 
-  unsigned* flags = p.hdr + PS_FLAG_OFF + grp * ntile;
+  unsigned* flags = p.ctl.hdr + PS_FLAG_OFF + grp * ntile;
   // epilogue role: thread <-> (clip row, unit)
   const int erow = tid >> 5, eun = tid & 31;
   const int em = m0 + erow, eu = n0 + eun;
@@ -433,7 +482,10 @@ __global__ __launch_bounds__(512) void lstm_persist_bwd_kernel(const PersistBwdP
     }
     f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
     if (k < T - 1) {
-      if (wid == 0 && alive) alive = ps_wait_flags(p.hdr, flags, ntile, (unsigned)(T - 1 - k), lane);
+      if (wid == 0 && alive) {
+        alive = ps_wait_flags(p.ctl, flags, ntile, (unsigned)(T - 1 - k), lane);
+        if (!alive) s_dead = 1;
+      }
       __syncthreads();
       const int tn = dir == 0 ? k + 1 : T - 2 - k;
       __amdgpu_buffer_rsrc_t ar = __builtin_amdgcn_make_buffer_rsrc(D.dgates + (int64_t)tn * BG, 0, (int)(BG * 4), 0x00020000);
@@ -498,6 +550,7 @@ __global__ __launch_bounds__(512) void lstm_persist_bwd_kernel(const PersistBwdP
         dcn = dc * fg;
         dpass = 0.f;
       }
+      if (s_dead) { d0 = d1 = d2 = d3 = dcn = __builtin_nanf(""); }   // a wait timed out: poison instead of garbage
       __amdgpu_buffer_rsrc_t orr = __builtin_amdgcn_make_buffer_rsrc(D.dgates + (int64_t)t * BG, 0, (int)(BG * 4), 0x00020000);
       const unsigned o = (unsigned)(((int64_t)em * 4 * H + eu) * 4);
       __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(d0), orr, o, 0, 16);
@@ -508,7 +561,8 @@ __global__ __launch_bounds__(512) void lstm_persist_bwd_kernel(const PersistBwdP
     if (k > 0) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // EVERY storing wave drains its write-through stores
       __syncthreads();
-      if (tid == 0) __hip_atomic_store(flags + ut, (unsigned)(T - k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (tid == 0 && (int)blockIdx.x != p.ctl.mute)
+        __hip_atomic_store(flags + ut, (unsigned)(T - k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }
@@ -536,10 +590,10 @@ extern "C" int ag_lstm_seq_bwd_persist(const float* const* gates, const float* c
     ag_set_error("ag_lstm_seq_bwd_persist: shape B=%d H=%d ndir=%d does not fit %d CUs", B, H, ndir, n_cu);
     return AG_ERR_UNSUPPORTED;
   }
-  AG_REQUIRE(ws_bytes >= PS_HDR_BYTES && ((uintptr_t)ws & 15) == 0, "ag_lstm_seq_bwd_persist: workspace too small");
+  AG_REQUIRE(ws_bytes >= PS_STICKY_BYTES + PS_HDR_BYTES && ((uintptr_t)ws & 15) == 0, "ag_lstm_seq_bwd_persist: workspace too small");
   AG_REQUIRE((int64_t)B * 4 * H * 4 < ((int64_t)1 << 31), "ag_lstm_seq_bwd_persist: step slab too large");
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(ws, 0, PS_HDR_BYTES, st) != hipSuccess) {
+  if (hipMemsetAsync((char*)ws + PS_STICKY_BYTES, 0, PS_HDR_BYTES, st) != hipSuccess) {
     ag_set_error("ag_lstm_seq_bwd_persist: memset failed");
     return AG_ERR_LAUNCH;
   }
@@ -548,7 +602,7 @@ extern "C" int ag_lstm_seq_bwd_persist(const float* const* gates, const float* c
     const int s = d < ndir ? d : 0;
     p.d[d].ga = gates[s]; p.d[d].whh = whh[s]; p.d[d].c_all = c_all[s]; p.d[d].dgates = dgates[s];
   }
-  p.dy = dy; p.valid = valid_i64; p.hdr = (unsigned*)ws;
+  p.dy = dy; p.valid = valid_i64; p.ctl = ps_ctl(ws);
   p.T = T; p.B = B; p.H = H; p.ndir = ndir; p.nbt = ag_cdiv(B, 16); p.ntile = H / 32;
   p.rb = ag_precision() == AG_PREC_BF16;
   const int grid = ndir * p.nbt * p.ntile;
@@ -592,7 +646,7 @@ struct FrontFwdP {
   float* x;            // [B, T*fs]
   float* hx;           // exchange: h   [2][nrt][S/8][32][8]
   float* xx;           // exchange: x   [2][nrt][fs/8][32][8]
-  unsigned* hdr;
+  PersistCtl ctl;
   int T, B, ldwx, nrt, rb;
 };
 
@@ -606,9 +660,12 @@ __global__ __launch_bounds__(512) void gfront_persist_fwd_kernel(const FrontFwdP
   constexpr int UP = S / 128;                // 16-k units of W_p per wave
   static_assert(S % 128 == 0 && FS % 64 == 0 && NB <= NUT, "unsupported front shape");
   __shared__ float red[8 * 1024];
+  __shared__ int s_dead;
   const int T = p.T, B = p.B;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l31 = lane & 31, hh = lane >> 5, li = lane & 15, g = lane >> 4;
+  if (tid == 0) s_dead = 0;
+  __syncthreads();
   const int rt = blockIdx.x % p.nrt, ut = blockIdx.x / p.nrt;
   const int u0 = ut * 8, row0 = rt * 32;
 
@@ -673,8 +730,8 @@ __global__ __launch_bounds__(512) void gfront_persist_fwd_kernel(const FrontFwdP
     }
   }
 
-  unsigned* flag_h = p.hdr + PS_FLAG_OFF + rt * NUT;
-  unsigned* flag_x = p.hdr + PS_FLAG_OFF + p.nrt * NUT + rt * NB;
+  unsigned* flag_h = p.ctl.hdr + PS_FLAG_OFF + rt * NUT;
+  unsigned* flag_x = p.ctl.hdr + PS_FLAG_OFF + p.nrt * NUT + rt * NB;
   const int64_t hgs = (int64_t)NUT * 32 * 8, xgs = (int64_t)(FS / 8) * 32 * 8;     // floats per (parity, rt)
   __amdgpu_buffer_rsrc_t hr = __builtin_amdgcn_make_buffer_rsrc(p.hx, 0, (int)(2 * p.nrt * hgs * 4), 0x00020000);
   __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(p.xx, 0, (int)(2 * p.nrt * xgs * 4), 0x00020000);
@@ -703,7 +760,10 @@ __global__ __launch_bounds__(512) void gfront_persist_fwd_kernel(const FrontFwdP
     if (t > 0) {
       const int par = (t - 1) & 1;
       // ---- h part (its flags were already waited for by the projection phase of frame t-1 on projection workgroups)
-      if (wid == 0 && alive) alive = ps_wait_flags(p.hdr, flag_h, NUT, (unsigned)t, lane);
+      if (wid == 0 && alive) {
+        alive = ps_wait_flags(p.ctl, flag_h, NUT, (unsigned)t, lane);
+        if (!alive) s_dead = 1;
+      }
       __syncthreads();
       if (PM == 2) {
         const unsigned ab = (unsigned)(((int64_t)(par * p.nrt + rt) * hgs + (int64_t)l31 * 8) * 4);
@@ -733,7 +793,10 @@ __global__ __launch_bounds__(512) void gfront_persist_fwd_kernel(const FrontFwdP
           for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a[q][e]), wh[PM == 2 ? 0 : q][e], acc, 0, 0, 0);
       }
       // ---- x part
-      if (wid == 0 && alive) alive = ps_wait_flags(p.hdr, flag_x, NB, (unsigned)t, lane);
+      if (wid == 0 && alive) {
+        alive = ps_wait_flags(p.ctl, flag_x, NB, (unsigned)t, lane);
+        if (!alive) s_dead = 1;
+      }
       __syncthreads();
       if (PM == 2) {
         const unsigned ab = (unsigned)(((int64_t)(par * p.nrt + rt) * xgs + (int64_t)l31 * 8) * 4);
@@ -781,6 +844,7 @@ __global__ __launch_bounds__(512) void gfront_persist_fwd_kernel(const FrontFwdP
       ig = ag_sigmoid(g4[0]); fg = ag_sigmoid(g4[1]); gg = tanhf(g4[2]); og = ag_sigmoid(g4[3]);
       creg = fg * creg + ig * gg;
       hreg = og * tanhf(creg);
+      if (s_dead) creg = hreg = ig = __builtin_nanf("");             // a wait timed out: poison instead of garbage
     }
     if (tid < 256) {
       // publish h_t (rows past the batch: zeros, so that the exchange buffer stays defined)
@@ -789,7 +853,8 @@ __global__ __launch_bounds__(512) void gfront_persist_fwd_kernel(const FrontFwdP
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
-    if (tid == 0) __hip_atomic_store(flag_h + ut, (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0 && (int)blockIdx.x != p.ctl.mute)
+      __hip_atomic_store(flag_h + ut, (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (epi) {
       float* pr = p.gates + ((int64_t)t * B + em) * 4 * S + eu;
       pr[0] = ig; pr[S] = fg; pr[2 * S] = gg; pr[3 * S] = og;
@@ -798,7 +863,10 @@ __global__ __launch_bounds__(512) void gfront_persist_fwd_kernel(const FrontFwdP
     }
     // ---- phase B: this workgroup's tile of x_t = tanh(h_t W_p^T + b)
     if (bwg) {
-      if (wid == 0 && alive) alive = ps_wait_flags(p.hdr, flag_h, NUT, (unsigned)(t + 1), lane);
+      if (wid == 0 && alive) {
+        alive = ps_wait_flags(p.ctl, flag_h, NUT, (unsigned)(t + 1), lane);
+        if (!alive) s_dead = 1;
+      }
       __syncthreads();
       f32x4 pacc = {0.f, 0.f, 0.f, 0.f};
       if (PM == 2) {
@@ -840,7 +908,7 @@ __global__ __launch_bounds__(512) void gfront_persist_fwd_kernel(const FrontFwdP
         float v = bbias;
 #pragma unroll
         for (int w = 0; w < 8; ++w) v += red[w * 256 + tid];
-        v = tanhf(v);
+        v = s_dead ? __builtin_nanf("") : tanhf(v);
         const int col = bcol0 + bcl;
         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(bm < B ? v : 0.f), xr,
             (unsigned)(((int64_t)((t & 1) * p.nrt + rt) * xgs + ((int64_t)(col >> 3) * 32 + 16 * bsub + brow) * 8 + (col & 7)) * 4), 0, 16);
@@ -863,7 +931,7 @@ static bool front_shape_ok(int B, int S, int fs, int n_cu) {
 extern "C" int ag_gfront_persist_ok(int B, int S, int fs, int n_cu) { return front_shape_ok(B, S, fs, n_cu) ? 1 : 0; }
 
 extern "C" int64_t ag_gfront_persist_ws_bytes(int B, int S, int fs) {
-  return PS_HDR_BYTES + (int64_t)2 * ag_cdiv(B, 32) * 32 * (S + fs) * 4;
+  return PS_STICKY_BYTES + PS_HDR_BYTES + (int64_t)2 * ag_cdiv(B, 32) * 32 * (S + fs) * 4;
 }
 
 // One launch for the whole frame loop of the Generator front (one LSTMCell layer).  gates [T,B,4S]: in = the z/c
@@ -883,15 +951,15 @@ extern "C" int ag_gfront_fwd_persist(float* gates, const float* w_x, int ldwx, c
   AG_REQUIRE(ldwx % 4 == 0 && (((uintptr_t)w_x | (uintptr_t)w_hh | (uintptr_t)w_p) & 15) == 0,
              "ag_gfront_fwd_persist: weights must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(ws, 0, PS_HDR_BYTES, st) != hipSuccess) {
+  if (hipMemsetAsync((char*)ws + PS_STICKY_BYTES, 0, PS_HDR_BYTES, st) != hipSuccess) {
     ag_set_error("ag_gfront_fwd_persist: memset failed");
     return AG_ERR_LAUNCH;
   }
   FrontFwdP p;
   p.gates = gates; p.wx = w_x; p.whh = w_hh; p.wp = w_p; p.bp = b_p; p.hs = hs; p.cs = cs; p.x = x;
-  p.hdr = (unsigned*)ws;
+  p.ctl = ps_ctl(ws);
   p.nrt = ag_cdiv(B, 32);
-  p.hx = (float*)((char*)ws + PS_HDR_BYTES);
+  p.hx = (float*)((char*)ws + PS_STICKY_BYTES + PS_HDR_BYTES);
   p.xx = p.hx + (int64_t)2 * p.nrt * 32 * S;
   p.T = T; p.B = B; p.ldwx = ldwx; p.rb = ag_precision() == AG_PREC_BF16;
   const int grid = p.nrt * (S / 8);

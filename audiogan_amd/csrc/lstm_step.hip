@@ -319,6 +319,7 @@ extern "C" int64_t ag_skinny_ws_numel(int M, int N, int K) {
 extern "C" int ag_skinny_gemm(const float* A, int lda, const float* B, int ldb, int tb, float* C, int ldc,
                               int M, int N, int K, float beta, const float* bias, int act, float slope,
                               int accumulate_atomic, void* stream) {
+  const AgWs ws = ag_ws_take();     // FIRST: an argument error below must not leave a stale binding behind
   AG_REQUIRE(A && B && C, "ag_skinny_gemm: null tensor");
   AG_REQUIRE(M > 0 && M <= 256 && N > 0 && K > 0, "ag_skinny_gemm: needs 0 < M <= 256");
   AG_REQUIRE(K % 8 == 0 && lda % 4 == 0 && ((uintptr_t)A & 15) == 0, "ag_skinny_gemm: A must be 16-B aligned, K%%8==0");
@@ -329,7 +330,7 @@ extern "C" int ag_skinny_gemm(const float* A, int lda, const float* B, int ldb, 
   p.q[1] = p.q[0];
   p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.M = M; p.N = N; p.K = K; p.tb = tb; p.act = act;
   p.slope = slope; p.beta = beta;
-  return launch_skinny(p, 1, accumulate_atomic, (hipStream_t)stream, ag_ws_take());
+  return launch_skinny(p, 1, accumulate_atomic, (hipStream_t)stream, ws);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -830,13 +831,13 @@ extern "C" int ag_lstm_seq_bwd(const float* const* gates, const float* const* wh
                                const float* const* c_all, const float* dy, float* const* dgates,
                                float* const* dhbuf, float* const* dcbuf, const int64_t* valid_i64, int T,
                                int B, int H, int ndir, int k_begin, int k_end, int phases, void* stream) {
+  const AgWs ws = ag_ws_take();     // FIRST: an argument error below must not leave a stale binding behind
   AG_REQUIRE(gates && whh && c_all && dy && dgates && dhbuf && dcbuf, "ag_lstm_seq_bwd: null table");
   AG_REQUIRE(phases >= 1 && phases <= 3, "ag_lstm_seq_bwd: phases is a bit mask (1 cell, 2 product)");
   AG_REQUIRE(ndir == 1 || ndir == 2, "ag_lstm_seq_bwd: ndir must be 1 or 2");
   AG_REQUIRE(T > 0 && B > 0 && B <= 256 && (4 * H) % 8 == 0, "ag_lstm_seq_bwd: bad shape");
   AG_REQUIRE(0 <= k_begin && k_begin <= k_end && k_end <= T, "ag_lstm_seq_bwd: bad step range");
   hipStream_t st = (hipStream_t)stream;
-  const AgWs ws = ag_ws_take();     // (only the unfused fallback below reduces across workgroups)
   const int64_t BH = (int64_t)B * H, BG = (int64_t)B * 4 * H;
   if (phases == 3 && H % 16 == 0) {
     // fused path: launch k = product of step k+1 + cell backward of step k

@@ -375,9 +375,9 @@ __global__ void grad_norms_finish_kernel(float* __restrict__ sq_to_norm, float* 
 
 extern "C" int ag_grad_norms(const ag_opt_desc* descs_dev, int n, float* norms, float* norm_sum,
                              int32_t* flags, float grad_scale, int32_t* step_dev, void* stream) {
+  const AgWs ws = ag_ws_take();     // FIRST: an argument error below must not leave a stale binding behind
   AG_REQUIRE(descs_dev && norms && n > 0 && n <= 65535, "ag_grad_norms: bad args");
   hipStream_t st = (hipStream_t)stream;
-  const AgWs ws = ag_ws_take();
   float* part = (ws.p && ws.numel >= (int64_t)n * OPT_CHUNKS) ? ws.p : nullptr;    // two-stage sum of squares
   if (!part && hipMemsetAsync(norms, 0, sizeof(float) * n, st) != hipSuccess) {
     ag_set_error("ag_grad_norms: memset failed");

@@ -27,7 +27,7 @@ class GradBucket(object):
         self.flat = torch.zeros(n, device=dev, dtype=torch.float32)
         assert comm_dtype in ('f32', 'bf16')
         self.comm = torch.zeros(n, device=dev, dtype=torch.bfloat16) if comm_dtype == 'bf16' else None
-        self._pending = None
+        self._pending = []        # (work or None, lo, hi) of every all-reduce not yet waited for / widened
         o = 0
         for p in self.params:
             p.grad = self.flat[o:o + p.numel()].view(p.shape)
@@ -35,7 +35,6 @@ class GradBucket(object):
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         # force_collective: issue the all-reduce even in a 1-rank group (single-GPU rehearsal of the RCCL path)
         self.force = bool(force_collective) and dist.is_available() and dist.is_initialized()
-        self._work = None
 
     def zero(self):
         self.flat.zero_()
@@ -58,28 +57,27 @@ class GradBucket(object):
             lo, hi = {'all': (0, self.flat.numel()), 'early': (0, self.n_early),
                       'late': (self.n_early, self.flat.numel())}[part]
             if hi > lo:
+                assert all(h <= lo or hi <= l for _, l, h in self._pending), \
+                    'GradBucket.all_reduce: this range already has an all-reduce in flight; call wait() first'
                 buf = self.flat[lo:hi]
                 if self.comm is not None:
                     buf = self.comm[lo:hi]
                     buf.copy_(self.flat[lo:hi])            # fp32 -> bf16 (RNE), once per rank
-                    self._pending = (lo, hi)
-                self._work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+                work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+                self._pending.append((work if async_op else None, lo, hi))
                 if not async_op:
-                    self._work = None
-                    self._widen()
+                    self.wait()
         return 1.0 / self.world
 
-    def _widen(self):
-        if self._pending is not None:
-            lo, hi = self._pending
-            self.flat[lo:hi].copy_(self.comm[lo:hi])       # bf16 sum -> the fp32 bucket the optimiser reads
-            self._pending = None
-
     def wait(self):
-        if self._work is not None:
-            self._work.wait()
-            self._work = None
-        self._widen()
+        """complete every all-reduce issued so far, in issue order (and widen bf16 sums back into the fp32 bucket the
+        optimiser reads)"""
+        pend, self._pending = self._pending, []
+        for work, lo, hi in pend:
+            if work is not None:
+                work.wait()
+            if self.comm is not None:
+                self.flat[lo:hi].copy_(self.comm[lo:hi])
 
 
 def broadcast_parameters(module, src=0, group=None):

@@ -60,6 +60,7 @@ def _bind_ws(numel, dev):
     """bind `numel` floats of scratch for the NEXT reducing call (ag_bind_workspace); the tensor comes from torch's
     stream-ordered caching allocator, so it is safe to drop it as soon as the call has been enqueued"""
     if not DETERMINISTIC[0] or numel <= 0:
+        lib.ag_bind_workspace(None, 0)       # no workspace for this call: drop whatever an earlier, failed call left bound
         return None
     ws = torch.empty(int(numel), dtype=torch.float32, device=dev)
     check(lib.ag_bind_workspace(_p(ws), int(numel)), 'ag_bind_workspace')
@@ -693,22 +694,57 @@ def lstm_persist_ok(B, H, ndir, dev):
     return bool(PERSIST[0] and lib.ag_lstm_persist_ok(B, H, ndir, _n_cu(dev)))
 
 
+_PERSIST_WS_MIN = 8 << 20      # covers every BASELINE shape (biLSTM at 256 clips, H 768: 3.2 MB; the generator front: 0.7 MB)
+
+
 def _persist_workspace(dev, nbytes):
-    ws = _persist_ws.get(dev)
-    if ws is None or ws.numel() < nbytes:
+    """the per-device workspace of the persistent launches (sticky status word + header + exchange buffers).  Allocated
+    once at a size that covers every shape the kernels accept at BASELINE batch sizes; if a later call still needs more,
+    a NEW buffer becomes current and the old one stays alive for good: a captured hipGraph has its pointer baked into
+    memset and kernel nodes and keeps using it on every replay (freeing it would hand that memory to another tensor)."""
+    lst = _persist_ws.setdefault(dev, [])
+    if not lst or lst[0].numel() < nbytes:
         if torch.cuda.is_current_stream_capturing():
             raise RuntimeError('audiogan_amd: the persistent LSTM workspace must exist before hipGraph capture '
                                '(run one eager step first)')
-        ws = _persist_ws[dev] = torch.zeros(int(nbytes), dtype=torch.uint8, device=dev)
-    return ws
+        lst.insert(0, torch.zeros(max(int(nbytes), _PERSIST_WS_MIN), dtype=torch.uint8, device=dev))
+    return lst[0]
 
 
-def lstm_persist_status(dev=None):
-    """status word of the last persistent launch(es) on `dev` (0 = ok; host sync).  Non-zero: a bounded wait timed
-    out, i.e. the launch's workgroups were not all co-resident (another persistent launch in flight?)."""
+def lstm_persist_status(dev=None, reset=False):
+    """sticky status of EVERY persistent launch on `dev` since the workspace was allocated (or since the last
+    ``reset=True``): 0 = all completed (host sync).  Non-zero: a bounded wait timed out, i.e. a launch's workgroups were
+    not all co-resident (another persistent or RCCL kernel holding CUs, a CU mask, a partition mode); everything that
+    launch produced afterwards is NaN."""
     dev = torch.device('cuda', torch.cuda.current_device()) if dev is None else torch.device(dev)
-    ws = _persist_ws.get(dev)
-    return 0 if ws is None else int(ws[:4].view(torch.int32).item())
+    if dev.index is None:
+        dev = torch.device('cuda', torch.cuda.current_device())
+    st = 0
+    for ws in _persist_ws.get(dev, []):
+        st |= int(ws[:4].view(torch.int32).item()) & 0xFFFFFFFF
+        if reset:
+            ws[:4].zero_()
+    return st
+
+
+class PersistentLaunchError(RuntimeError):
+    pass
+
+
+def check_persist_status(dev=None):
+    """raise if any persistent launch on `dev` gave up (see lstm_persist_status); resets the sticky word"""
+    st = lstm_persist_status(dev)
+    if st:
+        lstm_persist_status(dev, reset=True)
+        raise PersistentLaunchError(
+            'audiogan_amd: a persistent recurrent launch timed out waiting for its group (status 0x%08x: step %d); its '
+            'workgroups were not all co-resident - is another persistent or collective kernel holding compute units? '
+            'Results of that launch are NaN.  AG_LSTM_PERSIST=0 selects the per-step kernels.' % (st, st & 0x7FFFFFFF))
+
+
+def persist_debug(timeout_ticks=0, mute_block=-1):
+    """test hook (ag_persist_debug)"""
+    check(lib.ag_persist_debug(int(timeout_ticks), int(mute_block)), 'ag_persist_debug')
 
 
 def lstm_seq_fwd_persist(pre, whh, c_all, y, valid, static=None):
@@ -817,7 +853,7 @@ def _lstm_seq_bwd_persist_call(gates, whh, c_all, dy, dgates, valid):
             assert t_.is_contiguous() and tuple(t_.shape) == shp, (tuple(t_.shape), shp)
     _chk(dy, 'dy'); _chk(valid, 'valid', torch.int64)
     assert dy.is_contiguous() and tuple(dy.shape) == (T, B, ndir * H)
-    ws = _persist_workspace(dy.device, 8192)
+    ws = _persist_workspace(dy.device, 8192 + 256)
     check(lib.ag_lstm_seq_bwd_persist(_ptr_table(gates), _ptr_table(whh), _ptr_table(c_all), _p(dy),
                                       _ptr_table(dgates), _p(valid), _p(ws), ws.numel(), T, B, H, ndir,
                                       _n_cu(dy.device), _stream()), 'ag_lstm_seq_bwd_persist')

@@ -94,7 +94,8 @@ class _Fused(object):
     def step(self, clip_norm=0.0, grad_scale=1.0, check=False):
         """``clip_norm``: per-PARAMETER L2 clip (0 = off) exactly as clip_grad; ``grad_scale``
         multiplies every gradient first (1/world_size after a sum all-reduce); ``check`` reads
-        the NaN/|g|>1e5 flags back (one host sync) and asserts like check_grad."""
+        the NaN/|g|>1e5 flags back (one host sync) and asserts like check_grad; it also reads the sticky status word of
+        the persistent recurrent launches and raises ``kernels.PersistentLaunchError`` if one of them gave up."""
         self._ensure()
         st = self._state
         live = [(p, p.grad, a, (st['s2'][i] if st['s2'] else None))
@@ -109,6 +110,8 @@ class _Fused(object):
         K.grad_norms(ps, gs, s1, s2, st['norms'], st['norm_sum'], st['flags'], grad_scale, st['step'])
         if check:
             f = int(st['flags'].item())
+            if self.params[0].is_cuda:
+                K.check_persist_status(self.params[0].device)     # a persistent launch that gave up (its outputs are NaN)
             assert not (f & 1), 'NaN in gradients (check_grad)'
             assert not (f & 2), '|grad| > 1e5 (check_grad)'
         self._launch(ps, gs, s1, s2, st['norms'], clip_norm, grad_scale)

@@ -378,8 +378,27 @@ class GraphedStep(object):
             torch.cuda.synchronize()
             raise
 
-    def step(self):
-        """one G+D step; returns (loss_d, loss_g) - device scalars overwritten by the next step"""
+    def status(self):
+        """sticky status word of the persistent recurrent launches on this device (0 = every launch of every replay so
+        far completed; one host sync).  Replays cannot raise from inside the graph: call this (or ``check()``) every
+        N steps / at the end of a run."""
+        from . import kernels as K
+        return K.lstm_persist_status(self.b['real'].device)
+
+    def check(self):
+        """raise ``kernels.PersistentLaunchError`` if a persistent launch of any replay gave up"""
+        from . import kernels as K
+        K.check_persist_status(self.b['real'].device)
+
+    def step(self, check=False):
+        """one G+D step; returns (loss_d, loss_g) - device scalars overwritten by the next step.  ``check``: synchronise
+        and verify the persistent launches' status afterwards (see ``status``)."""
+        out = self._step()
+        if check:
+            self.check()
+        return out
+
+    def _step(self):
         if self.graph is not None:
             self.graph.replay()
         else:

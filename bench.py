@@ -159,7 +159,7 @@ def cpu_baseline(batch, steps, opt_kind, threads=0, budget_s=110.0, warm=2, work
     t = float(np.median(timed))
     short = '' if len(timed) >= steps else ' (time budget of %.0f s reached: %d of the %d timed steps asked for)' % (
         budget_s, len(timed), steps)
-    return dict(value=batch * L / t, unit='audio-samples/sec', cores=cores, kind='port',
+    return dict(value=batch * L / t, unit='audio-samples/sec', cores=cores, host_cores=os.cpu_count() or 0, kind='port',
                 sample='%d of the 64 clips per step, %d timed step(s) after %d warm-up%s (median %.2f s/step), '
                        'torch %s CPU, %d threads, %s' % (batch, len(timed), nwarm, short, t, torch.__version__,
                                                          cores, opt_kind))
@@ -335,6 +335,9 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     rec = K.Profiler.stop() if (dominant is not None and not graphed) else {}
+    # sticky status word of the persistent recurrent launches: non-zero = some launch of the warm-up or the timed region
+    # gave up waiting for its group (its results are NaN) - the number above would then be meaningless
+    persist_status = K.lstm_persist_status(dev)
 
     # ---- replay check (outside the timed region): one more replay of the captured step against one EAGER step from
     # the same parameters / optimiser state on the same batch; loss_d and loss_g must agree
@@ -359,6 +362,7 @@ def main():
         rel = max(abs(a - b) / max(abs(b), 1e-12) for a, b in zip(got, ref))
         replay = dict(ok=bool(rel <= 2e-4 and all(np.isfinite(got))), max_rel_diff=rel,
                       loss_d=[got[0], ref[0]], loss_g=[got[1], ref[1]])
+    persist_status |= K.lstm_persist_status(dev)          # ... and of the replay check's launches
     if graphed and dominant is not None:
         # per-kernel HIP-event timing is impossible inside a graph replay: time the dominant
         # kernel class in eager steps right after the timed region (same kernels, same shapes)
@@ -397,6 +401,7 @@ def main():
                                   if phases is not None
                                   else 'eager' + (' (capture failed: %s)' % capture_error if capture_error else ''))},
         }
+        out['persist_status'] = persist_status
         if replay is not None:
             out['replay_check'] = 'ok' if replay['ok'] else 'FAILED'
             out['replay_check_detail'] = {k: v for k, v in replay.items() if k != 'ok'}
@@ -441,7 +446,7 @@ def main():
                 for k, v in sorted(disc.items(), key=lambda kv: -kv[1]['ms'])[:14]]
         if world == 1 and not args.no_cpu_baseline:
             # torch CPU does not scale past ~32 threads on this model (128 threads measured slower
-            # than 8): use min(32, cores); `cores` in the result is the thread count actually used
+            # than 8): use min(32, cores); `cores` in the result is the thread count actually used, `host_cores` what the box has
             out['cpu_baseline'] = cpu_baseline(args.cpu_batch if not alt else min(args.cpu_batch, 16),
                                                args.cpu_steps if not alt else min(args.cpu_steps, 3), args.opt,
                                                min(32, os.cpu_count() or 1), workload=args.workload)
@@ -449,6 +454,9 @@ def main():
     if world > 1 or rehearse:
         dist.barrier()
         dist.destroy_process_group()
+    if persist_status != 0:
+        sys.stderr.write('a persistent recurrent launch timed out (status 0x%08x): results invalid\n' % persist_status)
+        sys.exit(2)
     if replay is not None and not replay['ok']:
         sys.stderr.write('replay check FAILED: %r\n' % (replay,))
         sys.exit(1)

@@ -280,10 +280,17 @@ int ag_lstm_seq_bwd(const float* const* gates, const float* const* whh, const fl
  * crosses workgroups (write-through stores + one agent-scope flag per workgroup and step).  Replaces T launches
  * that re-stream W_hh from the fabric each.  Needs every workgroup co-resident: ag_lstm_persist_ok() says whether
  * (B, H, ndir) fits `n_cu` compute units (H % 64 == 0, H <= 768, ndir * ceil(B/32 or 64) * H/8 <= n_cu); `ws` is
- * ag_lstm_persist_ws_bytes() bytes of 16-byte aligned device memory owned by this launch while it is in flight (its
- * first 8 KiB - status word + flags - are zeroed by a memset node enqueued in front of the kernel; word 0 != 0
- * afterwards = a bounded spin timed out).  ONE persistent launch per device at a time.
+ * ag_lstm_persist_ws_bytes() bytes of 16-byte aligned device memory owned by this launch while it is in flight.
+ * Workspace layout: [256 B sticky area][8 KiB header: launch status + flags][exchange buffers].  The header is zeroed
+ * by a memset node enqueued in front of the kernel.  The STICKY word (word 0 of the workspace, zero when the caller
+ * allocates it) is never cleared by a launch: every bounded spin that times out ORs 0x80000000|step into it, so one
+ * host read after any number of launches tells whether all of them completed.  A
+ * workgroup that gave up writes NaN into everything it produces from then on, so the failure also reaches the loss.
+ * ONE persistent launch per device at a time.
  * Tensors as for ag_lstm_seq_fwd (no hbuf: the state stays in registers). */
+/* test hook: timeout of the bounded spins in ticks of the 100 MHz realtime counter (<= 0: the default 3 s) and one
+ * block index that never publishes its flags (-1: none), applied to the persistent launches enqueued afterwards */
+int ag_persist_debug(int64_t timeout_ticks, int mute_block);
 int ag_lstm_persist_ok(int B, int H, int ndir, int n_cu);
 int64_t ag_lstm_persist_ws_bytes(int B, int H, int ndir);
 int ag_lstm_seq_fwd_persist(float* const* pre, const float* const* whh, float* const* c_all, float* y,
@@ -293,7 +300,7 @@ int ag_lstm_seq_fwd_persist(float* const* pre, const float* const* whh, float* c
 /* The layer's backward through time as ONE persistent launch: each workgroup (16 clips x 32 hidden units of one
  * direction) keeps its [4H x 32] panel of W_hh in REGISTERS for the whole sequence; dgates_k is written through
  * into the output tensor, which doubles as the exchange buffer.  H in {64,128,256,512} and
- * ndir * ceil(B/16) * H/32 <= n_cu (ag_lstm_persist_bwd_ok); `ws` >= 8 KiB as above.  Tensors as for
+ * ndir * ceil(B/16) * H/32 <= n_cu (ag_lstm_persist_bwd_ok); `ws` >= 256 B + 8 KiB, laid out as above.  Tensors as for
  * ag_lstm_seq_bwd (no dhbuf/dcbuf: the state stays in registers). */
 int ag_lstm_persist_bwd_ok(int B, int H, int ndir, int n_cu);
 int ag_lstm_seq_bwd_persist(const float* const* gates, const float* const* whh, const float* const* c_all,

@@ -38,7 +38,10 @@ def test_checkpoint_roundtrip_and_reference_key_compat(tmp_path, monkeypatch):
     # a reference-style checkpoint (whole-module pickle, audiogan.py:936-939) loads too
     torch.save(go, prefix + '-gen-00777')
     g3 = A.Generator(16, 6, 5, 24, 1, struct=[[9, 4, 8, 4]])
-    checkpoint.load(prefix, 777, g=g3)
+    import pytest
+    with pytest.raises(RuntimeError):
+        checkpoint.load(prefix, 777, g=g3)            # whole-module pickles execute code: refused unless asked for
+    checkpoint.load(prefix, 777, g=g3, allow_pickle=True)
     for (k, a), (_, b) in zip(g.state_dict().items(), g3.state_dict().items()):
         np.testing.assert_array_equal(a.numpy(), b.numpy(), err_msg=k)
     # the RNG stream is restored: the draw after load() repeats the draw after save()
@@ -47,3 +50,11 @@ def test_checkpoint_roundtrip_and_reference_key_compat(tmp_path, monkeypatch):
     torch.randn(100)
     checkpoint.load(prefix, 900, g=g2, opt_g=og2)
     np.testing.assert_array_equal(torch.randn(5).numpy(), a.numpy())
+    assert checkpoint.load.last_rng == 'restored'
+    # inference-only load (no optimiser): the RNG streams are left alone
+    torch.manual_seed(3)
+    a = torch.randn(3)
+    torch.manual_seed(3)
+    checkpoint.load(prefix, 900, g=g2)
+    assert checkpoint.load.last_rng == 'not restored'
+    np.testing.assert_array_equal(torch.randn(3).numpy(), a.numpy())

@@ -570,3 +570,53 @@ def test_gfront_persistent_launch(K, S, fs, B, T):
     close(outs[1][1], outs[0][1], rtol=1e-4, atol=1e-5)
     for a, b in zip(outs[1][2], outs[0][2]):
         close(a, b, rtol=1e-3, atol=1e-5 * max(1.0, float(b.abs().max())))
+
+
+def test_persistent_launch_timeout_surfaces(K):
+    """a persistent launch whose group never completes (one workgroup muted on purpose, 2 ms timeout): the launch
+    still ENDS, the sticky status word is set and survives later (healthy) launches, the stalled group's outputs are NaN,
+    and the product's checks raise - ADVICE round 2: such a failure used to leave plausible garbage with rc 0"""
+    from audiogan_amd import ops, optim
+    T, B, H, ndir = 6, 40, 128, 2
+    assert K.lstm_persist_ok(B, H, ndir, torch.device('cuda', 0))
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn(T, B, 24, generator=gen).cuda()
+    w = []
+    for _ in range(ndir):
+        w += [torch.nn.Parameter(torch.randn(4 * H, 24, generator=gen).cuda() * 0.1),
+              torch.nn.Parameter(torch.randn(4 * H, H, generator=gen).cuda() * 0.1),
+              torch.nn.Parameter(torch.zeros(4 * H).cuda()), torch.nn.Parameter(torch.zeros(4 * H).cuda())]
+    K.lstm_persist_status(reset=True)
+    y_ok = ops.LSTMSeqFn.apply(x, None, ndir, None, *w).detach().clone()
+    torch.cuda.synchronize()
+    assert K.lstm_persist_status() == 0 and bool(torch.isfinite(y_ok).all())
+    try:
+        K.persist_debug(timeout_ticks=200000, mute_block=0)          # 2 ms; block 0 never raises its flag
+        y_bad = ops.LSTMSeqFn.apply(x, None, ndir, None, *w)
+        torch.cuda.synchronize()
+    finally:
+        K.persist_debug(0, -1)
+    st = K.lstm_persist_status()
+    assert st & 0x80000000, hex(st)
+    assert bool(torch.isnan(y_bad).any()), 'a group that gave up must poison its outputs'
+    # a healthy launch afterwards does not clear the sticky word ...
+    y2 = ops.LSTMSeqFn.apply(x, None, ndir, None, *w)
+    torch.cuda.synchronize()
+    assert torch.equal(y2.detach(), y_ok) and K.lstm_persist_status() == st
+    # ... and the optimiser's check= path raises (then the word is reset)
+    opt = optim.make_optimizer(w, 'adam', 1e-4)
+    y2.sum().backward()
+    with pytest.raises(K.PersistentLaunchError):
+        opt.step(check=True)
+    assert K.lstm_persist_status() == 0
+    opt.step(check=True)
+
+
+def test_persistent_workspace_is_never_freed(K):
+    """a larger request after a buffer was handed out must not free that buffer (a captured graph keeps its pointer)"""
+    dev = torch.device('cuda', torch.cuda.current_device())
+    a = K._persist_workspace(dev, 1024)
+    b = K._persist_workspace(dev, a.numel() + 4096)
+    assert b.numel() >= a.numel() + 4096 and a.data_ptr() != b.data_ptr()
+    assert any(t is a for t in K._persist_ws[dev]) and K._persist_ws[dev][0] is b
+    assert K._persist_workspace(dev, 1024) is b
