@@ -95,3 +95,29 @@ def test_full_step_host_logic(monkeypatch):
 def test_full_step_gpu(kind):
     import audiogan_amd as A
     _run(torch.device('cuda'), A, kind)
+
+
+def _run_reference_fixture(dev, A, golden_dir):
+    """the product's d_step_full / g_step_full against tests/golden/ref_step.npz = what the REFERENCE's own loop bodies
+    (audiogan.py:711-788, :822-921) produced, incl. every post-step parameter"""
+    from audiogan_amd import optim, train
+    from tests import step_fixture as SF
+    v = SF.load(golden_dir)
+    g, d, e_g, e_d = mods = SF.build(A, v, dev)
+    opt_g = optim.make_optimizer(list(g.parameters()) + list(e_g.parameters()), 'rmsprop', 1e-4)
+    opt_d = optim.make_optimizer(list(d.parameters()) + list(e_d.parameters()), 'rmsprop', 1e-4)
+    agree = SF.run(v, mods, opt_d, opt_g, train.d_step_full, train.g_step_full, dev, rtol=1e-3, atol_scale=1e-4,
+                   post_atol=2e-3)
+    assert agree > 0.99
+
+
+def test_full_step_reference_fixture_host_logic(monkeypatch, golden_dir):
+    kernel_model.install(monkeypatch)
+    import audiogan_amd as A
+    _run_reference_fixture(torch.device('cpu'), A, golden_dir)
+
+
+@pytest.mark.gpu
+def test_full_step_reference_fixture_gpu(golden_dir):
+    import audiogan_amd as A
+    _run_reference_fixture(torch.device('cuda'), A, golden_dir)

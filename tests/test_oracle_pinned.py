@@ -199,3 +199,83 @@ def test_c2_width_fixture(golden_dir):
                 continue
             got = float(ps[k].grad.norm()) if ps[k].grad is not None else 0.0
             np.testing.assert_allclose(got, n, rtol=1e-3, atol=1e-7, err_msg=k)
+
+
+# --------------------------------------------------------------------------------------------------------------
+# round 3: the reference's own loader (dataset.py) and its own training-loop bodies (audiogan.py:711-788, :822-921)
+# --------------------------------------------------------------------------------------------------------------
+def test_dataset_interface_matches_reference_loader(golden_dir):
+    """audiogan_amd/dataset.py against results of the REFERENCE's dataset.py run by oracle/pin_reference.py on the same
+    in-memory word dataset with the same global numpy seeds: every array bit-exact (same RNG calls in the same order)"""
+    import types
+    import numpy.random as RNG
+    from audiogan_amd import dataset as D
+    v = _load(golden_dir, 'ref_dataset.npz')
+    ds = {str(w): v['ds.' + str(w)] for w in v['ds_order']}
+    args = types.SimpleNamespace(conditional=True, dataset=ds, minwordlen=2, subset=None, amplitudes=6)
+    RNG.seed(11)
+    dataset, maxlen, gen_train, gen_val, keys_train, keys_val = D.dataloader(3, args, maxlen=140, frame_size=32)
+    assert dataset is ds and maxlen == int(v['maxlen'])
+    assert list(keys_train) == [str(k) for k in v['keys_train']] and list(keys_val) == [str(k) for k in v['keys_val']]
+
+    def same(got, pre):
+        e, b, samples, lengths, keys, cseq, clen = got
+        np.testing.assert_array_equal([e, b], v[pre + 'epoch_batch'])
+        assert samples.dtype == v[pre + 'samples'].dtype and cseq.dtype == v[pre + 'cseq'].dtype
+        np.testing.assert_array_equal(samples, v[pre + 'samples'])
+        np.testing.assert_array_equal(lengths, v[pre + 'lengths'])
+        assert [str(k) for k in keys] == [str(k) for k in v[pre + 'keys']]
+        np.testing.assert_array_equal(cseq, v[pre + 'cseq'])
+        np.testing.assert_array_equal(clen, v[pre + 'clen'])
+    for i in range(3):
+        same(next(gen_train), 't%d_' % i)
+    same(next(gen_val), 'v0_')
+    maxchar = max(len(k) for k in keys_train)
+    keys, cs, cl, smp, ln = D.pick_words(4, maxlen, ds, keys_train, maxchar, args, skip_samples=True)
+    assert [str(k) for k in keys] == [str(k) for k in v['pw_keys']]
+    np.testing.assert_array_equal(cs, v['pw_cseq']); np.testing.assert_array_equal(cl, v['pw_clen'])
+    np.testing.assert_array_equal(smp, v['pw_samples']); np.testing.assert_array_equal(ln, v['pw_lengths'])
+    RNG.seed(12)
+    args2 = types.SimpleNamespace(conditional=True, dataset=ds, minwordlen=1, subset=None, amplitudes=6)
+    _, maxlen2, gen2, _, keys2, _ = D.dataloader(5, args2)
+    assert maxlen2 == int(v['maxlen2']) and list(keys2) == [str(k) for k in v['keys2']]
+    e, b, samples, lengths, keys, cseq, clen = next(gen2)
+    np.testing.assert_array_equal(samples, v['n_samples']); np.testing.assert_array_equal(lengths, v['n_lengths'])
+    assert [str(k) for k in keys] == [str(k) for k in v['n_keys']]
+    np.testing.assert_array_equal(cseq, v['n_cseq']); np.testing.assert_array_equal(clen, v['n_clen'])
+    RNG.seed(13)
+    for i in range(12):           # 'toolong' never fits, 'silent' is all zeros: both are redrawn
+        k, seq, n, smp, ln = D.pick_word(150, ds, ['toolong', 'silent', 'hello'], 7, args2)
+        assert k == 'hello'
+    np.testing.assert_array_equal(smp, v['redraw_last'])
+    np.testing.assert_array_equal(RNG.randint(0, 1 << 30, size=4), v['redraw_rng_after'])   # same number of RNG calls
+    RNG.seed(14)
+    unc = {'data': np.arange(80 * 8, dtype=np.float32).reshape(80, 8)}
+    none, gu, gv = D.dataloader(8, types.SimpleNamespace(conditional=False, dataset=unc, subset=None, amplitudes=6))
+    assert none is None
+    rows = []
+    for i in range(11):
+        r = next(gu)
+        assert r[3:] == [None] * 6 and r[2].shape == (8, 6)
+        rows.append(np.concatenate([[r[0], r[1]], r[2][:, 0]]))
+    np.testing.assert_array_equal(np.array(rows), v['unc_train'])
+    r = next(gv)
+    np.testing.assert_array_equal(np.concatenate([[r[0], r[1]], r[2][:, 0]]), v['unc_val'])
+    RNG.seed(15)
+    _, gs, _ = D.dataloader(4, types.SimpleNamespace(conditional=False, dataset=unc, subset=20, amplitudes=8))
+    np.testing.assert_array_equal(next(gs)[2], v['unc_subset'])
+
+
+def test_step_bodies_match_reference_loop(golden_dir):
+    """O.d_step_full / O.g_step_full held to what the reference's own loop statements (audiogan.py:711-788, :822-921)
+    produced: two critic iterations (odd = FGSM branch, even = instance noise) and one generator iteration (adversarial z,
+    feature penalty, REINFORCE of the stop head), every post-step parameter included"""
+    from tests import step_fixture as SF
+    v = SF.load(golden_dir)
+    np.testing.assert_array_equal(v['lines'], [711, 788, 822, 921])
+    g, d, e_g, e_d = mods = SF.build(O, v, torch.device('cpu'))
+    opt_g = O.make_optimizer(list(g.parameters()) + list(e_g.parameters()), 'rmsprop', 1e-4)
+    opt_d = O.make_optimizer(list(d.parameters()) + list(e_d.parameters()), 'rmsprop', 1e-4)
+    agree = SF.run(v, mods, opt_d, opt_g, O.d_step_full, O.g_step_full, torch.device('cpu'), rtol=1e-4, atol_scale=1e-5,
+                   post_atol=1e-4)
+    assert agree == 1.0
