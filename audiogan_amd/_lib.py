@@ -92,6 +92,7 @@ SIGNATURES = {
     'ag_gfront_persist_ok': (C.c_int, [C.c_int] * 4),
     'ag_gfront_persist_ws_bytes': (i64, [C.c_int] * 3),
     'ag_gfront_fwd_persist': (C.c_int, [vp, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, i64] + [C.c_int] * 5 + [vp]),
+    'ag_grufront_fwd_persist': (C.c_int, [vp, vp, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, i64] + [C.c_int] * 5 + [vp]),
     'ag_bce_logits_fwd': (C.c_int, [vp, C.c_int, f32, vp, vp, vp, f32, C.c_int, C.c_int, vp]),
     'ag_bce_logits_bwd': (C.c_int, [vp, C.c_int, f32, vp, vp, f32, vp, C.c_int, C.c_int, C.c_int, vp]),
     'ag_act_fwd': (C.c_int, [vp, vp, i64, C.c_int, f32, vp]),

@@ -644,6 +644,8 @@ struct FrontFwdP {
   float* hs;           // [T,B,S]
   float* cs;           // [T+1,B,S]  (cs[0] = 0 on entry)
   float* x;            // [B, T*fs]
+  float* gh;           // GRU cell only: [T,B,3S], the n slot receives W_hn h + b_hn (what the backward needs)
+  const float* bhn;    // GRU cell only: b_hh[2S:3S]
   float* hx;           // exchange: h   [2][nrt][S/8][32][8]
   float* xx;           // exchange: x   [2][nrt][fs/8][32][8]
   PersistCtl ctl;
@@ -652,7 +654,11 @@ struct FrontFwdP {
 
 // PM: 0 = as stored / operands rounded in registers when p.rb (fp32 MFMA); 2 = AG_PREC_BF16 on the bf16 MFMAs (panels
 // in registers as bf16: 8 k per 4 VGPRs)
-template <int S, int FS, int PM>
+// CELL: 0 = LSTMCell (4 gate columns per unit: i f g o).  1 = GRU cell (BASELINE configs[3]; PM = 0 only): the 4 column
+// blocks of a unit tile are  r | z | n_h | n_x : the h panel carries W_hr, W_hz, W_hn and zeros, the x panel W_xr, W_xz,
+// zeros and W_xn, so that ONE accumulator ends up with  r, z pre-activations complete and the two halves of n apart
+// (n = tanh(n_x + r * (n_h + b_hn)));  h_t = (1 - z) n + z h_{t-1} stays in a register like the LSTM's cell state.
+template <int S, int FS, int PM, int CELL = 0>
 __global__ __launch_bounds__(512) void gfront_persist_fwd_kernel(const FrontFwdP p) {
   constexpr int NUT = S / 8;                 // unit tiles = workgroups per row tile
   constexpr int QH = S / 64, QX = FS / 64;   // 8-k groups of the h / x panel per wave
@@ -690,16 +696,21 @@ __global__ __launch_bounds__(512) void gfront_persist_fwd_kernel(const FrontFwdP
       wxb[Q] = __builtin_bit_cast(ps_bf16x8, r);
     }
   } else {
-    const int wrow = (l31 >> 3) * S + u0 + (l31 & 7);
+    const int cb = l31 >> 3;
+    // (GRU: column block 3 of the h panel and block 2 of the x panel are zero; block 3 of the x panel is W_xn)
+    const bool hz = CELL == 1 && cb == 3, xz = CELL == 1 && cb == 2;
+    const int wrow = cb * S + u0 + (l31 & 7), wrowx = (CELL == 1 && cb == 3 ? 2 : cb) * S + u0 + (l31 & 7);
 #pragma unroll
     for (int q = 0; q < QH; ++q) {
-      const f32x4 v = ag_rbf4_if(*reinterpret_cast<const f32x4*>(p.whh + (int64_t)wrow * S + (wid * QH + q) * 8 + 4 * hh), p.rb);
+      const f32x4 v = hz ? f32x4{0.f, 0.f, 0.f, 0.f}
+                         : ag_rbf4_if(*reinterpret_cast<const f32x4*>(p.whh + (int64_t)wrow * S + (wid * QH + q) * 8 + 4 * hh), p.rb);
 #pragma unroll
       for (int e = 0; e < 4; ++e) wh[q][e] = v[e];
     }
 #pragma unroll
     for (int q = 0; q < QX; ++q) {
-      const f32x4 v = ag_rbf4_if(*reinterpret_cast<const f32x4*>(p.wx + (int64_t)wrow * p.ldwx + (wid * QX + q) * 8 + 4 * hh), p.rb);
+      const f32x4 v = xz ? f32x4{0.f, 0.f, 0.f, 0.f}
+                         : ag_rbf4_if(*reinterpret_cast<const f32x4*>(p.wx + (int64_t)wrowx * p.ldwx + (wid * QX + q) * 8 + 4 * hh), p.rb);
 #pragma unroll
       for (int e = 0; e < 4; ++e) wxr[q][e] = v[e];
     }
@@ -741,7 +752,8 @@ __global__ __launch_bounds__(512) void gfront_persist_fwd_kernel(const FrontFwdP
   const int em = row0 + erow, eu = u0 + euu;
   const bool epi = tid < 256 && em < B;
   const int ee = (erow & 3) + 4 * (erow >> 3), ehq = (erow >> 2) & 1;
-  float creg = 0.f;
+  float creg = 0.f;            // LSTM: cell state; GRU: h_{t-1}
+  const float ebhn = (CELL == 1 && epi) ? p.bhn[eu] : 0.f;
   // phase B epilogue role: thread (clip row within the 16-row subtile, column), tid < 256
   const int brow = tid >> 4, bcl = tid & 15;
   const int bm = row0 + 16 * bsub + brow;
@@ -751,8 +763,13 @@ __global__ __launch_bounds__(512) void gfront_persist_fwd_kernel(const FrontFwdP
   for (int t = 0; t < T; ++t) {
     float pre4[4] = {0.f, 0.f, 0.f, 0.f};
     if (epi) {
-      const float* pr = p.gates + ((int64_t)t * B + em) * 4 * S + eu;
-      pre4[0] = pr[0]; pre4[1] = pr[S]; pre4[2] = pr[2 * S]; pre4[3] = pr[3 * S];
+      if (CELL == 1) {
+        const float* pr = p.gates + ((int64_t)t * B + em) * 3 * S + eu;
+        pre4[0] = pr[0]; pre4[1] = pr[S]; pre4[2] = pr[2 * S];
+      } else {
+        const float* pr = p.gates + ((int64_t)t * B + em) * 4 * S + eu;
+        pre4[0] = pr[0]; pre4[1] = pr[S]; pre4[2] = pr[2 * S]; pre4[3] = pr[3 * S];
+      }
     }
     f32x16 acc;
 #pragma unroll
@@ -834,16 +851,24 @@ __global__ __launch_bounds__(512) void gfront_persist_fwd_kernel(const FrontFwdP
       float g4[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        float s = pre4[q];
+        float s = CELL == 1 ? 0.f : pre4[q];
         if (t > 0) {
 #pragma unroll
           for (int w = 0; w < 8; ++w) s += red[w * 1024 + ee * 64 + 32 * ehq + 8 * q + euu];
         }
         g4[q] = s;
       }
-      ig = ag_sigmoid(g4[0]); fg = ag_sigmoid(g4[1]); gg = tanhf(g4[2]); og = ag_sigmoid(g4[3]);
-      creg = fg * creg + ig * gg;
-      hreg = og * tanhf(creg);
+      if (CELL == 1) {
+        // ig / fg / gg = r / z / n;  og = the h half of n incl. its bias (saved for the backward)
+        og = g4[2] + ebhn;
+        ig = ag_sigmoid(pre4[0] + g4[0]); fg = ag_sigmoid(pre4[1] + g4[1]); gg = tanhf(pre4[2] + g4[3] + ig * og);
+        hreg = (1.f - fg) * gg + fg * creg;
+        creg = hreg;
+      } else {
+        ig = ag_sigmoid(g4[0]); fg = ag_sigmoid(g4[1]); gg = tanhf(g4[2]); og = ag_sigmoid(g4[3]);
+        creg = fg * creg + ig * gg;
+        hreg = og * tanhf(creg);
+      }
       if (s_dead) creg = hreg = ig = __builtin_nanf("");             // a wait timed out: poison instead of garbage
     }
     if (tid < 256) {
@@ -856,9 +881,15 @@ __global__ __launch_bounds__(512) void gfront_persist_fwd_kernel(const FrontFwdP
     if (tid == 0 && (int)blockIdx.x != p.ctl.mute)
       __hip_atomic_store(flag_h + ut, (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (epi) {
-      float* pr = p.gates + ((int64_t)t * B + em) * 4 * S + eu;
-      pr[0] = ig; pr[S] = fg; pr[2 * S] = gg; pr[3 * S] = og;
-      p.cs[((int64_t)(t + 1) * B + em) * S + eu] = creg;
+      if (CELL == 1) {
+        float* pr = p.gates + ((int64_t)t * B + em) * 3 * S + eu;
+        pr[0] = ig; pr[S] = fg; pr[2 * S] = gg;
+        p.gh[((int64_t)t * B + em) * 3 * S + 2 * S + eu] = og;
+      } else {
+        float* pr = p.gates + ((int64_t)t * B + em) * 4 * S + eu;
+        pr[0] = ig; pr[S] = fg; pr[2 * S] = gg; pr[3 * S] = og;
+        p.cs[((int64_t)(t + 1) * B + em) * S + eu] = creg;
+      }
       p.hs[((int64_t)t * B + em) * S + eu] = hreg;
     }
     // ---- phase B: this workgroup's tile of x_t = tanh(h_t W_p^T + b)
@@ -956,7 +987,7 @@ extern "C" int ag_gfront_fwd_persist(float* gates, const float* w_x, int ldwx, c
     return AG_ERR_LAUNCH;
   }
   FrontFwdP p;
-  p.gates = gates; p.wx = w_x; p.whh = w_hh; p.wp = w_p; p.bp = b_p; p.hs = hs; p.cs = cs; p.x = x;
+  p.gates = gates; p.gh = nullptr; p.bhn = nullptr; p.wx = w_x; p.whh = w_hh; p.wp = w_p; p.bp = b_p; p.hs = hs; p.cs = cs; p.x = x;
   p.ctl = ps_ctl(ws);
   p.nrt = ag_cdiv(B, 32);
   p.hx = (float*)((char*)ws + PS_STICKY_BYTES + PS_HDR_BYTES);
@@ -970,5 +1001,43 @@ extern "C" int ag_gfront_fwd_persist(float* gates, const float* w_x, int ldwx, c
     hipLaunchKernelGGL((gfront_persist_fwd_kernel<128, 64, 0>), dim3(grid), dim3(512), 0, st, p);   // (FS/8 per wave is odd)
   }
   AG_CHECK_LAUNCH("ag_gfront_fwd_persist");
+  return AG_OK;
+}
+
+// The GRU-front generator's frame loop (BASELINE configs[3]; the feedback loop of audiogan.py:428-460 with a GRU cell, gate
+// order r z n as torch.nn.GRUCell) as ONE persistent launch: the same kernel with the GRU column layout.
+//   gates [T,B,3S]  in: W_ih[:, fs:] zc_t + b_ih + (b_hr, b_hz, 0)  (one GEMM over all frames); out: activated (r, z, n)
+//   gh    [T,B,3S]  out: only the n slot, W_hn h_{t-1} + b_hn (what ag_gru_cell_bwd reads)
+//   w_x = W_ih[:, :fs] (row pitch ldwx), w_hh [3S,S], b_hn [S] = b_hh[2S:], w_p [fs,S], b_p [fs]
+//   hs [T,B,S] (h_t), x [B,T*fs].  Shapes as ag_gfront_persist_ok; workspace as ag_gfront_fwd_persist.
+extern "C" int ag_grufront_fwd_persist(float* gates, float* gh, const float* w_x, int ldwx, const float* w_hh,
+                                       const float* b_hn, const float* w_p, const float* b_p, float* hs, float* x, void* ws,
+                                       int64_t ws_bytes, int T, int B, int S, int fs, int n_cu, void* stream) {
+  AG_REQUIRE(gates && gh && w_x && w_hh && b_hn && w_p && b_p && hs && x && ws, "ag_grufront_fwd_persist: null tensor");
+  AG_REQUIRE(T > 0, "ag_grufront_fwd_persist: T must be positive");
+  if (!front_shape_ok(B, S, fs, n_cu)) {
+    ag_set_error("ag_grufront_fwd_persist: shape B=%d S=%d fs=%d is not supported on %d CUs", B, S, fs, n_cu);
+    return AG_ERR_UNSUPPORTED;
+  }
+  AG_REQUIRE(ws_bytes >= ag_gfront_persist_ws_bytes(B, S, fs) && ((uintptr_t)ws & 15) == 0,
+             "ag_grufront_fwd_persist: workspace too small or misaligned");
+  AG_REQUIRE(ldwx % 4 == 0 && (((uintptr_t)w_x | (uintptr_t)w_hh | (uintptr_t)w_p) & 15) == 0,
+             "ag_grufront_fwd_persist: weights must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync((char*)ws + PS_STICKY_BYTES, 0, PS_HDR_BYTES, st) != hipSuccess) {
+    ag_set_error("ag_grufront_fwd_persist: memset failed");
+    return AG_ERR_LAUNCH;
+  }
+  FrontFwdP p;
+  p.gates = gates; p.gh = gh; p.bhn = b_hn; p.wx = w_x; p.whh = w_hh; p.wp = w_p; p.bp = b_p; p.hs = hs; p.cs = nullptr; p.x = x;
+  p.ctl = ps_ctl(ws);
+  p.nrt = ag_cdiv(B, 32);
+  p.hx = (float*)((char*)ws + PS_STICKY_BYTES + PS_HDR_BYTES);
+  p.xx = p.hx + (int64_t)2 * p.nrt * 32 * S;
+  p.T = T; p.B = B; p.ldwx = ldwx; p.rb = ag_precision() == AG_PREC_BF16;
+  const int grid = p.nrt * (S / 8);
+  if (S == 1024) hipLaunchKernelGGL((gfront_persist_fwd_kernel<1024, 256, 0, 1>), dim3(grid), dim3(512), 0, st, p);
+  else hipLaunchKernelGGL((gfront_persist_fwd_kernel<128, 64, 0, 1>), dim3(grid), dim3(512), 0, st, p);
+  AG_CHECK_LAUNCH("ag_grufront_fwd_persist");
   return AG_OK;
 }

@@ -830,6 +830,31 @@ def gfront_fwd_persist(gates, wx, whh, wp, bp, hs, cs, x):
           'ag_gfront_fwd_persist')
 
 
+def grufront_fwd_persist(gates, gh, wx, whh, bhn, wp, bp, hs, x):
+    """the GRU-front generator's frame loop in ONE persistent launch (ag_grufront_fwd_persist); hs: [T,B,S] (h_t)"""
+    T, B, S3 = gates.shape
+    S = S3 // 3
+    fs = wp.size(0)
+    for t_, n, shp in ((gates, 'gates', (T, B, 3 * S)), (gh, 'gh', (T, B, 3 * S)), (whh, 'whh', (3 * S, S)), (bhn, 'bhn', (S,)),
+                       (wp, 'wp', (fs, S)), (bp, 'bp', (fs,)), (hs, 'hs', (T, B, S)), (x, 'x', (B, T * fs))):
+        _chk(t_, n)
+        assert t_.is_contiguous() and tuple(t_.shape) == shp, (n, tuple(t_.shape), shp)
+    _chk(wx, 'wx')
+    assert tuple(wx.shape) == (3 * S, fs) and wx.stride(1) == 1
+    nb = int(lib.ag_gfront_persist_ws_bytes(B, S, fs))
+    ws = _persist_workspace(x.device, nb)
+    check(lib.ag_grufront_fwd_persist(_p(gates), _p(gh), _p(wx), wx.stride(0), _p(whh), _p(bhn), _p(wp), _p(bp), _p(hs),
+                                      _p(x), _p(ws), ws.numel(), T, B, S, fs, _n_cu(x.device), _stream()),
+          'ag_grufront_fwd_persist')
+
+
+def _work_grufront(gates, gh, wx, whh, bhn, wp, *a_, **kw):
+    T, B, S3 = gates.shape
+    S, fs = S3 // 3, wp.size(0)
+    return 'gfront_persist_fwd_kernel<gru>', T * 2.0 * B * (S3 * (S + fs) + fs * S), \
+        4.0 * (S3 * (S + fs) + fs * S + T * B * (2 * S3 + 2 * S + fs)), 1
+
+
 def _work_gfront(gates, wx, whh, wp, *a_, **kw):
     T, B, S4 = gates.shape
     S, fs = S4 // 4, wp.size(0)
@@ -959,7 +984,8 @@ def _work_seq_bwd_cell(gates, whh, *a_, **kw):
 
 for _n, _w in (('skinny_gemm', _work_skinny), ('lstm_step_fwd', _work_step),
                ('_lstm_seq_fwd_range', _work_seq_fwd), ('_lstm_seq_fwd_persist_call', _work_seq_fwd_persist),
-               ('_lstm_seq_bwd_persist_call', _work_seq_bwd_persist), ('gfront_fwd_persist', _work_gfront), ('_lstm_seq_bwd_prod', _work_seq_bwd_prod),
+               ('_lstm_seq_bwd_persist_call', _work_seq_bwd_persist), ('gfront_fwd_persist', _work_gfront),
+               ('grufront_fwd_persist', _work_grufront), ('_lstm_seq_bwd_prod', _work_seq_bwd_prod),
                ('_lstm_seq_bwd_cell', _work_seq_bwd_cell), ('_lstm_seq_bwd_step', _work_seq_bwd_step)):
     _instrument(_n, _w)
 

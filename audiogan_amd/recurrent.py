@@ -407,8 +407,17 @@ class GRUFrontFn(torch.autograd.Function):
         gh = torch.empty(T, B, 3 * S, device=dev)      # h-part incl. b_hh (n slot needed for backward)
         hs = torch.empty(T + 1, B, S, device=dev)      # hs[t+1] = h_t, hs[0] = 0
         hs[0].zero_()
-        K.gemm(zc.contiguous().view(T * B, Fz), wz, gi.view(T * B, 3 * S), tb=True, bias=b_ih)
-        for t in range(T):
+        persist = K.gfront_persist_ok(B, S, fs, dev)
+        if persist:
+            # the whole frame loop (GRU step + projection, fed back) in ONE launch, weights resident in registers: the r / z
+            # halves of b_hh ride with the precomputed input part, b_hn stays apart (it sits inside r * (...))
+            bias = b_ih.clone()
+            bias[:2 * S] += b_hh[:2 * S]
+            K.gemm(zc.contiguous().view(T * B, Fz), wz, gi.view(T * B, 3 * S), tb=True, bias=bias)
+            K.grufront_fwd_persist(gi, gh, wx, w_hh, b_hh[2 * S:].contiguous(), pw, pb, hs[1:], x)
+        else:
+            K.gemm(zc.contiguous().view(T * B, Fz), wz, gi.view(T * B, 3 * S), tb=True, bias=b_ih)
+        for t in range(0 if persist else T):
             if t > 0:
                 _small_acc(x[:, (t - 1) * fs:t * fs], wx, gi[t], tb=True)
             _small(hs[t], w_hh, gh[t], tb=True, bias=b_hh)

@@ -420,3 +420,124 @@ class GraphedStep(object):
                 bg.all_reduce(part='late')
             ph[5].replay()                                  # opt_g
         return self.losses['d'], self.losses['g']
+
+
+# --------------------------------------------------------------------------------------
+# Training feed: dataset.dataloader minibatches -> the static device tensors a GraphedStep replays on
+# (audiogan.py:94-97 ``tovar``, :714-716, :823-828: the reference converts and uploads every minibatch synchronously
+# inside the iteration).  Here the upload of minibatch i+1 runs on a copy stream WHILE step i is replaying:
+#   host arrays -> pinned staging (slot i & 1) --H2D, copy stream--> device staging (slot i & 1)
+#   step boundary, main stream: wait for that H2D, static tensors <- device staging (a few MB of D2D), replay
+# The replayed graph reads only the static tensors; they are rewritten only between replays, on the stream the
+# replays run on, so no replay ever sees a half-written batch.
+# --------------------------------------------------------------------------------------
+def batch_from_loader(item, device_noise=True):
+    """the reference loader's ``next()`` list (dataset.py:91: [epoch, batch, samples f64, lengths, keys, cseq i32, clen])
+    as the host half of a feed: float32 clips (``tovar``, audiogan.py:95) and int64 lengths / character sequences"""
+    import numpy as np
+    _, _, samples, lengths, _, cseq, clen = item
+    return dict(real=np.ascontiguousarray(samples, dtype=np.float32), real_len=np.asarray(lengths, dtype=np.int64),
+                cs=np.asarray(cseq, dtype=np.int64), cl=np.asarray(clen, dtype=np.int64))
+
+
+class Feeder(object):
+    def __init__(self, static, keys=None, device_fill=None):
+        """``static``: dict of the step's static device tensors (``GraphedStep.b``).  ``keys``: the entries that come
+        from the host (default: all of ``static``); the others stay as they are unless ``device_fill`` (dict key ->
+        callable(tensor), e.g. ``lambda t: t.normal_().mul_(0.01)`` for instance noise / z) refreshes them on the device
+        at every step boundary."""
+        self.static = static
+        self.keys = list(keys) if keys is not None else list(static.keys())
+        self.device_fill = dict(device_fill or {})
+        for k in self.keys + list(self.device_fill):
+            if k not in static:
+                raise KeyError('Feeder: %r is not one of the step\'s static tensors %r' % (k, sorted(static)))
+        any_t = static[self.keys[0]]
+        self.cuda = any_t.is_cuda
+        self.n_staged = self.n_fed = 0
+        self._ready = [None, None]
+        if self.cuda:
+            self.copy_stream = torch.cuda.Stream(device=any_t.device)
+            self.pinned = [{k: torch.empty(static[k].shape, dtype=static[k].dtype).pin_memory() for k in self.keys}
+                           for _ in range(2)]
+            self.dev = [{k: torch.empty_like(static[k]) for k in self.keys} for _ in range(2)]
+            self._free = [None, None]            # event: the device staging slot has been consumed (D2D done)
+        else:
+            self.dev = [{k: torch.empty_like(static[k]) for k in self.keys} for _ in range(2)]
+
+    def _check(self, host):
+        for k in self.keys:
+            if k not in host:
+                raise KeyError('Feeder.stage: the host batch lacks %r' % k)
+            t = host[k] if torch.is_tensor(host[k]) else torch.from_numpy(host[k])
+            if tuple(t.shape) != tuple(self.static[k].shape):
+                raise ValueError('Feeder.stage: %r has shape %r, the captured step expects %r (a hipGraph replays fixed '
+                                 'shapes: pad / crop the minibatch, e.g. dataloader(..., maxlen=, frame_size=))'
+                                 % (k, tuple(t.shape), tuple(self.static[k].shape)))
+            if t.dtype != self.static[k].dtype:
+                raise TypeError('Feeder.stage: %r is %s, expected %s' % (k, t.dtype, self.static[k].dtype))
+            yield k, t
+
+    def stage(self, host):
+        """start moving the NEXT minibatch (dict key -> numpy array / CPU tensor) towards the device; returns at once.
+        At most one batch can be staged ahead of the one being fed."""
+        if self.n_staged - self.n_fed >= 2:
+            raise RuntimeError('Feeder.stage: two minibatches are already staged; call feed() first')
+        slot = self.n_staged & 1
+        items = list(self._check(host))
+        if not self.cuda:
+            for k, t in items:
+                self.dev[slot][k].copy_(t)
+        else:
+            if self._free[slot] is not None:
+                self._free[slot].synchronize()       # the pinned + device slot were consumed two batches ago
+            for k, t in items:
+                self.pinned[slot][k].copy_(t)
+            with torch.cuda.stream(self.copy_stream):
+                if self._free[slot] is not None:
+                    self.copy_stream.wait_event(self._free[slot])
+                for k, _ in items:
+                    self.dev[slot][k].copy_(self.pinned[slot][k], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(self.copy_stream)
+                self._ready[slot] = ev
+        self.n_staged += 1
+
+    def feed(self):
+        """step boundary: make the oldest staged minibatch the step's input (enqueued on the current stream, behind the
+        previous replay): static tensors <- device staging, device-side refreshes; then call ``GraphedStep.step()``"""
+        if self.n_fed >= self.n_staged:
+            raise RuntimeError('Feeder.feed: nothing staged')
+        slot = self.n_fed & 1
+        if self.cuda:
+            torch.cuda.current_stream().wait_event(self._ready[slot])
+        for k in self.keys:
+            self.static[k].copy_(self.dev[slot][k], non_blocking=True)
+        if self.cuda:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            self._free[slot] = ev
+        for k, fn in self.device_fill.items():
+            fn(self.static[k])
+        self.n_fed += 1
+
+    def run(self, graphed, host_batches, on_step=None):
+        """feed ``host_batches`` (an iterable of host dicts, e.g. ``map(batch_from_loader, gen_train)``) through
+        ``graphed`` with the upload of batch i+1 overlapping step i; returns the number of steps"""
+        it = iter(host_batches)
+        try:
+            self.stage(next(it))
+        except StopIteration:
+            return 0
+        n = 0
+        while self.n_fed < self.n_staged:
+            self.feed()
+            out = graphed.step()
+            try:
+                self.stage(next(it))          # overlaps the replay just enqueued
+            except StopIteration:
+                pass
+            n += 1
+            if on_step is not None:
+                on_step(n, out)
+        return n

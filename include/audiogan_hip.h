@@ -319,6 +319,15 @@ int ag_gfront_fwd_persist(float* gates, const float* w_x, int ldwx, const float*
                           const float* b_p, float* hs, float* cs, float* x, void* ws, int64_t ws_bytes, int T, int B,
                           int S, int fs, int n_cu, void* stream);
 
+/* The same frame loop with a GRU cell (BASELINE configs[3]: the audiogan.py Generator with the LSTMCell of :380-386 replaced
+ * by a GRU cell, gate order r z n as torch.nn.GRUCell) as ONE persistent launch.  gates [T,B,3S]: in = W_ih[:, fs:] zc_t +
+ * b_ih + (b_hr, b_hz, 0), out = activated (r, z, n); gh [T,B,3S]: only its n slot is written (W_hn h_{t-1} + b_hn, what
+ * ag_gru_cell_bwd reads); w_x = W_ih[:, :fs] (row pitch ldwx), w_hh [3S,S], b_hn [S] = b_hh[2S:], w_p [fs,S], b_p [fs];
+ * outputs hs [T,B,S] and the frames x [B,T*fs].  Shapes and workspace as for ag_gfront_fwd_persist. */
+int ag_grufront_fwd_persist(float* gates, float* gh, const float* w_x, int ldwx, const float* w_hh, const float* b_hn,
+                            const float* w_p, const float* b_p, float* hs, float* x, void* ws, int64_t ws_bytes, int T,
+                            int B, int S, int fs, int n_cu, void* stream);
+
 /* One fused backward step of the Generator front (audiogan.py:428-460: LSTMCell -> tanh(Linear) fed back), frame t:
  *   gx     = dxa * (1 - x_t^2)                        d(pre-tanh) of the projection, stored to gx_out [B,Kp]
  *   dh     = dh_acc + gx * w_proj                      w_proj [Kp = frame size, H]; dh_acc [B,H] rows, pitch lddh

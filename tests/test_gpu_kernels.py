@@ -620,3 +620,42 @@ def test_persistent_workspace_is_never_freed(K):
     assert b.numel() >= a.numel() + 4096 and a.data_ptr() != b.data_ptr()
     assert any(t is a for t in K._persist_ws[dev]) and K._persist_ws[dev][0] is b
     assert K._persist_workspace(dev, 1024) is b
+
+
+@pytest.mark.parametrize('S,fs,B,T', [(128, 64, 5, 3), (128, 64, 40, 6), (1024, 256, 64, 4), (1024, 256, 33, 3)])
+def test_grufront_persistent_launch(K, S, fs, B, T):
+    """the GRU-front generator's frame loop (BASELINE configs[3]) as ONE persistent launch vs one launch per operation:
+    frames, stop logits and every gradient (the backward runs on the saved gates / hidden states of either forward)"""
+    from audiogan_amd import ops
+    assert K.lib.ag_gfront_persist_ok(B, S, fs, 256)
+    gen = torch.Generator().manual_seed(29)
+    Fz = 24
+    front = ops.GRUFront(fs, S)
+    shapes = [(3 * S, fs + Fz), (3 * S, S), (3 * S,), (3 * S,), (fs, S), (fs,), (1, S), (1,)]
+    params = []
+    for shp in shapes:
+        v = torch.nn.Parameter((torch.randn(shp, generator=gen) / (shp[-1] ** 0.5 if len(shp) > 1 else 4.0)).cuda())
+        gq = torch.nn.Parameter((v.detach().reshape(shp[0], -1).norm(dim=1) if len(shp) > 1 else v.detach().abs())
+                                .view([shp[0]] + [1] * (len(shp) - 1)).clone())
+        front.group.add(v, gq)
+        params += [v, gq]
+    zc = torch.randn(T, B, Fz, generator=gen).cuda()
+    gx, gs = torch.randn(B, T * fs, generator=gen).cuda(), torch.randn(B, T, generator=gen).cuda()
+    outs = []
+    old = K.PERSIST[0]
+    try:
+        for persist in (False, True):
+            K.PERSIST[0] = persist
+            for q in params:
+                q.grad = None
+            x, s = ops.GRUFrontFn.apply(zc, front, *front.group.params())
+            ((x * gx).sum() + (s * gs).sum()).backward()
+            torch.cuda.synchronize()
+            assert K.lstm_persist_status() == 0
+            outs.append((x.detach().clone(), s.detach().clone(), [q.grad.clone() for q in params]))
+    finally:
+        K.PERSIST[0] = old
+    close(outs[1][0], outs[0][0], rtol=1e-4, atol=1e-6)
+    close(outs[1][1], outs[0][1], rtol=1e-4, atol=1e-5)
+    for a, b in zip(outs[1][2], outs[0][2]):
+        close(a, b, rtol=1e-3, atol=1e-5 * max(1.0, float(b.abs().max())))
