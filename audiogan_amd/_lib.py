@@ -93,6 +93,14 @@ SIGNATURES = {
     'ag_gfront_persist_ws_bytes': (i64, [C.c_int] * 3),
     'ag_gfront_fwd_persist': (C.c_int, [vp, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, i64] + [C.c_int] * 5 + [vp]),
     'ag_grufront_fwd_persist': (C.c_int, [vp, vp, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, i64] + [C.c_int] * 5 + [vp]),
+    'ag_convlstm_peephole_fwd': (C.c_int, [vp] * 8 + [C.c_int] * 4 + [vp]),
+    'ag_convlstm_peephole_bwd': (C.c_int, [vp] * 11 + [C.c_int] * 4 + [vp]),
+    'ag_convlstm_cell_fwd': (C.c_int, [vp] * 6 + [f32, vp, vp] + [C.c_int] * 4 + [vp]),
+    'ag_convlstm_cell_bwd': (C.c_int, [vp] * 6 + [f32] + [vp] * 7 + [C.c_int] * 4 + [vp]),
+    'ag_convlstm_out_fwd': (C.c_int, [vp, vp, vp, i64, vp]),
+    'ag_convlstm_out_bwd': (C.c_int, [vp, vp, vp, vp, vp, i64, vp]),
+    'ag_layer_norm_hbfw_fwd': (C.c_int, [vp, vp, vp, f32, vp, vp, vp] + [C.c_int] * 4 + [vp]),
+    'ag_layer_norm_hbfw_bwd': (C.c_int, [vp] * 8 + [C.c_int] * 4 + [vp]),
     'ag_bce_logits_fwd': (C.c_int, [vp, C.c_int, f32, vp, vp, vp, f32, C.c_int, C.c_int, vp]),
     'ag_bce_logits_bwd': (C.c_int, [vp, C.c_int, f32, vp, vp, f32, vp, C.c_int, C.c_int, C.c_int, vp]),
     'ag_act_fwd': (C.c_int, [vp, vp, i64, C.c_int, f32, vp]),

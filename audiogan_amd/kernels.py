@@ -1097,3 +1097,100 @@ def time_moments_bwd(h, lens, gm, gs, gf, dh):
         assert t_ is None or (t_.is_contiguous() and tuple(t_.shape) == (B, Cc))
     check(lib.ag_time_moments_bwd(_p(h), a[0], a[1], _p(lens), _p(gm), _p(gs), _p(gf), _p(dh), d[0], d[1], B, Cc, L,
                                   _stream()), 'ag_time_moments_bwd')
+
+
+# ------------------------------------------------------------------------------------
+# Conv2DLSTMCell pieces (csrc/convlstm.hip); every map [H, B, C, W] contiguous, peephole weights [H, F, W]
+# ------------------------------------------------------------------------------------
+def _hbcw(t, name, shape=None):
+    _chk(t, name)
+    assert t.is_contiguous() and t.dim() == 4, name + ' must be a contiguous [H,B,C,W] map'
+    if shape is not None:
+        assert tuple(t.shape) == tuple(shape), (name, tuple(t.shape), tuple(shape))
+    return t
+
+
+def _peep(t, name, H, F, W):
+    if t is None:
+        return None
+    _chk(t, name)
+    assert t.is_contiguous() and tuple(t.shape) == (H, F, W), (name, tuple(t.shape))
+    return t
+
+
+def convlstm_peephole_fwd(y, c, wci, wcf, j, ip, fp, o):
+    H, B, F, W = c.shape
+    _hbcw(y, 'y', (H, B, 4 * F, W))
+    for t_, n in ((c, 'c'), (j, 'j'), (ip, 'i_pre'), (fp, 'f_pre'), (o, 'o_raw')):
+        _hbcw(t_, n, (H, B, F, W))
+    check(lib.ag_convlstm_peephole_fwd(_p(y), _p(c), _p(_peep(wci, 'w_ci', H, F, W)), _p(_peep(wcf, 'w_cf', H, F, W)), _p(j),
+                                       _p(ip), _p(fp), _p(o), H, B, F, W, _stream()), 'ag_convlstm_peephole_fwd')
+
+
+def convlstm_peephole_bwd(dj, di, df, do, c, wci, wcf, dy, dc, dwci, dwcf):
+    """dy [H,B,4F,W] written; dc accumulated into; dwci / dwcf written when given"""
+    H, B, F, W = c.shape
+    _hbcw(dy, 'dy', (H, B, 4 * F, W))
+    for t_, n in ((dj, 'dj'), (di, 'di'), (df, 'df'), (do, 'do'), (c, 'c'), (dc, 'dc')):
+        _hbcw(t_, n, (H, B, F, W))
+    check(lib.ag_convlstm_peephole_bwd(_p(dj), _p(di), _p(df), _p(do), _p(c), _p(_peep(wci, 'w_ci', H, F, W)),
+                                       _p(_peep(wcf, 'w_cf', H, F, W)), _p(dy), _p(dc), _p(_peep(dwci, 'dw_ci', H, F, W)),
+                                       _p(_peep(dwcf, 'dw_cf', H, F, W)), H, B, F, W, _stream()), 'ag_convlstm_peephole_bwd')
+
+
+def convlstm_cell_fwd(j, i_, f_, c, o_raw, wco, forget_bias, c_new, o_pre):
+    H, B, F, W = c.shape
+    for t_, n in ((j, 'j'), (i_, 'i'), (f_, 'f'), (c, 'c'), (o_raw, 'o_raw'), (c_new, 'c_new'), (o_pre, 'o_pre')):
+        _hbcw(t_, n, (H, B, F, W))
+    check(lib.ag_convlstm_cell_fwd(_p(j), _p(i_), _p(f_), _p(c), _p(o_raw), _p(_peep(wco, 'w_co', H, F, W)), float(forget_bias),
+                                   _p(c_new), _p(o_pre), H, B, F, W, _stream()), 'ag_convlstm_cell_fwd')
+
+
+def convlstm_cell_bwd(j, i_, f_, c, c_new, wco, forget_bias, dc_new, do_pre, dj, di, df, dc, dwco):
+    """dc_new: in = dL/dc', out = dL/dc' + do_pre * W_co; dj, di, df, dc written; dwco written when given"""
+    H, B, F, W = c.shape
+    for t_, n in ((j, 'j'), (i_, 'i'), (f_, 'f'), (c, 'c'), (c_new, 'c_new'), (dc_new, 'dc_new'), (do_pre, 'do_pre'),
+                  (dj, 'dj'), (di, 'di'), (df, 'df'), (dc, 'dc')):
+        _hbcw(t_, n, (H, B, F, W))
+    check(lib.ag_convlstm_cell_bwd(_p(j), _p(i_), _p(f_), _p(c), _p(c_new), _p(_peep(wco, 'w_co', H, F, W)), float(forget_bias),
+                                   _p(dc_new), _p(do_pre), _p(dj), _p(di), _p(df), _p(dc), _p(_peep(dwco, 'dw_co', H, F, W)),
+                                   H, B, F, W, _stream()), 'ag_convlstm_cell_bwd')
+
+
+def convlstm_out_fwd(o, c, h):
+    for t_, n in ((o, 'o'), (c, 'c'), (h, 'h')):
+        _chk(t_, n)
+        assert t_.is_contiguous() and t_.numel() == o.numel()
+    check(lib.ag_convlstm_out_fwd(_p(o), _p(c), _p(h), o.numel(), _stream()), 'ag_convlstm_out_fwd')
+
+
+def convlstm_out_bwd(o, c, dh, do, dc):
+    for t_, n in ((o, 'o'), (c, 'c'), (dh, 'dh'), (do, 'do'), (dc, 'dc')):
+        _chk(t_, n)
+        assert t_.is_contiguous() and t_.numel() == o.numel()
+    check(lib.ag_convlstm_out_bwd(_p(o), _p(c), _p(dh), _p(do), _p(dc), o.numel(), _stream()), 'ag_convlstm_out_bwd')
+
+
+def layer_norm_hbfw_fwd(x, gamma, beta, eps, y, mean, rstd):
+    H, B, F, W = x.shape
+    _hbcw(x, 'x'); _hbcw(y, 'y', x.shape)
+    for t_, n, k in ((gamma, 'gamma', F), (beta, 'beta', F), (mean, 'mean', B), (rstd, 'rstd', B)):
+        _chk(t_, n)
+        assert t_.is_contiguous() and t_.numel() == k, n
+    check(lib.ag_layer_norm_hbfw_fwd(_p(x), _p(gamma), _p(beta), float(eps), _p(y), _p(mean), _p(rstd), H, B, F, W, _stream()),
+          'ag_layer_norm_hbfw_fwd')
+
+
+def layer_norm_hbfw_bwd(dy, x, gamma, mean, rstd, dx, dgp, dbp):
+    H, B, F, W = x.shape
+    _hbcw(x, 'x'); _hbcw(dy, 'dy', x.shape); _hbcw(dx, 'dx', x.shape)
+    for t_, n, k in ((gamma, 'gamma', F), (mean, 'mean', B), (rstd, 'rstd', B), (dgp, 'dgamma_part', B * F), (dbp, 'dbeta_part', B * F)):
+        _chk(t_, n)
+        assert t_.is_contiguous() and t_.numel() == k, n
+    check(lib.ag_layer_norm_hbfw_bwd(_p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(dgp), _p(dbp), H, B, F, W, _stream()),
+          'ag_layer_norm_hbfw_bwd')
+
+
+for _n in ('convlstm_peephole_fwd', 'convlstm_peephole_bwd', 'convlstm_cell_fwd', 'convlstm_cell_bwd', 'convlstm_out_fwd',
+           'convlstm_out_bwd', 'layer_norm_hbfw_fwd', 'layer_norm_hbfw_bwd'):
+    _instrument(_n, None)

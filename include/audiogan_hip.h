@@ -408,6 +408,35 @@ int ag_opt_step(const ag_opt_desc* descs_dev, int n, const float* norms, int kin
                 float clip, float grad_scale, float alpha_or_beta1, float beta2, float eps, int step,
                 const int32_t* step_dev, void* stream);
 
+/* ---- Conv2DLSTMCell (reference cells.py:4-103: convolutional LSTM with peepholes and TF layer normalisation) ----------
+ * Pointwise / normalisation pieces (csrc/convlstm.hip); the convolution runs on ag_conv1d_engine, one launch per kernel row.
+ * Every map is [H, B, C, W] contiguous (rows x batch = the 1-D engine's batch axis, W = its time axis); peephole weights
+ * [H, F, W]; gate blocks of the convolution output y [H,B,4F,W] along C in TF.split order j | i | f | o (cells.py:66).
+ *   peephole_fwd  j, i_pre = i + W_ci c, f_pre = f + W_cf c, o_raw  (cells.py:66-70; w_ci / w_cf may be NULL: no peepholes)
+ *   cell_fwd      c' = c sigmoid(f + forget_bias) + sigmoid(i) tanh(j);  o_pre = o_raw + W_co c'   (:77-82)
+ *   out_fwd       h = sigmoid(o) tanh(c)                                                               (:88-89)
+ *   layer_norm    tf.contrib.layers.layer_norm: per sample over (H, W, F), gamma / beta per feature, eps inside the sqrt
+ * The backward forms take the forward's inputs again (nothing is saved besides mean / rstd); dc of peephole_bwd is
+ * ACCUMULATED into (it also receives the cell path's dc); weight gradients are written (summed over the batch in a fixed
+ * order); layer_norm_bwd writes per-sample partials [B,F] of dgamma / dbeta for a fixed-order column sum by the caller. */
+int ag_convlstm_peephole_fwd(const float* y, const float* c, const float* w_ci, const float* w_cf, float* j, float* i_pre,
+                             float* f_pre, float* o_raw, int H, int B, int F, int W, void* stream);
+int ag_convlstm_peephole_bwd(const float* dj, const float* di, const float* df, const float* d_o, const float* c,
+                             const float* w_ci, const float* w_cf, float* dy, float* dc, float* dw_ci, float* dw_cf, int H,
+                             int B, int F, int W, void* stream);
+int ag_convlstm_cell_fwd(const float* j, const float* i_, const float* f_, const float* c, const float* o_raw,
+                         const float* w_co, float forget_bias, float* c_new, float* o_pre, int H, int B, int F, int W,
+                         void* stream);
+int ag_convlstm_cell_bwd(const float* j, const float* i_, const float* f_, const float* c, const float* c_new,
+                         const float* w_co, float forget_bias, float* dc_new, const float* do_pre, float* dj, float* di,
+                         float* df, float* dc, float* dw_co, int H, int B, int F, int W, void* stream);
+int ag_convlstm_out_fwd(const float* o, const float* c, float* h, int64_t n, void* stream);
+int ag_convlstm_out_bwd(const float* o, const float* c, const float* dh, float* d_o, float* dc, int64_t n, void* stream);
+int ag_layer_norm_hbfw_fwd(const float* x, const float* gamma, const float* beta, float eps, float* y, float* mean, float* rstd,
+                           int H, int B, int F, int W, void* stream);
+int ag_layer_norm_hbfw_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd, float* dx,
+                           float* dgamma_part, float* dbeta_part, int H, int B, int F, int W, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

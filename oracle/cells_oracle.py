@@ -39,3 +39,46 @@ def feedback_multi_lstm_cell(inputs, state, params, forget_bias=1.0):
         new_state.append(s)
     new_state.append(x)
     return x, new_state
+
+
+def _tf_layer_norm(x, gamma, beta):
+    """tf.contrib.layers.layer_norm defaults: moments over every axis but the batch (begin_norm_axis = 1), gamma / beta over
+    the last axis (begin_params_axis = -1), tf.nn.batch_normalization with variance_epsilon = 1e-12"""
+    dims = tuple(range(1, x.dim()))
+    m = x.mean(dim=dims, keepdim=True)
+    v = ((x - m) ** 2).mean(dim=dims, keepdim=True)
+    return (x - m) * torch.rsqrt(v + 1e-12) * gamma + beta
+
+
+def conv2d_lstm_cell(x, state, kernel, bias=None, peep=None, ln=None, forget_bias=1.0, pre=None, post=None):
+    """cells.py:50-103, channels_last.  x [B,H,W,Cin]; state (c [B,H,W,F], h); kernel [kh,kw,Cin+Ch,4F] (TF HWIO, gate blocks
+    j | i | f | o); bias [4F] or None (only without layer norm, :64-65); peep = (W_ci, W_cf, W_co) each [H,W,F] or None; ln =
+    list of five (gamma, beta) in call order j, i, f, o, c or None.  TF 'SAME' (odd kernels: symmetric zero padding).
+    PARITY UNPINNED (TensorFlow is absent; the reference holds no fixture): the published TF op definitions restated."""
+    import torch.nn.functional as F_
+    c, h = state
+    if pre is not None:
+        x, h = pre(x, h)
+    xh = torch.cat([x, h], -1)
+    kh, kw = kernel.shape[:2]
+    y = F_.conv2d(xh.permute(0, 3, 1, 2), kernel.permute(3, 2, 0, 1), padding=((kh - 1) // 2, (kw - 1) // 2)).permute(0, 2, 3, 1)
+    if ln is None and bias is not None:
+        y = y + bias
+    j, i, f, o = y.chunk(4, -1)
+    if peep is not None:
+        i = i + peep[0] * c
+        f = f + peep[1] * c
+    if ln is not None:
+        j, i, f = _tf_layer_norm(j, *ln[0]), _tf_layer_norm(i, *ln[1]), _tf_layer_norm(f, *ln[2])
+    f = torch.sigmoid(f + forget_bias)
+    i = torch.sigmoid(i)
+    c = c * f + i * torch.tanh(j)
+    if peep is not None:
+        o = o + peep[2] * c
+    if ln is not None:
+        o, c = _tf_layer_norm(o, *ln[3]), _tf_layer_norm(c, *ln[4])
+    o = torch.sigmoid(o)
+    h = o * torch.tanh(c)
+    if post is not None:
+        h = post(h)
+    return h, (c, h)

@@ -485,3 +485,67 @@ def time_moments_bwd(h, lens, gm, gs, gf, dh):
 
 ALL = [n for n, v in list(globals().items()) if callable(v) and not n.startswith('_')
        and n not in ('F', 'install')]
+
+
+# ---- Conv2DLSTMCell pieces (csrc/convlstm.hip): maps [H,B,C,W], peephole weights [H,F,W] --------------------------------
+def _pw(w):
+    return w.unsqueeze(1) if w is not None else 0.0          # [H,1,F,W] broadcasts over the batch axis
+
+
+def convlstm_peephole_fwd(y, c, wci, wcf, j, ip, fp, o):
+    F_ = c.size(2)
+    yj, yi, yf, yo = (y[:, :, k * F_:(k + 1) * F_] for k in range(4))
+    j.copy_(yj); ip.copy_(yi + _pw(wci) * c); fp.copy_(yf + _pw(wcf) * c); o.copy_(yo)
+
+
+def convlstm_peephole_bwd(dj, di, df, do, c, wci, wcf, dy, dc, dwci, dwcf):
+    dy.copy_(torch.cat([dj, di, df, do], 2))
+    dc.add_(di * _pw(wci) + df * _pw(wcf))
+    if dwci is not None:
+        dwci.copy_((di * c).sum(1))
+    if dwcf is not None:
+        dwcf.copy_((df * c).sum(1))
+
+
+def convlstm_cell_fwd(j, i_, f_, c, o_raw, wco, forget_bias, c_new, o_pre):
+    v = c * torch.sigmoid(f_ + forget_bias) + torch.sigmoid(i_) * torch.tanh(j)
+    c_new.copy_(v)
+    o_pre.copy_(o_raw + _pw(wco) * v)
+
+
+def convlstm_cell_bwd(j, i_, f_, c, c_new, wco, forget_bias, dc_new, do_pre, dj, di, df, dc, dwco):
+    if dwco is not None:
+        dwco.copy_((do_pre * c_new).sum(1))
+    g = dc_new + do_pre * _pw(wco)
+    sf, si, tj = torch.sigmoid(f_ + forget_bias), torch.sigmoid(i_), torch.tanh(j)
+    dc_new.copy_(g)
+    dc.copy_(g * sf); df.copy_(g * c * sf * (1 - sf)); di.copy_(g * tj * si * (1 - si)); dj.copy_(g * si * (1 - tj * tj))
+
+
+def convlstm_out_fwd(o, c, h):
+    h.copy_(torch.sigmoid(o) * torch.tanh(c))
+
+
+def convlstm_out_bwd(o, c, dh, do, dc):
+    so, tc = torch.sigmoid(o), torch.tanh(c)
+    do.copy_(dh * tc * so * (1 - so)); dc.copy_(dh * so * (1 - tc * tc))
+
+
+def layer_norm_hbfw_fwd(x, gamma, beta, eps, y, mean, rstd):
+    m = x.mean(dim=(0, 2, 3))
+    v = ((x - m.view(1, -1, 1, 1)) ** 2).mean(dim=(0, 2, 3))
+    r = torch.rsqrt(v + eps)
+    mean.copy_(m); rstd.copy_(r)
+    y.copy_((x - m.view(1, -1, 1, 1)) * r.view(1, -1, 1, 1) * gamma.view(1, 1, -1, 1) + beta.view(1, 1, -1, 1))
+
+
+def layer_norm_hbfw_bwd(dy, x, gamma, mean, rstd, dx, dgp, dbp):
+    xh = (x - mean.view(1, -1, 1, 1)) * rstd.view(1, -1, 1, 1)
+    g = dy * gamma.view(1, 1, -1, 1)
+    m1, m2 = g.mean(dim=(0, 2, 3)).view(1, -1, 1, 1), (g * xh).mean(dim=(0, 2, 3)).view(1, -1, 1, 1)
+    dx.copy_(rstd.view(1, -1, 1, 1) * (g - m1 - xh * m2))
+    dgp.copy_((dy * xh).sum(dim=(0, 3)).view(dgp.shape)); dbp.copy_(dy.sum(dim=(0, 3)).view(dbp.shape))
+
+
+ALL = [n for n, v in list(globals().items()) if callable(v) and not n.startswith('_')
+       and getattr(v, '__module__', None) == __name__ and n not in ('install',)]
