@@ -24,7 +24,8 @@ extern "C" const char* ag_last_error(void) { return g_err; }
 static std::atomic<int> g_prec{AG_PREC_F32};
 
 extern "C" int ag_set_precision(int mode) {
-  AG_REQUIRE(mode == AG_PREC_F32 || mode == AG_PREC_BF16, "ag_set_precision: mode must be 0 (f32) or 1 (bf16)");
+  AG_REQUIRE(mode == AG_PREC_F32 || mode == AG_PREC_BF16 || mode == AG_PREC_F32X3,
+             "ag_set_precision: mode must be 0 (f32), 1 (bf16) or 2 (f32x3)");
   g_prec.store(mode);
   return AG_OK;
 }

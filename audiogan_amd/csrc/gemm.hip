@@ -501,6 +501,14 @@ typedef unsigned u32x2g __attribute__((ext_vector_type(2)));
 // c ^ ((r >> 1) & 7): the 16 rows of a ds_read_b128 lane group then cover 16 distinct (slot, 128-B half) pairs.
 __device__ __forceinline__ int bf_slot(int r, int c) { return r * 128 + ((c ^ ((r >> 1) & 7)) << 4); }
 
+// AG_PREC_F32X3 (an EXPERIMENT, never the headline precision): x = hi + lo with hi = bf16(x), lo = bf16(x - hi); the product
+// a b ~ a_hi b_hi + a_hi b_lo + a_lo b_hi on three bf16 MFMAs with fp32 accumulation drops only a_lo b_lo (2^-16 of the
+// product).  The lo image sits LO_OFF bytes behind the hi image in LDS.
+__device__ __forceinline__ void bf_split(float x0, float x1, unsigned& hi, unsigned& lo) {
+  hi = ag_pack_bf16(x0, x1);
+  lo = ag_pack_bf16(x0 - __uint_as_float(hi << 16), x1 - __uint_as_float(hi & 0xFFFF0000u));
+}
+
 template <int T_>      // 0: stored [rows][K] (k contiguous)   1: stored [K][rows]
 struct Bf16Loader {
   f32x4 v[8];
@@ -525,6 +533,40 @@ struct Bf16Loader {
         for (int i = 0; i < 4; ++i) {
           const int k = k0 + 4 * kq + i;
           v[4 * it + i] = *reinterpret_cast<const f32x4*>(G + (int64_t)min(k, K - 1) * ld + min(r0 + 4 * r4, nrows - 4));
+        }
+      }
+    }
+  }
+  template <int LO_OFF>
+  __device__ __forceinline__ void store_split(char* S, int tid, int k0, int K) const {
+    if (T_ == 0) {
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int idx = tid + 256 * it;
+        const int r = idx >> 4, q = idx & 15;
+        const unsigned msk = (k0 + 4 * q < K) ? 0xFFFFFFFFu : 0u;
+        unsigned h0, l0, h1, l1;
+        bf_split(v[it][0], v[it][1], h0, l0);
+        bf_split(v[it][2], v[it][3], h1, l1);
+        char* d = S + bf_slot(r, q >> 1) + ((q & 1) << 3);
+        *reinterpret_cast<u32x2g*>(d) = u32x2g{h0 & msk, h1 & msk};
+        *reinterpret_cast<u32x2g*>(d + LO_OFF) = u32x2g{l0 & msk, l1 & msk};
+      }
+    } else {
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int idx = tid + 256 * it;
+        const int kq = idx >> 5, r4 = idx & 31;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const int r = 4 * r4 + rr;
+          const unsigned msk = (k0 + 4 * kq < K) ? 0xFFFFFFFFu : 0u;
+          unsigned h0, l0, h1, l1;
+          bf_split(v[4 * it][rr], v[4 * it + 1][rr], h0, l0);
+          bf_split(v[4 * it + 2][rr], v[4 * it + 3][rr], h1, l1);
+          char* d = S + bf_slot(r, kq >> 1) + ((kq & 1) << 3);
+          *reinterpret_cast<u32x2g*>(d) = u32x2g{h0 & msk, h1 & msk};
+          *reinterpret_cast<u32x2g*>(d + LO_OFF) = u32x2g{l0 & msk, l1 & msk};
         }
       }
     }
@@ -557,10 +599,11 @@ struct Bf16Loader {
   }
 };
 
-template <int TA, int TB>
+template <int TA, int TB, int X3 = 0>      // X3: the split-bf16 form (hi + lo images, 3 MFMAs per product)
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmP p) {
-  constexpr int BM = 128, BN = 128, TILEB = 128 * 128;      // bytes per operand tile
-  extern __shared__ __attribute__((aligned(16))) char sm[];   // 2 buffers x (A tile + B tile) = 64 KiB
+  constexpr int BM = 128, BN = 128, IMG = 128 * 128;        // bytes per operand image
+  constexpr int TILEB = X3 ? 2 * IMG : IMG;                  // bytes per operand tile (X3: hi image, then lo image)
+  extern __shared__ __attribute__((aligned(16))) char sm[];   // 2 buffers x (A tile + B tile) = 64 KiB (X3: 128 KiB)
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l31 = lane & 31, h = lane >> 5;
   const int wm0 = (wid >> 1) * 64, wn0 = (wid & 1) * 64;
@@ -590,8 +633,13 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmP p) {
   const int kend = (kbeg + p.kchunk < p.K) ? kbeg + p.kchunk : p.K;
   la.load(p.A, p.lda, m0, p.M, kbeg, kend, tid);
   lb.load(p.B, p.ldb, n0, p.N, kbeg, kend, tid);
-  la.store(sm, tid, kbeg, kend);
-  lb.store(sm + TILEB, tid, kbeg, kend);
+  if (X3) {
+    la.template store_split<IMG>(sm, tid, kbeg, kend);
+    lb.template store_split<IMG>(sm + TILEB, tid, kbeg, kend);
+  } else {
+    la.store(sm, tid, kbeg, kend);
+    lb.store(sm + TILEB, tid, kbeg, kend);
+  }
   __syncthreads();
   int buf = 0;
   for (int k0 = kbeg; k0 < kend; k0 += BF_BK) {
@@ -609,6 +657,21 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmP p) {
       for (int i = 0; i < 2; ++i) av[i] = *reinterpret_cast<const bf16x8*>(As + bf_slot(wm0 + 32 * i + l31, 2 * s_ + h));
 #pragma unroll
       for (int j = 0; j < 2; ++j) bv[j] = *reinterpret_cast<const bf16x8*>(Bs + bf_slot(wn0 + 32 * j + l31, 2 * s_ + h));
+      if (X3) {
+        bf16x8 al[2], bl[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) al[i] = *reinterpret_cast<const bf16x8*>(As + IMG + bf_slot(wm0 + 32 * i + l31, 2 * s_ + h));
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bl[j] = *reinterpret_cast<const bf16x8*>(Bs + IMG + bf_slot(wn0 + 32 * j + l31, 2 * s_ + h));
+        // small terms first, the large one last
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bv[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bl[j], acc[i][j], 0, 0, 0);
+          }
+      }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -616,8 +679,13 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmP p) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
     }
     if (more) {
-      la.store(sm + (buf ^ 1) * 2 * TILEB, tid, k0 + BF_BK, kend);
-      lb.store(sm + (buf ^ 1) * 2 * TILEB + TILEB, tid, k0 + BF_BK, kend);
+      if (X3) {
+        la.template store_split<IMG>(sm + (buf ^ 1) * 2 * TILEB, tid, k0 + BF_BK, kend);
+        lb.template store_split<IMG>(sm + (buf ^ 1) * 2 * TILEB + TILEB, tid, k0 + BF_BK, kend);
+      } else {
+        la.store(sm + (buf ^ 1) * 2 * TILEB, tid, k0 + BF_BK, kend);
+        lb.store(sm + (buf ^ 1) * 2 * TILEB + TILEB, tid, k0 + BF_BK, kend);
+      }
     }
     __syncthreads();
     buf ^= 1;
@@ -654,19 +722,27 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmP p) {
     }
 }
 
-template <int TA, int TB>
+template <int TA, int TB, int X3>
 static void launch_bf16_one(const GemmP& p, dim3 grid, hipStream_t st) {
-  auto kern = gemm_bf16_kernel<TA, TB>;
-  (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-  hipLaunchKernelGGL(kern, grid, dim3(256), 64 * 1024, st, p);
+  auto kern = gemm_bf16_kernel<TA, TB, X3>;
+  const int lds = (X3 ? 128 : 64) * 1024;
+  (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
 }
 
-static int launch_gemm_bf16(const GemmP& p, int ta, int tb, hipStream_t st) {
+static int launch_gemm_bf16(const GemmP& p, int ta, int tb, hipStream_t st, bool x3 = false) {
   dim3 grid(ag_cdiv(p.N, 128), ag_cdiv(p.M, 128), p.ksplit);
-  if (ta == 0 && tb == 0) launch_bf16_one<0, 0>(p, grid, st);
-  if (ta == 0 && tb == 1) launch_bf16_one<0, 1>(p, grid, st);
-  if (ta == 1 && tb == 0) launch_bf16_one<1, 0>(p, grid, st);
-  if (ta == 1 && tb == 1) launch_bf16_one<1, 1>(p, grid, st);
+  if (x3) {
+    if (ta == 0 && tb == 0) launch_bf16_one<0, 0, 1>(p, grid, st);
+    if (ta == 0 && tb == 1) launch_bf16_one<0, 1, 1>(p, grid, st);
+    if (ta == 1 && tb == 0) launch_bf16_one<1, 0, 1>(p, grid, st);
+    if (ta == 1 && tb == 1) launch_bf16_one<1, 1, 1>(p, grid, st);
+  } else {
+    if (ta == 0 && tb == 0) launch_bf16_one<0, 0, 0>(p, grid, st);
+    if (ta == 0 && tb == 1) launch_bf16_one<0, 1, 0>(p, grid, st);
+    if (ta == 1 && tb == 0) launch_bf16_one<1, 0, 0>(p, grid, st);
+    if (ta == 1 && tb == 1) launch_bf16_one<1, 1, 0>(p, grid, st);
+  }
   AG_CHECK_LAUNCH("ag_gemm(bf16)");
   return AG_OK;
 }
@@ -787,10 +863,12 @@ extern "C" int ag_gemm(const float* A, int lda, int ta, const float* B, int ldb,
   int rc;
   // bf16 mode: the bf16-MFMA kernel takes every shape with more than one row tile's worth of work whose operands
   // can be read 16 bytes at a time; the rest runs the fp32 kernels on operands rounded in registers
-  const bool bf16k = p.rb && M > 32 && N > 32 && p.vecA && p.vecB && K % 4 == 0 && p.kchunk % 64 == 0 &&
+  // AG_PREC_F32X3: the same kernel in its split-bf16 form for the large products only (the others stay exact fp32)
+  const bool x3 = ag_precision() == AG_PREC_F32X3 && use128;
+  const bool bf16k = (p.rb || x3) && M > 32 && N > 32 && p.vecA && p.vecB && K % 4 == 0 && p.kchunk % 64 == 0 &&
                      (ta == 0 || (M % 4 == 0 && M >= 4)) && (tb == 1 || (N % 4 == 0 && N >= 4));
   if (bf16k) {
-    rc = launch_gemm_bf16(p, ta, tb, st);
+    rc = launch_gemm_bf16(p, ta, tb, st, x3);
   } else if (use128) {
     // LDS-DMA variant: whole 16-k tiles only, 16-byte aligned rows, row-contiguous operands with rows % 4 == 0
     // (AG_GEMM_NODMA=1 in the environment forces the register-staged kernel: A/B switch for tools/prof_gemm.py)

@@ -74,13 +74,15 @@ def set_precision(mode):
     """'f32': exact fp32 contractions.  'bf16': every contraction rounds both operands to bfloat16 (RNE) and
     accumulates in fp32 (GEMMs and the persistent recurrent kernels on v_mfma_f32_32x32x16_bf16 / rounded operands);
     memory, epilogues, losses and the optimiser stay fp32.  Returns the previous mode."""
-    old = 'bf16' if lib.ag_get_precision() == 1 else 'f32'
-    check(lib.ag_set_precision({'f32': 0, 'bf16': 1}[mode]), 'ag_set_precision')
+    old = get_precision()
+    check(lib.ag_set_precision({'f32': 0, 'bf16': 1, 'f32x3': 2}[mode]), 'ag_set_precision')
     return old
 
 
 def get_precision():
-    return 'bf16' if lib.ag_get_precision() == 1 else 'f32'
+    """'f32x3' is an experiment (bench.py --dtype f32x3): the large GEMMs on three bf16 MFMAs per product of bf16 hi + lo
+    operand parts (~2^-16 relative per product), everything else exact fp32"""
+    return {0: 'f32', 1: 'bf16', 2: 'f32x3'}[lib.ag_get_precision()]
 
 
 class precision(object):
@@ -511,10 +513,12 @@ def _work_gemm(A, B, Cm, ta=False, tb=False, *a_, **kw):
     # mirrors ag_gemm's dispatch: the LDS-DMA kernel takes the 128x128 case when K % 16 == 0 and rows are 16-B aligned
     dma = use128 and Kd % 16 == 0 and (not ta or M % 4 == 0) and (tb or N % 4 == 0) and \
         A.stride(0) % 4 == 0 and B.stride(0) % 4 == 0 and _al16(A) and _al16(B)
-    bf = (lib.ag_get_precision() == 1 and M > 32 and N > 32 and Kd % 4 == 0 and A.stride(0) % 4 == 0 and
-          B.stride(0) % 4 == 0 and _al16(A) and _al16(B) and (not ta or M % 4 == 0) and (tb or N % 4 == 0))
-    if bf:
-        key = 'gemm_bf16_kernel<%d,%d>' % (int(ta), int(tb))
+    bf_shape_ok = (M > 32 and N > 32 and Kd % 4 == 0 and A.stride(0) % 4 == 0 and
+                   B.stride(0) % 4 == 0 and _al16(A) and _al16(B) and (not ta or M % 4 == 0) and (tb or N % 4 == 0))
+    bf = lib.ag_get_precision() == 1 and bf_shape_ok
+    x3 = lib.ag_get_precision() == 2 and use128 and bf_shape_ok
+    if bf or x3:
+        key = 'gemm_bf16_kernel<%d,%d%s>' % (int(ta), int(tb), ',x3' if x3 else '')
     elif dma:
         key = 'gemm_dma_kernel<%d,%d>' % (int(ta), int(tb))
     else:

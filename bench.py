@@ -210,9 +210,10 @@ def main():
     ap.add_argument('--batch', type=int, default=64, help='clips per GPU')
     ap.add_argument('--opt', default='adam', choices=['adam', 'rmsprop'],
                     help='adam = north_star; rmsprop = audiogan.py:693-694')
-    ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'],
+    ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16', 'f32x3'],
                     help='f32 = BASELINE configs[1] (the headline); bf16 = configs[2]: every contraction rounds its '
-                         'operands to bfloat16 and accumulates in fp32, gradients cross ranks as bfloat16')
+                         'operands to bfloat16 and accumulates in fp32, gradients cross ranks as bfloat16; f32x3 = an EXPERIMENT, never '
+                         'the headline: the large GEMMs on three bf16 MFMAs per product of bf16 hi + lo operand parts')
     ap.add_argument('--workload', default='c2', choices=['c2', 'c4', 'c5'],
                     help='c2 = the headline (BASELINE configs[1]; with --dtype bf16: configs[2]); c4 = GRU-front '
                          'generator + conv critic (configs[3]); c5 = WGAN-GP with the conv critic (configs[4]): extra '
@@ -270,9 +271,9 @@ def main():
         ddp.broadcast_parameters(g)
         ddp.broadcast_parameters(d)
         bd = ddp.GradBucket(list(d.parameters()), early=None if alt else d.early_params(), force_collective=rehearse,
-                            comm_dtype=args.dtype)
+                            comm_dtype='bf16' if args.dtype == 'bf16' else 'f32')
         bg = ddp.GradBucket(list(g.parameters()), early=g.early_params(), force_collective=rehearse,
-                            comm_dtype=args.dtype)
+                            comm_dtype='bf16' if args.dtype == 'bf16' else 'f32')
         opt_d.bucket, opt_g.bucket = bd, bg
         hook_d, hook_g = bd.all_reduce, bg.all_reduce
     batch = synthetic_batch(args.batch, dev, seed=1000 + rank)
@@ -386,9 +387,11 @@ def main():
             'warmup': args.warmup, 'ms_per_step': ms, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': WORKLOAD_TEXT[args.workload] % (
-                                       ('C2' if args.dtype == 'f32' else 'C3 (the C2 models with bf16 contractions)')
+                                       ('C2' if args.dtype == 'f32' else 'C2 with the large GEMMs as split-bf16 (3 MFMAs per '
+                                        'product) - an experiment, not the headline' if args.dtype == 'f32x3' else
+                                        'C3 (the C2 models with bf16 contractions)')
                                        if args.workload == 'c2' else args.workload.upper(), args.batch, args.opt) + (
-                                       '' if args.dtype == 'f32' else '; every contraction rounds both operands to '
+                                       '' if args.dtype != 'bf16' else '; every contraction rounds both operands to '
                                        'bfloat16 and accumulates in fp32, gradient all-reduce in bfloat16'),
                        'global_batch': world * args.batch, 'clip_len': L,
                        'parallelism': 'dp%d' % world,

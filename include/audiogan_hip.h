@@ -220,6 +220,10 @@ int ag_gru_cell_bwd(const float* gates_act, const float* gh, const float* h_prev
  *   the reference itself is fp32 only. */
 #define AG_PREC_F32 0
 #define AG_PREC_BF16 1
+/*   2 = f32x3, an EXPERIMENT (bench.py --dtype f32x3; never the headline precision): the large ag_gemm products (128x128-tile
+ *   class) split both operands into bfloat16 hi + lo parts and sum hi*hi + hi*lo + lo*hi on the bf16 MFMA with fp32
+ *   accumulation (~2^-16 relative per product); every other kernel computes exactly as in mode 0. */
+#define AG_PREC_F32X3 2
 int ag_set_precision(int mode);
 int ag_get_precision(void);
 

@@ -244,3 +244,27 @@ def test_bf16_mfma_persistent_recurrent_kernels(K, bf16, B):
             if (k.split('.')[-1].startswith('bias') and k.endswith('_v')) or rp[k].grad is None:
                 continue
             close_bf16(q.grad, rp[k].grad, k, elem=5e-2, l2=5e-2 if k.endswith('_g') else 2e-2)
+
+
+@pytest.mark.parametrize('shape', [(8192, 1024, 1024), (2048, 2048, 1480), (4096, 1480, 8192)])
+@pytest.mark.parametrize('ta,tb', [(False, True), (False, False), (True, False)])
+def test_gemm_f32x3_experiment(K, shape, ta, tb):
+    """AG_PREC_F32X3 (an experiment, bench.py --dtype f32x3): bf16 hi + lo split of both operands, three bf16 MFMAs per
+    product.  Error bound per product 2^-16 relative (the dropped lo*lo term and the rounding of lo); measured against
+    float64: within 2e-5 of the output scale, ~100x closer than the plain bf16 mode"""
+    M, N, Kd = shape
+    gen = torch.Generator().manual_seed(5)
+    A = torch.randn((Kd, M) if ta else (M, Kd), generator=gen)
+    B = torch.randn((N, Kd) if tb else (Kd, N), generator=gen)
+    ref = (A.t() if ta else A).double() @ (B.t() if tb else B).double()
+    out = torch.empty(M, N).cuda()
+    old = K.set_precision('f32x3')
+    try:
+        K.gemm(A.cuda(), B.cuda(), out, ta=ta, tb=tb)
+    finally:
+        K.set_precision(old)
+    err = float((out.cpu().double() - ref).abs().max()) / float(ref.abs().max())
+    assert err <= 2e-5, (shape, ta, tb, err)
+    out32 = torch.empty(M, N).cuda()
+    K.gemm(A.cuda(), B.cuda(), out32, ta=ta, tb=tb)
+    assert not torch.equal(out, out32), 'the mode did not take the split-bf16 kernel'
