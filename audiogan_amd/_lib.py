@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libaudiogan_hip.so')
 
 AG_OK, AG_ERR_ARG, AG_ERR_LAUNCH, AG_ERR_UNSUPPORTED = 0, -1, -2, -3
-ACT_NONE, ACT_LEAKY, ACT_TANH = 0, 1, 2
+ACT_NONE, ACT_LEAKY, ACT_TANH, ACT_LEAKY_GATE = 0, 1, 2, 3
 OPT_RMSPROP, OPT_ADAM = 0, 1
 FLAG_NAN, FLAG_BIG = 1, 2
 

@@ -80,6 +80,9 @@ __device__ __forceinline__ bool conv_epilogue_fast(const ConvP& p, f32x16 (&acc)
   __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(a.res ? a.res + (int64_t)b * a.res_bs : a.y), 0, a.res ? (int)((int64_t)a.O * a.res_cs * 4) : 0, 0x00020000);
   const bool has_res = a.res != nullptr;
+  // AG_ACT_LEAKY_GATE: `res` is not added - it is the SAVED OUTPUT of a LeakyReLU whose derivative scales this result
+  // (the activation backward of the producing layer folded into this backward-data pass)
+  const bool gate = a.act == AG_ACT_LEAKY_GATE;
   if (a.mode == 0) {
 #pragma unroll
     for (int i = 0; i < TILES_O; ++i) {
@@ -96,7 +99,10 @@ __device__ __forceinline__ bool conv_epilogue_fast(const ConvP& p, f32x16 (&acc)
           const bool ok = valid && t < a.Lout;
           const unsigned yo = ok ? (unsigned)((rowy + t) * 4) : OOB;
           float v = acc[i][j][e] + bo;
-          if (has_res) v += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rr, ok ? (unsigned)((rowr + t) * 4) : OOB, 0, 0));
+          if (has_res) {
+            const float rv = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rr, ok ? (unsigned)((rowr + t) * 4) : OOB, 0, 0));
+            v = gate ? (rv > 0.f ? v : v * a.slope) : v + rv;
+          }
           v = ag_apply_act(v, a.act, a.slope);
           if (t >= lenb) v = 0.f;
           if (a.accumulate) v += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(yr, yo, 0, 0));
@@ -144,8 +150,10 @@ __device__ __forceinline__ bool conv_epilogue_fast(const ConvP& p, f32x16 (&acc)
             float v0 = acc[i][j][4 * g + 2 * c2 + 1] + bo, v1 = acc[i][j][4 * g + 2 * c2] + bo;     // swapped pair
             if (has_res) {
               const unsigned ro_ = valid ? (unsigned)((rowr + u0) * 4) : OOB;
-              v0 += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rr, ro_, 0, 0));
-              v1 += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rr, ro_ + 4u, 0, 0));
+              const float r0 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rr, ro_, 0, 0));
+              const float r1 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rr, ro_ + 4u, 0, 0));
+              v0 = gate ? (r0 > 0.f ? v0 : v0 * a.slope) : v0 + r0;
+              v1 = gate ? (r1 > 0.f ? v1 : v1 * a.slope) : v1 + r1;
             }
             v0 = ag_apply_act(v0, a.act, a.slope);
             v1 = ag_apply_act(v1, a.act, a.slope);
@@ -207,7 +215,10 @@ __device__ __forceinline__ bool conv_epilogue_fast(const ConvP& p, f32x16 (&acc)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           v[q] += bo;
-          if (has_res) v[q] += __uint_as_float(pre[g][j][q]);
+          if (has_res) {
+            const float rv = __uint_as_float(pre[g][j][q]);
+            v[q] = gate ? (rv > 0.f ? v[q] : v[q] * a.slope) : v[q] + rv;
+          }
           v[q] = ag_apply_act(v[q], a.act, a.slope);
           if (u0 + q >= lenb) v[q] = 0.f;
           if (!has_res && a.accumulate) v[q] += __uint_as_float(pre[g][j][q]);
@@ -251,7 +262,10 @@ __device__ __forceinline__ void conv_epilogue_any(const ConvP& p, f32x16 (&acc)[
         const int u = a.mode == 0 ? n : s * (n - ((p.aligned && r >= rho) ? 1 : 0)) + r - a.pad;
         if (u < 0 || u >= a.Lout) continue;
         float v = acc[i][j][e] + bo;
-        if (rb) v += rb[(int64_t)o * a.res_cs + u];
+        if (rb) {
+          const float rv = rb[(int64_t)o * a.res_cs + u];
+          v = a.act == AG_ACT_LEAKY_GATE ? (rv > 0.f ? v : v * a.slope) : v + rv;
+        }
         v = ag_apply_act(v, a.act, a.slope);
         if (u >= lenb) v = 0.f;
         float* dst = yb + (int64_t)o * a.y_cs + u;

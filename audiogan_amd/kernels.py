@@ -9,7 +9,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import lib, check, ACT_NONE, ACT_LEAKY, ACT_TANH, OPT_RMSPROP, OPT_ADAM  # noqa: F401
+from ._lib import lib, check, ACT_NONE, ACT_LEAKY, ACT_TANH, ACT_LEAKY_GATE, OPT_RMSPROP, OPT_ADAM  # noqa: F401
 
 LEAKY_SLOPE = 0.01
 
@@ -262,7 +262,9 @@ def conv_engine(x, wp, y, K, stride, pad, mode, bias=None, res=None, lens=None, 
                 slope=LEAKY_SLOPE, accumulate=False, wp_pad=0):
     """mode 0: y[b,o,t] = sum W x[b,c,s*t+k-p]   (wp = gather layout of the weight)
     mode 1: y[b,o,s*t+k-p] += W x[b,c,t]        (wp = scatter layout; wp_pad = the padding it was prepared for)
-    x: [B,C,Lin] view, y: [B,O,Lout] view (written in place)."""
+    x: [B,C,Lin] view, y: [B,O,Lout] view (written in place).  act=ACT_LEAKY_GATE: ``res`` is the saved output of a
+    LeakyReLU and scales the result by that activation's derivative instead of being added."""
+    assert act != ACT_LEAKY_GATE or res is not None, 'ACT_LEAKY_GATE needs the saved activation in `res`'
     x_bs, x_cs = _bcl(x, 'x')
     y_bs, y_cs = _bcl(y, 'y')
     _chk(wp, 'wp'); _chk(bias, 'bias'); _chk(lens, 'lens', torch.int64)

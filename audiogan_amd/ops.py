@@ -13,7 +13,7 @@ hand-written kernels; torch is used for memory, views and the autograd graph onl
 import torch
 
 from . import kernels as K
-from .kernels import ACT_NONE, ACT_LEAKY, ACT_TANH
+from .kernels import ACT_NONE, ACT_LEAKY, ACT_TANH, ACT_LEAKY_GATE
 
 from .common import PARAM_EPOCH, Prepared, WNGroup, _zeros_like_list  # noqa: F401
 
@@ -48,13 +48,19 @@ def conv_fwd(spec, prep, x, y, bias=None, res=None, lens=None, act=ACT_NONE):
         K.conv_engine(x, prep.wpb, y, spec.K, spec.stride, spec.pad, 1, bias, res, lens, act, wp_pad=prep.pad)
 
 
-def conv_bwd_data(spec, prep, dy, dx, accumulate=False):
+def conv_bwd_data(spec, prep, dy, dx, accumulate=False, gate=None, lens=None):
+    """``gate``: the saved output of the LeakyReLU that produced this layer's input - its derivative (and the length mask
+    ``lens`` of that output) is applied in the epilogue, so ``dx`` comes out as the gradient of the PRE-activation below
+    (one pass instead of this launch plus a separate activation-backward pass over the same tensor)"""
+    act = ACT_LEAKY_GATE if gate is not None else ACT_NONE
     if prep.w is not None and _o1(spec):
+        assert gate is None
         K.conv_o1_bwd_data(dy, prep.w, dx, spec.K, spec.pad, accumulate)
     elif spec.kind == 'conv':
-        K.conv_engine(dy, prep.wpb, dx, spec.K, spec.stride, spec.pad, 1, accumulate=accumulate, wp_pad=prep.pad)
+        K.conv_engine(dy, prep.wpb, dx, spec.K, spec.stride, spec.pad, 1, res=gate, lens=lens, act=act,
+                      accumulate=accumulate, wp_pad=prep.pad)
     else:
-        K.conv_engine(dy, prep.wpa, dx, spec.K, spec.stride, spec.pad, 0, accumulate=accumulate)
+        K.conv_engine(dy, prep.wpa, dx, spec.K, spec.stride, spec.pad, 0, res=gate, lens=lens, act=act, accumulate=accumulate)
 
 
 def conv_wgrad(spec, x, dy, dw, db):
@@ -138,9 +144,11 @@ class GTrunkFn(torch.autograd.Function):
             hid = hids[i]
             if wg:
                 conv_wgrad(ds, hid, dout, dws[4 * i + 2], None)
+            # the hidden LeakyReLU's backward rides in the epilogue of this backward-data pass (dhid = d(pre-activation))
             dhid = torch.empty_like(hid)
-            conv_bwd_data(ds, qw, dout, dhid)
-            K.leaky_bwd(dhid, hid, dhid, bias_grad=dws[4 * i + 1] if wg else None)
+            conv_bwd_data(ds, qw, dout, dhid, gate=hid)
+            if wg:
+                K.channel_sum(dhid, dws[4 * i + 1])
             if wg:
                 conv_wgrad(cs, slab[:, :cin], dhid, dws[4 * i], None)
             conv_bwd_data(cs, pw, dhid, dslab[:, :cin], accumulate=True)
@@ -188,7 +196,7 @@ class DConvStackFn(torch.autograd.Function):
         wg = any(ctx.needs_input_grad[3:])
         dws = stack.group.zero_dws() if wg else None
         n = len(stack.specs)
-        d = None
+        d, gated = None, False
         for i in reversed(range(n)):
             sp = stack.specs[i]
             g = dacts[i]
@@ -198,16 +206,22 @@ class DConvStackFn(torch.autograd.Function):
                 d = torch.empty_like(acts[i])
                 K.leaky_bwd(g.contiguous(), acts[i], d, lens=ctx.lens_list[i],     # out of place: no clone
                             bias_grad=dws[2 * i + 1] if wg else None)
-            else:
+            elif not gated:
                 if g is not None:
                     K.axpby(g.contiguous(), d, 1.0, 1.0)
                 K.leaky_bwd(d, acts[i], d, lens=ctx.lens_list[i], bias_grad=dws[2 * i + 1] if wg else None)
+            elif wg:
+                K.channel_sum(d, dws[2 * i + 1])          # (d already is d(pre-activation): see below)
             xin = acts[i - 1] if i > 0 else x.contiguous().view(B, 1, L)
             if wg:
                 conv_wgrad(sp, xin, d, dws[2 * i], None)
             if i > 0 or ctx.needs_input_grad[0]:
                 dx = torch.empty_like(xin)
-                conv_bwd_data(sp, prep[2 * i], d, dx)
+                # when the layer below receives no other gradient its LeakyReLU + length-mask backward rides in this
+                # launch's epilogue (dx = d(pre-activation) of layer i - 1) instead of a pass of its own
+                gated = i > 0 and dacts[i - 1] is None
+                conv_bwd_data(sp, prep[2 * i], d, dx, gate=acts[i - 1] if gated else None,
+                              lens=ctx.lens_list[i - 1] if gated else None)
                 d = dx
             else:
                 d = None

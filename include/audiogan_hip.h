@@ -34,6 +34,10 @@ extern "C" {
 #define AG_ACT_NONE 0
 #define AG_ACT_LEAKY 1 /* LeakyReLU(slope): audiogan.py:261,277,532 (slope 0.01) */
 #define AG_ACT_TANH 2  /* audiogan.py:443 */
+/* ag_conv1d_engine only: `res` is not a residual but the SAVED OUTPUT y of a LeakyReLU; the result is scaled by that
+ * activation's derivative (1 where y > 0, slope elsewhere) - the LeakyReLU backward of the layer below folded into this
+ * layer's backward-data pass (the .backward() of audiogan.py:277, :532); bias, length mask and accumulate as usual */
+#define AG_ACT_LEAKY_GATE 3
 
 /* library / build identification (ABI version, gfx arch string) */
 int ag_abi_version(void);

@@ -9,7 +9,7 @@ box the real HIP kernels run and are themselves compared with the oracle (tests 
 import torch
 import torch.nn.functional as F
 
-ACT_NONE, ACT_LEAKY, ACT_TANH = 0, 1, 2
+ACT_NONE, ACT_LEAKY, ACT_TANH, ACT_LEAKY_GATE = 0, 1, 2, 3
 OPT_RMSPROP, OPT_ADAM = 0, 1
 LEAKY_SLOPE = 0.01
 
@@ -124,8 +124,8 @@ def conv_engine(x, wp, y, K, stride, pad, mode, bias=None, res=None, lens=None, 
     if bias is not None:
         out = out + bias.view(1, O, 1)
     if res is not None:
-        out = out + res
-    out = _act(out, act, slope)
+        out = out * torch.where(res > 0, torch.ones_like(res), torch.full_like(res, slope)) if act == ACT_LEAKY_GATE else out + res
+    out = _act(out, act if act != ACT_LEAKY_GATE else ACT_NONE, slope)
     if lens is not None:
         out = out * (torch.arange(Lout).view(1, 1, Lout) < lens.view(B, 1, 1)).float()
     if accumulate:

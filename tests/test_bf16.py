@@ -153,16 +153,21 @@ def test_networks_bf16_vs_rounded_oracle(K, bf16):
     l32 = do(x32, lens, c)[0]
     with O.bf16_mode():
         xo = go(z=z, c=c, stop=stop)[0]
+        xo.retain_grad()
         lo, actso, _, _ = do(xo, lens, c)
         (lo * wl).sum().backward()
     x = g(z=z.cuda(), c=c.cuda(), stop='never')[0]
+    x.retain_grad()
     l, acts, _, _ = d(x, lens.cuda(), c.cuda())
     (l * wl.cuda()).sum().backward()
     close_bf16(x, xo, 'waveform')
     close_bf16(l, lo, 'logits')
     for i, (a, b) in enumerate(zip(acts, actso)):
         close_bf16(a, b, 'act%d' % i)
-    for mod, ref in ((g, go), (d, do)):
+    # the critic's input gradient first: it is what the generator's gradients are made of (a mismatch further down with
+    # this one green points at the generator's backward, red at the critic's)
+    close_bf16(x.grad, xo.grad, 'd(loss)/d(waveform)', elem=5e-2, l2=2e-2)
+    for mod, ref in ((d, do), (g, go)):
         rp = dict(ref.named_parameters())
         for k, q in mod.named_parameters():
             if k.split('.')[-1].startswith('bias') and k.endswith('_v'):

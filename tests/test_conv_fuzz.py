@@ -40,7 +40,9 @@ def _cases(n, seed):
         lout = (lin + 2 * p - k) // s + 1 if kind == 'conv' else (lin - 1) * s - 2 * p + k
         if lout < 1 or (kind == 'conv' and lin + 2 * p < k):
             continue
-        opts = dict(bias=ri(0, 1), res=ri(0, 1), lens=ri(0, 1), act=ri(0, 1), acc=ri(0, 1), view=ri(0, 1))
+        opts = dict(bias=ri(0, 1), res=ri(0, 1), lens=ri(0, 1), act=ri(0, 2), acc=ri(0, 1), view=ri(0, 1))
+        if opts['act'] == 2:
+            opts['res'] = 1          # act 2 = ACT_LEAKY_GATE: `res` is the saved activation that gates the result
         out.append((kind, cin, cout, k, s, p, lin, B, opts))
     return out
 
@@ -68,9 +70,11 @@ def test_conv_engine_and_wgrad_random_shapes(K, prec):
             v = lin_out
             if bias is not None:
                 v = v + bias.double().view(1, -1, 1)
-            if res is not None:
+            if res is not None and o['act'] == 2:
+                v = v * torch.where(res > 0, torch.ones_like(res), torch.full_like(res, K.LEAKY_SLOPE)).double()
+            elif res is not None:
                 v = v + res.double()
-            if o['act']:
+            if o['act'] == 1:
                 v = F.leaky_relu(v, K.LEAKY_SLOPE)
             if lens is not None:
                 v = v * (torch.arange(lout).view(1, 1, -1) < lens.view(B, 1, 1)).double()
@@ -87,7 +91,7 @@ def test_conv_engine_and_wgrad_random_shapes(K, prec):
             y = y0.cuda().clone()
             K.conv_engine(xg, prep.wpa if kind == 'conv' else prep.wpb, y, k, s, p, 0 if kind == 'conv' else 1,
                           bias=bias.cuda() if bias is not None else None, res=res.cuda() if res is not None else None,
-                          lens=lens.cuda() if lens is not None else None, act=K.ACT_LEAKY if o['act'] else K.ACT_NONE,
+                          lens=lens.cuda() if lens is not None else None, act=(K.ACT_NONE, K.ACT_LEAKY, K.ACT_LEAKY_GATE)[o['act']],
                           accumulate=bool(o['acc']), wp_pad=p)
             scale = max(1.0, float(ref.detach().abs().max()))
             err = float((y.cpu().double() - ref.detach()).abs().max())
