@@ -106,17 +106,21 @@ def one_step(train, g, d, opt_g, opt_d, b, hook_d=None, hook_g=None, overlap=Fal
 
 
 def pmc_traffic(kernel, dtype='f32'):
-    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes
-    (profiles/r02_pmc_traffic.json, for --dtype bf16 profiles/r02_pmc_traffic_bf16.json: FETCH_SIZE and WRITE_SIZE in
-    separate passes, gfx950 x2 read correction applied); the instantiation if it was profiled under that name, else
-    the kernel class; None when neither was."""
-    path = os.path.join(ROOT, 'profiles', 'r02_pmc_traffic_bf16.json' if dtype == 'bf16' else 'r02_pmc_traffic.json')
-    if not os.path.exists(path):
-        return None
-    tab = json.load(open(path))
-    name = kernel.replace(' ', '')
-    ent = tab.get(name) or tab.get(name.split('<')[0])
-    return ent['bytes_per_launch'] if ent else None
+    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r03_pmc_traffic.json, for
+    --dtype bf16 profiles/r03_pmc_traffic_bf16.json; the round-2 files when a round-3 one is absent: FETCH_SIZE and
+    WRITE_SIZE in separate passes, gfx950 x2 read correction applied); the instantiation if it was profiled under that
+    name, else the kernel class; None when neither was."""
+    suffix = '_bf16' if dtype == 'bf16' else ''
+    for rnd in ('r03', 'r02'):
+        path = os.path.join(ROOT, 'profiles', '%s_pmc_traffic%s.json' % (rnd, suffix))
+        if not os.path.exists(path):
+            continue
+        tab = json.load(open(path))
+        name = kernel.replace(' ', '')
+        ent = tab.get(name) or tab.get(name.split('<')[0])
+        if ent:
+            return ent['bytes_per_launch']
+    return None
 
 
 def cpu_baseline(batch, steps, opt_kind, threads=0, budget_s=110.0, warm=2, workload='c2'):

@@ -15,8 +15,10 @@ LAYERS = [('G1.conv', 'conv', 1, 128, 17, 8, 8, 8192), ('G1.deconv', 'convt', 12
           ('G5.final', 'o1', 113, 1, 3, 1, 1, 8192),
           ('D1', 'conv', 1, 16, 7, 2, 3, 8192), ('D2', 'conv', 16, 32, 7, 2, 3, 4096), ('D3', 'conv', 32, 64, 7, 2, 3, 2048),
           ('D4', 'conv', 64, 128, 7, 2, 3, 1024), ('D5', 'conv', 128, 256, 7, 2, 3, 512), ('D6', 'conv', 256, 512, 7, 2, 3, 256)]
-PEAK_TF, PEAK_GBS = 157.3, 8000.0        # fp32 MFMA peak; in bf16 mode the table still prices against it (the layers
-# mix bf16-MFMA kernels with fp32 ones), so fractions above 1 mean "faster than any fp32 kernel could be"
+# priced against the dense matrix peak of the mode's MFMA: fp32 157.3 TFLOP/s, bf16 2500 TFLOP/s (MI355X_MICROARCH.md).
+# In bf16 mode a few layers (single input channel, the 113 -> 1 final conv) still run fp32 FMA / MFMA kernels on rounded
+# operands: their fraction of the bf16 peak is what it is.
+PEAK_TF, PEAK_GBS = (2500.0 if PREC == 'bf16' else 157.3), 8000.0
 
 
 def timed(fn):
