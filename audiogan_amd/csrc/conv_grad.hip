@@ -30,6 +30,21 @@ struct WgP {
 // LDS: sh tile TRANSPOSED [TC][AT+1] (MFMA A operand = unit-stride read), lg rows [maxch][lgp].
 template <int TA, int TN, int WA, int WN>
 __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgP p) {
+  // XCD-aware tile order (workgroup ids go round-robin over the 8 XCDs, each with its own L2): XCD i works on a contiguous
+  // run of logical tiles, i.e. on all the column tiles of a few (row tile, reduction share) pairs, which read the SAME
+  // gradient rows - they then come out of that XCD's L2 instead of crossing the fabric once per column tile (speed only)
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  const int gz_ = gridDim.z;
+  {
+    const int gx = gridDim.x, gy = gridDim.y, nwg = gx * gy * gz_;
+    if (nwg >= 16) {
+      // XCD i = lin % 8 holds nwg / 8 (+1 for i < nwg % 8) workgroups: give it that many CONSECUTIVE logical tiles
+      const int lin = (bz * gy + by) * gx + bx;
+      const int xi = lin & 7, q = nwg >> 3, r = nwg & 7;
+      const int t = xi * q + (xi < r ? xi : r) + (lin >> 3);
+      bx = t % gx; by = (t / gx) % gy; bz = t / (gx * gy);
+    }
+  }
   static_assert(WA * WN == 4, "4 compute waves");
   constexpr int AT = 32 * TA * WA, NT = 32 * TN * WN;
   constexpr int SP = AT + 1;
@@ -40,14 +55,14 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgP p) {
   const int l31 = lane & 31, h = lane >> 5;
   const int cw = wid & 3;
   const int wa = cw / WN, wn = cw % WN;
-  const int a0 = blockIdx.y * AT, ck0 = blockIdx.x * NT;
+  const int a0 = by * AT, ck0 = bx * NT;
   const int c_lo = ck0 / p.K;
   int c_hi = (ck0 + NT - 1) / p.K;
   if (c_hi >= p.C) c_hi = p.C - 1;
   const int nch = c_hi - c_lo + 1;
   const int span = p.s * (p.TC - 1) + p.K;
   const int total = p.B * p.nchunk;
-  const int nmine = (total - (int)blockIdx.z + (int)gridDim.z - 1) / (int)gridDim.z;   // chunks of this block
+  const int nmine = (total - bz + gz_ - 1) / gz_;   // chunks of this block
 
   auto stage = [&](int ch, int buf, int sw, int nsw) {
     float* shs = smem + buf * bufsz;
@@ -121,7 +136,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgP p) {
     }
   };
 
-  if (nmine > 0) stage(blockIdx.z, 0, wid, 8);
+  if (nmine > 0) stage(bz, 0, wid, 8);
   __syncthreads();
 
   if (__builtin_amdgcn_readfirstlane(threadIdx.x) >= 256) {
@@ -164,7 +179,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgP p) {
     if (fastp) {
       for (; ci < nmine; ++ci) {
         if (ci + 1 < nmine) {
-          const int ch = blockIdx.z + (ci + 1) * gridDim.z;
+          const int ch = bz + (ci + 1) * gz_;
           const int b = ch / p.nchunk;
           const int t0 = (ch - b * p.nchunk) * p.TC;
           const int g0 = p.s * t0 - p.p;
@@ -206,7 +221,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgP p) {
       }
     }
     for (; ci < nmine; ++ci) {
-      if (ci + 1 < nmine) stage(blockIdx.z + (ci + 1) * gridDim.z, (ci + 1) & 1, cw, 4);
+      if (ci + 1 < nmine) stage(bz + (ci + 1) * gz_, (ci + 1) & 1, cw, 4);
       __syncthreads();
     }
     return;
@@ -265,7 +280,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgP p) {
       for (int j = 0; j < TN; ++j) {
         const int ck = ck0 + wn * 32 * TN + 32 * j + l31;
         if (ck >= p.CK) continue;
-        if (p.part) p.part[((int64_t)blockIdx.z * p.A + a) * p.CK + ck] = acc[i][j][e];
+        if (p.part) p.part[((int64_t)bz * p.A + a) * p.CK + ck] = acc[i][j][e];
         else atomicAdd(p.dw + (int64_t)a * p.CK + ck, acc[i][j][e]);
       }
     }
@@ -289,6 +304,21 @@ typedef unsigned wu32x2 __attribute__((ext_vector_type(2)));
 
 template <int TA, int TN, int WA, int WN>
 __global__ __launch_bounds__(512) void conv_wgrad_bf16_kernel(const WgP p) {
+  // XCD-aware tile order (workgroup ids go round-robin over the 8 XCDs, each with its own L2): XCD i works on a contiguous
+  // run of logical tiles, i.e. on all the column tiles of a few (row tile, reduction share) pairs, which read the SAME
+  // gradient rows - they then come out of that XCD's L2 instead of crossing the fabric once per column tile (speed only)
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  const int gz_ = gridDim.z;
+  {
+    const int gx = gridDim.x, gy = gridDim.y, nwg = gx * gy * gz_;
+    if (nwg >= 16) {
+      // XCD i = lin % 8 holds nwg / 8 (+1 for i < nwg % 8) workgroups: give it that many CONSECUTIVE logical tiles
+      const int lin = (bz * gy + by) * gx + bx;
+      const int xi = lin & 7, q = nwg >> 3, r = nwg & 7;
+      const int t = xi * q + (xi < r ? xi : r) + (lin >> 3);
+      bx = t % gx; by = (t / gx) % gy; bz = t / (gx * gy);
+    }
+  }
   static_assert(WA * WN == 4, "4 compute waves");
   constexpr int AT = 32 * TA * WA, NT = 32 * TN * WN;
   extern __shared__ float smem[];
@@ -301,14 +331,14 @@ __global__ __launch_bounds__(512) void conv_wgrad_bf16_kernel(const WgP p) {
   const int l31 = lane & 31, h = lane >> 5;
   const int cw = wid & 3;
   const int wa = cw / WN, wn = cw % WN;
-  const int a0 = blockIdx.y * AT, ck0 = blockIdx.x * NT;
+  const int a0 = by * AT, ck0 = bx * NT;
   const int c_lo = ck0 / p.K;
   int c_hi = (ck0 + NT - 1) / p.K;
   if (c_hi >= p.C) c_hi = p.C - 1;
   const int nch = c_hi - c_lo + 1;
   const int span = p.s * (p.TC - 1) + p.K;
   const int total = p.B * p.nchunk;
-  const int nmine = (total - (int)blockIdx.z + (int)gridDim.z - 1) / (int)gridDim.z;   // chunks of this block
+  const int nmine = (total - bz + gz_ - 1) / gz_;   // chunks of this block
 
   if (__builtin_amdgcn_readfirstlane(threadIdx.x) >= 256) {
     // ---------------- staging waves
@@ -339,7 +369,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_bf16_kernel(const WgP p) {
     f32x4 sv[WB_FS], lv[WB_FL];
     bool lok[WB_FL];
     auto loadc = [&](int cix) __attribute__((always_inline)) {
-      const int ch = blockIdx.z + cix * gridDim.z;
+      const int ch = bz + cix * gz_;
       const int b = ch / p.nchunk;
       const int t0 = (ch - b * p.nchunk) * p.TC;
       const int g0 = p.s * t0 - p.p;
@@ -448,7 +478,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_bf16_kernel(const WgP p) {
       for (int j = 0; j < TN; ++j) {
         const int ck = ck0 + wn * 32 * TN + 32 * j + l31;
         if (ck >= p.CK) continue;
-        if (p.part) p.part[((int64_t)blockIdx.z * p.A + a) * p.CK + ck] = acc[i][j][e];
+        if (p.part) p.part[((int64_t)bz * p.A + a) * p.CK + ck] = acc[i][j][e];
         else atomicAdd(p.dw + (int64_t)a * p.CK + ck, acc[i][j][e]);
       }
     }
