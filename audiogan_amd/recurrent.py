@@ -302,9 +302,7 @@ class GFrontFn(torch.autograd.Function):
                 K.gemm(ds_tb, hs.view(T * B, S), dws[4 * nl + 2], ta=True)
                 K.col_sum(ds_tb, dws[4 * nl + 3])
             K.gemm(ds_tb, sw, dacc.view(T * B, S + fs)[:, :S])
-        # [W_hh | W_x]^T stored [S+fs, 4S]: the per-frame product below then reads BOTH operands as 16-byte k-contiguous
-        # row pieces (the k-strided form of the same product needs 4-byte loads of the 21 MB panel, every frame)
-        wcat_t = torch.cat([w_hh, wx], 1).t().contiguous()
+        wcat = torch.cat([w_hh, wx], 1)                # [4S, S+fs]
         dgs = torch.empty(T, B, 4 * S, device=dev)
         dxt = torch.empty(T, B, fs, device=dev)
         dcs = [torch.empty(B, S, device=dev), torch.empty(B, S, device=dev)]
@@ -312,7 +310,7 @@ class GFrontFn(torch.autograd.Function):
             K.lstm_front_bwd_step(dacc[t, :, S:], x[:, t * fs:(t + 1) * fs], dxt[t], pw, dacc[t, :, :S], gates[t], cs[t],
                                   cs[t + 1], dcs[(t + 1) & 1] if t < T - 1 else None, dgs[t], dcs[t & 1])
             if t > 0:
-                K.skinny_gemm(dgs[t], wcat_t, dacc[t - 1], tb=True, atomic=True)
+                K.skinny_gemm(dgs[t], wcat, dacc[t - 1], atomic=True)
         return [dgs], dxt
 
     @staticmethod
@@ -456,18 +454,15 @@ class GRUFrontFn(torch.autograd.Function):
         dgh = torch.empty(T, B, 3 * S, device=dev)
         dxt = torch.empty(T, B, fs, device=dev)
         dh_dir = torch.empty(B, S, device=dev)
-        # transposed copies, once per backward: the three per-frame products then read both operands as 16-byte k-contiguous
-        # row pieces instead of 4-byte k-strided loads of the weight panels
-        pw_t, whh_t, wx_t = pw.t().contiguous(), w_hh.t().contiguous(), wx.t().contiguous()
         for t in reversed(range(T)):
             gx = dxt[t]
             K.act_bwd2d(dxa[:, t * fs:(t + 1) * fs], x[:, t * fs:(t + 1) * fs], gx, ACT_TANH)
-            _small_acc(gx, pw_t, dha[t + 1], tb=True)
+            _small_acc(gx, pw, dha[t + 1])
             K.gru_cell_bwd(gi[t], gh[t], hs[t], dha[t + 1], dgi[t], dgh[t], dh_dir)
             K.axpby(dh_dir, dha[t], 1.0, 1.0)                     # direct path  dh * z
-            _small_acc(dgh[t], whh_t, dha[t], tb=True)            # through the hidden product
+            _small_acc(dgh[t], w_hh, dha[t])                      # through the hidden product
             if t > 0:
-                _small_acc(dgi[t], wx_t, dxa[:, (t - 1) * fs:t * fs], tb=True)
+                _small_acc(dgi[t], wx, dxa[:, (t - 1) * fs:t * fs])
         dxt2, dgi2, dgh2 = dxt.view(T * B, fs), dgi.view(T * B, 3 * S), dgh.view(T * B, 3 * S)
         if wg:
             K.gemm(dxt2, hs[1:].view(T * B, S), dws[4], ta=True)
