@@ -127,7 +127,12 @@ def _load():
     return lib
 
 
+ABI_VERSION = 3      # what this package was written against (csrc/api.hip: ag_abi_version)
+
 lib = _load()
+if lib.ag_abi_version() != ABI_VERSION:
+    raise ImportError('audiogan_amd: %s has ABI version %d, this package needs %d - rebuild it (make -C audiogan_amd/csrc)'
+                      % (LIB_PATH, lib.ag_abi_version(), ABI_VERSION))
 
 
 class AudioganHipError(RuntimeError):
