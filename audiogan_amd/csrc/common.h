@@ -137,3 +137,11 @@ __device__ __forceinline__ float ag_apply_act(float v, int act, float slope) {
 }
 
 __device__ __forceinline__ float ag_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }
+
+// single-input-channel convolutions (conv_c1.hip): taken by ag_conv1d_engine / ag_conv1d_wgrad for the layer shapes they
+// are instantiated for.  try_*: 1 = launched (status in *rc), 0 = not this kernel's case.
+int ag_conv_c1_try_fwd(const ag_conv_args& a, int rb, hipStream_t st, int* rc);
+int ag_conv_c1_try_bwdx(const ag_conv_args& a, int rb, hipStream_t st, int* rc);
+int ag_conv_c1_wgrad_slabs(int B, int A, int Lt, int s, int K, int* bper_out);
+int ag_conv_c1_wgrad(const float* dy, int64_t dy_bs, int64_t dy_cs, const float* x, int64_t x_bs, float* part, int B, int A,
+                     int Lt, int Lx, int s, int K, int pad, int rb, hipStream_t st);

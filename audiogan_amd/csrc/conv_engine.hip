@@ -974,6 +974,12 @@ extern "C" int ag_conv1d_engine(const ag_conv_args* args, void* stream) {
       p.n_cnt = n_hi - p.n_lo + 1;
     }
   }
+  if (getenv("AG_CONV_C1") == nullptr || getenv("AG_CONV_C1")[0] != '0') {
+    // single-input-channel layers (D1, G1.conv) and their backward-data: streaming kernels (conv_c1.hip)
+    int rc = AG_OK;
+    if (ag_conv_c1_try_fwd(a, p.rb, (hipStream_t)stream, &rc)) return rc;
+    if (ag_conv_c1_try_bwdx(a, p.rb, (hipStream_t)stream, &rc)) return rc;
+  }
   AG_REQUIRE(p.taps <= MAX_TAPS, "ag_conv1d_engine: more than %d taps", MAX_TAPS);
   p.sp_shift = ilog2_exact(p.sp);
   p.s_shift = ilog2_exact(a.stride);

@@ -647,6 +647,16 @@ extern "C" int ag_conv1d_wgrad(const float* sh, int64_t sh_bs, int64_t sh_cs, co
   p.rb = ag_precision() == AG_PREC_BF16;
   p.vec = (((uintptr_t)sh & 15) == 0) && (sh_bs % 4 == 0) && (sh_cs % 4 == 0);
   hipStream_t st = (hipStream_t)stream;
+  if (C == 1 && ws.p && ag_conv_c1_wgrad_slabs(B, A, Lsh, stride, K, nullptr) > 0 &&
+      (((uintptr_t)sh & 15) == 0) && sh_bs % 4 == 0 && sh_cs % 4 == 0 &&
+      ws.numel >= (int64_t)ag_conv_c1_wgrad_slabs(B, A, Lsh, stride, K, nullptr) * A * K &&
+      (getenv("AG_CONV_C1") == nullptr || getenv("AG_CONV_C1")[0] != '0')) {
+    // D1 / G1.conv: streaming kernel, one partial [A][K] per block, fixed-order second stage (conv_c1.hip)
+    const int slabs = ag_conv_c1_wgrad_slabs(B, A, Lsh, stride, K, nullptr);
+    const int rc = ag_conv_c1_wgrad(sh, sh_bs, sh_cs, lg, lg_bs, ws.p, B, A, Lsh, Llg, stride, K, pad, p.rb, st);
+    if (rc != AG_OK) return rc;
+    return ag_slab_reduce(ws.p, slabs, (int64_t)A * K, dw, 1, st);
+  }
   if (C == 1 && K <= 8) {       // (K = 17, A = 128 - G1.conv - measured faster on the MFMA path: 43 vs 88 us)
     const int ag = 8;
     const int gx = ag_cdiv(Lsh, 256), gy = ag_cdiv(A, ag);
@@ -673,6 +683,17 @@ extern "C" int ag_conv1d_wgrad(const float* sh, int64_t sh_bs, int64_t sh_cs, co
 
 // floats of workspace ag_conv1d_wgrad wants bound (ag_bind_workspace) for its two-stage reduction
 extern "C" int64_t ag_conv1d_wgrad_ws_numel(int B, int A, int Lsh, int C, int K) {
+  if (C == 1 && K == 7) {
+    // (the stride is not an argument here: the larger of what the streaming kernel of conv_c1.hip - stride 2 - and the
+    // generic single-channel reduction need)
+    const int64_t need = (int64_t)ag_conv_c1_wgrad_slabs(B, A, Lsh, 2, K, nullptr) * A * K;
+    const int gx = ag_cdiv(Lsh, 256), gy = ag_cdiv(A, 8);
+    int gz = ag_cdiv(512, gx * gy);
+    if (gz > B) gz = B;
+    if (gz < 1) gz = 1;
+    const int64_t n2 = (int64_t)gz * gx * A * K;
+    return n2 > need ? n2 : need;
+  }
   if (C == 1 && K <= 8) {
     const int gx = ag_cdiv(Lsh, 256), gy = ag_cdiv(A, 8);
     int gz = ag_cdiv(512, gx * gy);

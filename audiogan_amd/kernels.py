@@ -542,6 +542,12 @@ def _work_conv(x, wp, y, K_, stride, pad, mode, *a_, **kw):
     else:
         tile = '2,2,2,2'
     macs = B * O * Lout * Cc * K_ if mode == 0 else B * Cc * Lin * O * K_
+    if (K_, stride) == (7, 2) and _os0.environ.get('AG_CONV_C1', '1') != '0':
+        # the critic's single-input-channel first layer and its backward-data: streaming kernels (conv_c1.hip)
+        if mode == 0 and Cc == 1 and kw.get('res') is None and not kw.get('accumulate'):
+            return 'conv_c1_fwd_kernel<%d,%d>' % (stride, K_), 2.0 * macs, 4.0 * (x.numel() + y.numel() + O * K_)
+        if mode == 1 and O == 1 and kw.get('res') is None and kw.get('bias') is None and kw.get('lens') is None:
+            return 'conv_c1_bwdx_kernel<%d,%d>' % (stride, K_), 2.0 * macs, 4.0 * (x.numel() + y.numel() + Cc * K_)
     taps = K_ if mode == 0 else _cdiv(K_, stride)
     ts = (taps, stride if mode == 0 else 0)
     if ts not in ((17, 8), (9, 4), (7, 2), (3, 1), (16, 8), (8, 4), (2, 0), (3, 0), (4, 0)):
@@ -563,6 +569,8 @@ def _work_conv(x, wp, y, K_, stride, pad, mode, *a_, **kw):
 def _work_wgrad(sh, lg, dw, K_, stride, pad):
     B, A, Lsh = sh.shape
     Cc = lg.size(1)
+    if Cc == 1 and (K_, stride) == (7, 2) and _os0.environ.get('AG_CONV_C1', '1') != '0':
+        return 'conv_c1_wgrad4_kernel<%d,%d>' % (stride, K_), 2.0 * B * A * Lsh * K_, 4.0 * (sh.numel() + lg.numel() + dw.numel())
     tile = '1,1,1,4' if A <= 32 else ('1,1,2,2' if (A <= 64 or Cc * K_ <= 64) else '2,2,2,2')
     return 'conv_wgrad_kernel<%s>' % tile, 2.0 * B * A * Lsh * Cc * K_, 4.0 * (sh.numel() + lg.numel() + dw.numel())
 

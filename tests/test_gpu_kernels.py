@@ -2,6 +2,8 @@
 libaudiogan_hip.so) and compared with torch-CPU fp32 on the same seeded inputs.
 Tolerance: 1e-3 relative (north_star), written per test; most kernels are far tighter because
 v_mfma_f32_32x32x2_f32 is an exact fp32 fma chain."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -659,3 +661,52 @@ def test_grufront_persistent_launch(K, S, fs, B, T):
     close(outs[1][1], outs[0][1], rtol=1e-4, atol=1e-5)
     for a, b in zip(outs[1][2], outs[0][2]):
         close(a, b, rtol=1e-3, atol=1e-5 * max(1.0, float(b.abs().max())))
+
+
+@pytest.mark.parametrize('k,s,p,cout,lin,B', [(7, 2, 3, 16, 8192, 3), (7, 2, 3, 16, 1001, 2), (7, 2, 3, 5, 64, 1),
+                                             (17, 8, 8, 128, 8192, 2), (17, 8, 8, 128, 1000, 3), (17, 8, 8, 33, 40, 1)])
+def test_single_input_channel_conv_kernels(K, k, s, p, cout, lin, B):
+    """D1 (one input channel, k7 s2): the streaming kernels of conv_c1.hip (G1.conv's shape stays on the engine; its cases
+    here check that the dispatch leaves it alone) - forward with bias + LeakyReLU + length
+    mask, backward-data (plain and accumulating), backward-weight - against float64 convolutions, and against the general
+    engine (AG_CONV_C1=0) which must agree to fp32 rounding"""
+    from audiogan_amd import ops
+    gen = torch.Generator().manual_seed(61)
+    w = torch.randn(cout, 1, k, generator=gen) / k ** 0.5
+    x = torch.randn(B, 1, lin, generator=gen)
+    spec = ops.ConvSpec('conv', 1, cout, k, s, p)
+    lout = spec.out_len(lin)
+    bias = torch.randn(cout, generator=gen)
+    lens = torch.randint(1, lout + 1, (B,), generator=gen)
+    lens[0] = lout
+    dy = torch.randn(B, cout, lout, generator=gen)
+    xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    lin_out = F.conv1d(xr, wr, None, s, p)
+    ref = F.leaky_relu(lin_out + bias.double().view(1, -1, 1), K.LEAKY_SLOPE) * \
+        (torch.arange(lout).view(1, 1, -1) < lens.view(B, 1, 1)).double()
+    lin_out.backward(dy.double())
+    prep = ops.Prepared(w=None, wpa=torch.zeros(K.wpa_numel(cout, 1, k)).cuda(), wpb=torch.zeros(K.wpb_numel(cout, 1, k, s)).cuda(), pad=p)
+    K.prep_conv_weight(w.cuda(), prep.wpa, prep.wpb, s, p)
+    dx0 = torch.randn(B, 1, lin, generator=gen)
+    res = {}
+    for sw in ('1', '0'):
+        os.environ['AG_CONV_C1'] = sw
+        try:
+            y = torch.full((B, cout, lout), float('nan')).cuda()
+            K.conv_engine(x.cuda(), prep.wpa, y, k, s, p, 0, bias=bias.cuda(), lens=lens.cuda(), act=K.ACT_LEAKY)
+            dx = torch.full((B, 1, lin), float('nan')).cuda()
+            ops.conv_bwd_data(spec, prep, dy.cuda(), dx)
+            dxa = dx0.cuda().clone()
+            ops.conv_bwd_data(spec, prep, dy.cuda(), dxa, accumulate=True)
+            dw = torch.zeros(cout, 1, k).cuda()
+            ops.conv_wgrad(spec, x.cuda(), dy.cuda(), dw, None)
+            res[sw] = (y.cpu(), dx.cpu(), dxa.cpu(), dw.cpu())
+        finally:
+            os.environ.pop('AG_CONV_C1', None)
+    y, dx, dxa, dw = res['1']
+    close(y, ref, rtol=1e-4, atol=1e-5, msg='fwd')
+    close(dx, xr.grad, rtol=1e-4, atol=1e-4 * float(xr.grad.abs().max()), msg='bwd-data')
+    close(dxa, dx0.double() + xr.grad, rtol=1e-4, atol=1e-4 * float(xr.grad.abs().max()), msg='bwd-data accumulate')
+    close(dw, wr.grad, rtol=1e-4, atol=1e-4 * float(wr.grad.abs().max()), msg='bwd-weight')
+    for a, b, n in zip(res['1'], res['0'], ('fwd', 'bwd-data', 'bwd-data acc', 'bwd-weight')):
+        close(a, b, rtol=1e-4, atol=1e-4 * max(1.0, float(b.abs().max())), msg='vs engine: ' + n)
