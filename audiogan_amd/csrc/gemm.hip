@@ -174,6 +174,30 @@ struct RContig {
   }
 };
 
+// XCD-aware placement.  Workgroup ids go round-robin over the 8 XCDs, each with its own L2.  In plain order the column
+// tiles of one row band land on 8 different XCDs and every XCD pulls ALL of A through the fabric; with K split over
+// grid.z every XCD additionally pulls every K slice of B.  Remapped: with 8 | ksplit one XCD works on whole K slices (its
+// L2 fetches that slice of A and of B once); with ksplit in {1, 2, 4} a slice is shared by 8 / ksplit XCDs, each taking a
+// contiguous band of the slice's tiles.  Speed only: the result does not depend on placement (slices are indexed by bz).
+__device__ __forceinline__ void xcd_place(int& bx, int& by, int& bz) {
+  const int gx = gridDim.x, nwg = gx * gridDim.y, ks = gridDim.z;
+  const int lin = (blockIdx.z * gridDim.y + blockIdx.y) * gx + blockIdx.x;
+  const int x = lin & 7, q = lin >> 3;
+  bx = blockIdx.x; by = blockIdx.y; bz = blockIdx.z;
+  int tile;
+  if ((ks & 7) == 0) {
+    bz = x + 8 * (q / nwg);
+    tile = q % nwg;
+  } else if (ks <= 4 && (8 % ks) == 0 && nwg % (8 / ks) == 0) {
+    bz = x % ks;
+    tile = (x / ks) * (nwg / (8 / ks)) + q;
+  } else {
+    return;
+  }
+  by = tile / gx;
+  bx = tile - by * gx;
+}
+
 template <int TM, int TN, int WM, int WN, int TA, int TB>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
   static_assert(WM * WN == 4, "4 waves");
@@ -185,7 +209,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l31 = lane & 31, h = lane >> 5;
   const int wm0 = (wid / WN) * 32 * TM, wn0 = (wid % WN) * 32 * TN;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  int bx, by, bz;
+  xcd_place(bx, by, bz);
+  const int m0 = by * BM, n0 = bx * BN;
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -198,7 +224,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
   typename std::conditional<TA == 0, KContig<BM>, RContig<BM>>::type la;
   typename std::conditional<TB == 1, KContig<BN>, RContig<BN>>::type lb;
 
-  const int kbeg = blockIdx.z * p.kchunk;
+  const int kbeg = bz * p.kchunk;
   const int kend = (kbeg + p.kchunk < p.K) ? kbeg + p.kchunk : p.K;
   const bool fast = p.vecA && p.vecB && la.fast_ok(m0, p.M) && lb.fast_ok(n0, p.N);
   if (fast) {
@@ -282,10 +308,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
         float* dst = p.C + (int64_t)row * p.ldc + col;
         if (p.ksplit > 1) {
           if (p.part) {
-            p.part[((int64_t)blockIdx.z * p.M + row) * p.N + col] = v;
+            p.part[((int64_t)bz * p.M + row) * p.N + col] = v;
             continue;
           }
-          if (blockIdx.z == 0) {
+          if (bz == 0) {
             if (p.bias) v += p.bias[col];
             if (p.res) v += p.res[(int64_t)row * p.ldres + col];
           }
@@ -324,17 +350,8 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmP p) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l31 = lane & 31, h = lane >> 5;
   const int wm0 = (wid >> 1) * 64, wn0 = (wid & 1) * 64;
-  // XCD-aware tile order (see gemm_bf16_kernel): XCD i works on a contiguous band of row tiles, so each XCD's L2 pulls
-  // its own share of A plus B instead of all of A
-  int bx = blockIdx.x, by = blockIdx.y;
-  {
-    const int nwg = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;
-    if ((nwg & 7) == 0) {
-      const int tile = (lin & 7) * (nwg >> 3) + (lin >> 3);
-      by = tile / gridDim.x;
-      bx = tile - by * gridDim.x;
-    }
-  }
+  int bx, by, bz;
+  xcd_place(bx, by, bz);
   const int m0 = by * BM, n0 = bx * BN;
 
   // per-lane DMA sources at k = 0 (two 16-byte pieces per operand per tile)
@@ -379,7 +396,7 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmP p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  const int kbeg = blockIdx.z * p.kchunk;
+  const int kbeg = bz * p.kchunk;
   const int kend = (kbeg + p.kchunk < p.K) ? kbeg + p.kchunk : p.K;
   stage(kbeg, 0);
   __syncthreads();
@@ -462,10 +479,10 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmP p) {
         float* dst = p.C + (int64_t)row * p.ldc + col;
         if (p.ksplit > 1) {
           if (p.part) {
-            p.part[((int64_t)blockIdx.z * p.M + row) * p.N + col] = v;
+            p.part[((int64_t)bz * p.M + row) * p.N + col] = v;
             continue;
           }
-          if (blockIdx.z == 0) {
+          if (bz == 0) {
             if (p.bias) v += p.bias[col];
             if (p.res) v += p.res[(int64_t)row * p.ldres + col];
           }
@@ -607,18 +624,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmP p) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l31 = lane & 31, h = lane >> 5;
   const int wm0 = (wid >> 1) * 64, wn0 = (wid & 1) * 64;
-  // XCD-aware tile order: workgroup ids go round-robin over the 8 XCDs (each with its own L2).  In plain order the 8
-  // column tiles of one row band land on 8 different XCDs and every XCD pulls ALL of A through the fabric; remapped,
-  // XCD i works on a contiguous band of row tiles (speed only - the result does not depend on placement).
-  int bx = blockIdx.x, by = blockIdx.y;
-  {
-    const int nwg = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;
-    if ((nwg & 7) == 0) {
-      const int tile = (lin & 7) * (nwg >> 3) + (lin >> 3);
-      by = tile / gridDim.x;
-      bx = tile - by * gridDim.x;
-    }
-  }
+  int bx, by, bz;
+  xcd_place(bx, by, bz);
   const int m0 = by * BM, n0 = bx * BN;
   Bf16Loader<TA> la;
   Bf16Loader<(TB == 1 ? 0 : 1)> lb;
@@ -629,7 +636,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmP p) {
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-  const int kbeg = blockIdx.z * p.kchunk;
+  const int kbeg = bz * p.kchunk;
   const int kend = (kbeg + p.kchunk < p.K) ? kbeg + p.kchunk : p.K;
   la.load(p.A, p.lda, m0, p.M, kbeg, kend, tid);
   lb.load(p.B, p.ldb, n0, p.N, kbeg, kend, tid);
@@ -704,10 +711,10 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmP p) {
         float* dst = p.C + (int64_t)row * p.ldc + col;
         if (p.ksplit > 1) {
           if (p.part) {
-            p.part[((int64_t)blockIdx.z * p.M + row) * p.N + col] = v;
+            p.part[((int64_t)bz * p.M + row) * p.N + col] = v;
             continue;
           }
-          if (blockIdx.z == 0) {
+          if (bz == 0) {
             if (p.bias) v += p.bias[col];
             if (p.res) v += p.res[(int64_t)row * p.ldres + col];
           }
@@ -806,6 +813,17 @@ static int launch_gemm(const GemmP& p, int ta, int tb, hipStream_t st) {
 
 static bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
+// K slices for a product with few output tiles and a long reduction: about 512 workgroups, slices of at least 256 k,
+// slab traffic (2 * ks * M * N * 4 B) capped at 12 M floats, and a count xcd_place can put on whole XCDs (2, 4 or a
+// multiple of 8).  0 / 1 = do not split.
+static int gemm_pick_ksplit(int64_t tiles, int64_t mn, int K) {
+  static const int cand[] = {32, 24, 16, 8, 4, 2};
+  const int64_t want = (512 * 4 / tiles + 2) / 3;            // up to a third above 512 / tiles
+  for (int c : cand)
+    if (c <= want && c <= K / 256 && (int64_t)c * mn <= ((int64_t)12 << 20)) return c;
+  return 1;
+}
+
 extern "C" int ag_gemm(const float* A, int lda, int ta, const float* B, int ldb, int tb, float* C,
                        int ldc, int M, int N, int K, float alpha, float beta, const float* bias,
                        const float* res, int ldres, int act, float slope, void* stream) {
@@ -834,10 +852,8 @@ extern "C" int ag_gemm(const float* A, int lda, int ta, const float* B, int ldb,
   // they are combined with atomics.  Needs a linear epilogue.
   p.part = nullptr;
   if (tiles < 192 && K >= 1024 && act == AG_ACT_NONE) {
-    int ks = (int)(512 / tiles);
-    if (ks > K / 256) ks = K / 256;
-    if (ks > 32) ks = 32;
     const int64_t mn = (int64_t)M * N;
+    int ks = gemm_pick_ksplit(tiles, mn, K);
     const bool slabs = ws.p && ws.numel >= 2 * mn;
     if (slabs && (int64_t)ks * mn > ws.numel) ks = (int)(ws.numel / mn);
     if (ks >= 2 && (slabs || beta == 0.f || beta == 1.f)) {
@@ -888,11 +904,7 @@ extern "C" int64_t ag_gemm_ws_numel(int M, int N, int K, int act) {
   const bool use128 = M > 64 && N > 64 && (big >= 192 || K >= 2048);
   const int64_t tiles = use128 ? big : (int64_t)ag_cdiv(M, 64) * ag_cdiv(N, 64);
   if (!(tiles < 192 && K >= 1024 && act == AG_ACT_NONE)) return 0;
-  int ks = (int)(512 / tiles);
-  if (ks > K / 256) ks = K / 256;
-  if (ks > 32) ks = 32;
-  // cap the slab traffic (2 * ks * M * N * 4 B): beyond ~8 slices of a large output it costs more than it buys
-  while (ks > 2 && (int64_t)ks * M * N > ((int64_t)8 << 20)) --ks;
+  const int ks = gemm_pick_ksplit(tiles, (int64_t)M * N, K);
   return ks >= 2 ? (int64_t)ks * M * N : 0;
 }
 
