@@ -1041,3 +1041,253 @@ extern "C" int ag_grufront_fwd_persist(float* gates, float* gh, const float* w_x
   AG_CHECK_LAUNCH("ag_grufront_fwd_persist");
   return AG_OK;
 }
+
+// ------------------------------------------------------------------------------------------
+// Backward through time of the Generator's recurrent front (audiogan.py:428-460 under .backward() :903) as ONE
+// persistent launch.  Per frame t (T-1 .. 0), with dacc[t] = [dL/dh_t | dL/dx_t] (the stop head's and the conv trunk's
+// gradients, filled in by the host) as the external part:
+//   gx_t  = (dacc_x[t] + dgates_{t+1} W_x) * (1 - x_t^2)                       d(pre-tanh) of the projection
+//   dh_t  = dacc_h[t] + dgates_{t+1} W_hh + gx_t W_p
+//   dgates_t = cell backward(dh_t, dc_{t+1})
+// The launch-per-op path costs three launches per frame (fused cell step, a [B,4S] x [4S,S+fs] product that re-streams
+// its 21 MB of weights from the fabric, the second stage of its K split).  Here every weight stays in REGISTERS:
+//   workgroup (clip tile of 32, column tile of 16): one 16-column tile of [W_hh | W_x] = a [4S x 16] panel, K split
+//   over the 8 waves (128 VGPRs per lane at S = 1024); S/16 "h tiles" + fs/16 "x tiles" per clip tile.
+//   x tile, frame t: dx_t -> gx_t, published (write-through into dxt[t], which is also an output) + flag
+//   h tile, frame t: waits for gx_t -> gx_t W_p against its resident [fs x 16] W_p panel -> cell backward of its
+//                    (clip, unit) pairs (dc stays in a register) -> dgates_t published (into dgs[t]) + flag
+//   both, t > 0    : wait for all dgates_t of the clip tile -> [32 x 4S] x panel on v_mfma_f32_16x16x4_f32 -> LDS sum of
+//                    the 8 K slices -> the recurrent term of frame t-1, kept in a register.
+// Two hand-offs per frame; one slot per frame in dgs / dxt (no parity); flags count frames.
+// ------------------------------------------------------------------------------------------
+struct FrontBwdP {
+  const float* ga;     // [T,B,4S] activated gates (i, f, g, o)
+  const float* c_all;  // [T+1,B,S]
+  const float* x;      // [B,T*fs] the front's output (after tanh)
+  const float* dacc;   // [T,B,S+fs] external gradient [dL/dh_t | dL/dx_t]
+  const float* w_hh;   // [4S,S]
+  const float* w_x;    // [4S,ldwx]: W_ih[:, :fs]
+  const float* w_p;    // [fs,S]
+  float* dgs;          // [T,B,4S] out (and exchange)
+  float* dxt;          // [T,B,fs] out (and exchange)
+  PersistCtl ctl;
+  int T, B, ldwx;
+};
+
+template <int S, int FS, bool RB>
+__global__ __launch_bounds__(512) void gfront_persist_bwd_kernel(const FrontBwdP p) {
+  constexpr int K4 = 4 * S, NU = K4 / 128;                  // 16-k units of the big product per wave
+  constexpr int NHT = S / 16, NXT = FS / 16, NT = NHT + NXT;
+  constexpr int NP = FS >= 128 ? FS / 128 : 1;              // 16-k units of the projection product per wave
+  static_assert(NU * 128 == K4 && FS % 16 == 0 && S % 16 == 0, "shape");
+  __shared__ float red[8 * 512];
+  __shared__ int s_dead;
+  const int T = p.T, B = p.B;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  if (tid == 0) s_dead = 0;
+  __syncthreads();
+  const int bt = blockIdx.x / NT, ct = blockIdx.x % NT;
+  const bool isx = ct >= NHT;
+  const int m0 = bt * 32;
+  const int n0 = (isx ? ct - NHT : ct) * 16;                // first column inside W_hh / W_x
+  const int64_t BG = (int64_t)B * K4, BH = (int64_t)B * S, BX = (int64_t)B * FS, BA = (int64_t)B * (S + FS);
+
+  // resident panel: wreg[u][e] = W[(wid*NU + u)*16 + 4g + e][n0 + li]
+  float wreg[NU][4];
+  {
+    const float* W = isx ? p.w_x : p.w_hh;
+    const int ldw = isx ? p.ldwx : S;
+#pragma unroll
+    for (int u = 0; u < NU; ++u)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        wreg[u][e] = ag_rbf_if(W[(int64_t)((wid * NU + u) * 16 + 4 * g + e) * ldw + n0 + li], RB);
+  }
+  // h tiles: wp[u][e] = W_p[(wid*NP + u)*16 + 4g + e][n0 + li]
+  const bool pw_on = !isx && (wid * NP * 16 < FS);
+  float wp[NP][4];
+#pragma unroll
+  for (int u = 0; u < NP; ++u)
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      wp[u][e] = pw_on ? ag_rbf_if(p.w_p[(int64_t)((wid * NP + u) * 16 + 4 * g + e) * S + n0 + li], RB) : 0.f;
+
+  unsigned* flags_h = p.ctl.hdr + PS_FLAG_OFF + bt * NT;
+  unsigned* flags_x = flags_h + NHT;
+  unsigned* my_flag = flags_h + ct;
+  // epilogue role: thread <-> (clip row, column of the tile)
+  const int erow = tid >> 4, ecol = tid & 15;
+  const int em = m0 + erow;
+  const bool epi = em < B;
+  // A operand rows of this lane for the two 16-clip halves (clamped: rows past the batch feed only their own, unwritten outputs)
+  const int ar0 = min(m0 + li, B - 1), ar1 = min(m0 + 16 + li, B - 1);
+  float carry = 0.f, dcn = 0.f;
+  bool alive = true;
+
+  for (int t = T - 1; t >= 0; --t) {
+    const unsigned seq = (unsigned)(T - t);
+    if (isx) {
+      if (epi) {
+        const float dx = p.dacc[(int64_t)t * BA + (int64_t)em * (S + FS) + S + n0 + ecol] + carry;
+        const float xv = p.x[(int64_t)em * T * FS + (int64_t)t * FS + n0 + ecol];
+        float gx = dx * (1.f - xv * xv);
+        if (s_dead) gx = __builtin_nanf("");
+        __amdgpu_buffer_rsrc_t orr = __builtin_amdgcn_make_buffer_rsrc(p.dxt + (int64_t)t * BX, 0, (int)(BX * 4), 0x00020000);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(gx), orr, (unsigned)(((int64_t)em * FS + n0 + ecol) * 4), 0, 16);
+      }
+    } else {
+      float ig = 0.f, fg = 0.f, gg = 0.f, og = 0.f, cp = 0.f, cn = 0.f, ext = 0.f;
+      if (epi) {
+        const float* gr = p.ga + (int64_t)t * BG + (int64_t)em * K4 + n0 + ecol;
+        ig = gr[0]; fg = gr[S]; gg = gr[2 * S]; og = gr[3 * S];
+        cp = p.c_all[(int64_t)t * BH + (int64_t)em * S + n0 + ecol];
+        cn = p.c_all[(int64_t)(t + 1) * BH + (int64_t)em * S + n0 + ecol];
+        ext = p.dacc[(int64_t)t * BA + (int64_t)em * (S + FS) + n0 + ecol];
+      }
+      if (wid == 0 && alive) {
+        alive = ps_wait_flags(p.ctl, flags_x, NXT, seq, lane);
+        if (!alive) s_dead = 1;
+      }
+      __syncthreads();
+      // gx_t [32 clips, fs] x W_p panel
+      f32x4 pa[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+      if (pw_on) {
+        __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dxt) + (int64_t)t * BX, 0, (int)(BX * 4), 0x00020000);
+        u32x4 a[2][NP];
+#pragma unroll
+        for (int u = 0; u < NP; ++u) {
+          const unsigned ko = (unsigned)(((wid * NP + u) * 16 + 4 * g) * 4);
+          a[0][u] = __builtin_amdgcn_raw_buffer_load_b128(xr, (unsigned)(ar0 * FS * 4) + ko, 0, 16);
+          a[1][u] = __builtin_amdgcn_raw_buffer_load_b128(xr, (unsigned)(ar1 * FS * 4) + ko, 0, 16);
+        }
+#pragma unroll
+        for (int u = 0; u < NP; ++u)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+              pa[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(ag_rbf_if(__uint_as_float(a[r][u][e]), RB), wp[u][e], pa[r], 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) red[wid * 512 + (16 * r + 4 * g + e) * 16 + li] = pa[r][e];
+      __syncthreads();
+      if (epi) {
+        float dhv = ext + carry;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) dhv += red[w * 512 + tid];
+        const float tc = tanhf(cn);
+        const float dc = dcn + dhv * og * (1.f - tc * tc);
+        float d0 = dc * gg * ig * (1.f - ig);
+        float d1 = dc * cp * fg * (1.f - fg);
+        float d2 = dc * ig * (1.f - gg * gg);
+        float d3 = dhv * tc * og * (1.f - og);
+        dcn = dc * fg;
+        if (s_dead) { d0 = d1 = d2 = d3 = dcn = __builtin_nanf(""); }   // a wait timed out: poison instead of garbage
+        __amdgpu_buffer_rsrc_t orr = __builtin_amdgcn_make_buffer_rsrc(p.dgs + (int64_t)t * BG, 0, (int)(BG * 4), 0x00020000);
+        const unsigned o = (unsigned)(((int64_t)em * K4 + n0 + ecol) * 4);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(d0), orr, o, 0, 16);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(d1), orr, o + (unsigned)(S * 4), 0, 16);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(d2), orr, o + (unsigned)(2 * S * 4), 0, 16);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(d3), orr, o + (unsigned)(3 * S * 4), 0, 16);
+      }
+    }
+    if (t == 0 && !isx) break;                                // dgates_0 has no reader inside the launch
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // EVERY storing wave drains its write-through stores
+    __syncthreads();
+    if (tid == 0 && (int)blockIdx.x != p.ctl.mute)
+      __hip_atomic_store(my_flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t == 0) break;
+    // ---- the recurrent term of frame t-1: dgates_t [32 clips, 4S] x panel
+    if (wid == 0 && alive) {
+      alive = ps_wait_flags(p.ctl, flags_h, NHT, seq, lane);
+      if (!alive) s_dead = 1;
+    }
+    __syncthreads();
+    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    {
+      __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc(p.dgs + (int64_t)t * BG, 0, (int)(BG * 4), 0x00020000);
+      const unsigned o0 = (unsigned)(((int64_t)ar0 * K4 + wid * NU * 16 + 4 * g) * 4);
+      const unsigned o1 = (unsigned)(((int64_t)ar1 * K4 + wid * NU * 16 + 4 * g) * 4);
+      constexpr int UB = NU < 4 ? NU : 4;
+#pragma unroll
+      for (int ub = 0; ub < NU; ub += UB) {
+        u32x4 a[2][UB];
+#pragma unroll
+        for (int i = 0; i < UB; ++i) {
+          a[0][i] = __builtin_amdgcn_raw_buffer_load_b128(gr, o0 + (unsigned)((ub + i) * 64), 0, 16);
+          a[1][i] = __builtin_amdgcn_raw_buffer_load_b128(gr, o1 + (unsigned)((ub + i) * 64), 0, 16);
+        }
+#pragma unroll
+        for (int i = 0; i < UB; ++i)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+              acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(ag_rbf_if(__uint_as_float(a[r][i][e]), RB), wreg[ub + i][e], acc[r], 0, 0, 0);
+      }
+    }
+    // C layout of a 16x16 tile: col = lane & 15, row = 4 * (lane >> 4) + e
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) red[wid * 512 + (16 * r + 4 * g + e) * 16 + li] = acc[r][e];
+    __syncthreads();
+    carry = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) carry += red[w * 512 + tid];
+    __syncthreads();                                          // red is written again in the next frame
+  }
+}
+
+static bool front_bwd_shape_ok(int B, int S, int fs, int n_cu) {
+  if (!((S == 1024 && fs == 256) || (S == 128 && fs == 64))) return false;
+  if (B < 1) return false;
+  if (n_cu > 256) n_cu = 256;
+  const int64_t grid = (int64_t)ag_cdiv(B, 32) * ((S + fs) / 16);
+  return grid <= n_cu && grid <= (PS_HDR_BYTES / 4 - PS_FLAG_OFF);
+}
+
+extern "C" int ag_gfront_bwd_persist_ok(int B, int S, int fs, int n_cu) { return front_bwd_shape_ok(B, S, fs, n_cu) ? 1 : 0; }
+
+// The frame loop of the Generator front's backward in ONE launch.  ga [T,B,4S] activated gates and c_all [T+1,B,S] as
+// saved by the forward, x [B,T*fs] the front's output, dacc [T,B,S+fs] the external gradient [dL/dh_t | dL/dx_t] (read
+// only), w_hh [4S,S], w_x = W_ih[:, :fs] (row pitch ldwx), w_p [fs,S]; outputs dgs [T,B,4S] (d gate pre-activations) and
+// dxt [T,B,fs] (d pre-tanh of the projection).  `ws`: >= PS_STICKY_BYTES + 8 KiB (status + flags).
+extern "C" int ag_gfront_bwd_persist(const float* ga, const float* c_all, const float* x, const float* dacc,
+                                     const float* w_hh, const float* w_x, int ldwx, const float* w_p, float* dgs,
+                                     float* dxt, void* ws, int64_t ws_bytes, int T, int B, int S, int fs, int n_cu,
+                                     void* stream) {
+  AG_REQUIRE(ga && c_all && x && dacc && w_hh && w_x && w_p && dgs && dxt && ws, "ag_gfront_bwd_persist: null tensor");
+  AG_REQUIRE(T > 0, "ag_gfront_bwd_persist: T must be positive");
+  if (!front_bwd_shape_ok(B, S, fs, n_cu)) {
+    ag_set_error("ag_gfront_bwd_persist: shape B=%d S=%d fs=%d is not supported on %d CUs", B, S, fs, n_cu);
+    return AG_ERR_UNSUPPORTED;
+  }
+  AG_REQUIRE(ws_bytes >= PS_STICKY_BYTES + PS_HDR_BYTES && ((uintptr_t)ws & 15) == 0, "ag_gfront_bwd_persist: workspace too small");
+  AG_REQUIRE(ldwx >= fs, "ag_gfront_bwd_persist: bad row pitch");
+  AG_REQUIRE((int64_t)B * 4 * S * 4 < ((int64_t)1 << 31), "ag_gfront_bwd_persist: frame slab too large");
+  AG_REQUIRE((((uintptr_t)dgs | (uintptr_t)dxt) & 15) == 0, "ag_gfront_bwd_persist: outputs must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync((char*)ws + PS_STICKY_BYTES, 0, PS_HDR_BYTES, st) != hipSuccess) {
+    ag_set_error("ag_gfront_bwd_persist: memset failed");
+    return AG_ERR_LAUNCH;
+  }
+  FrontBwdP p;
+  p.ga = ga; p.c_all = c_all; p.x = x; p.dacc = dacc; p.w_hh = w_hh; p.w_x = w_x; p.w_p = w_p; p.dgs = dgs; p.dxt = dxt;
+  p.ctl = ps_ctl(ws);
+  p.T = T; p.B = B; p.ldwx = ldwx;
+  const bool rb = ag_precision() == AG_PREC_BF16;
+  const int grid = ag_cdiv(B, 32) * ((S + fs) / 16);
+  if (S == 1024) {
+    if (rb) hipLaunchKernelGGL((gfront_persist_bwd_kernel<1024, 256, true>), dim3(grid), dim3(512), 0, st, p);
+    else hipLaunchKernelGGL((gfront_persist_bwd_kernel<1024, 256, false>), dim3(grid), dim3(512), 0, st, p);
+  } else {
+    if (rb) hipLaunchKernelGGL((gfront_persist_bwd_kernel<128, 64, true>), dim3(grid), dim3(512), 0, st, p);
+    else hipLaunchKernelGGL((gfront_persist_bwd_kernel<128, 64, false>), dim3(grid), dim3(512), 0, st, p);
+  }
+  AG_CHECK_LAUNCH("ag_gfront_bwd_persist");
+  return AG_OK;
+}

@@ -844,6 +844,29 @@ def gfront_fwd_persist(gates, wx, whh, wp, bp, hs, cs, x):
           'ag_gfront_fwd_persist')
 
 
+def gfront_bwd_persist_ok(B, S, fs, dev):
+    return bool(PERSIST[0] and torch.device(dev).type == 'cuda' and lib.ag_gfront_bwd_persist_ok(B, S, fs, _n_cu(dev)))
+
+
+def gfront_bwd_persist(gates, cs, x, dacc, whh, wx, wp, dgs, dxt):
+    """the backward through time of the Generator front's frame loop in ONE persistent launch (ag_gfront_bwd_persist);
+    dacc [T,B,S+fs] = the external gradient [dL/dh_t | dL/dx_t], read only"""
+    T, B, S4 = gates.shape
+    S = S4 // 4
+    fs = wp.size(0)
+    for t_, n, shp in ((gates, 'gates', (T, B, 4 * S)), (cs, 'cs', (T + 1, B, S)), (x, 'x', (B, T * fs)),
+                       (dacc, 'dacc', (T, B, S + fs)), (whh, 'whh', (4 * S, S)), (wp, 'wp', (fs, S)),
+                       (dgs, 'dgs', (T, B, 4 * S)), (dxt, 'dxt', (T, B, fs))):
+        _chk(t_, n)
+        assert t_.is_contiguous() and tuple(t_.shape) == shp, (n, tuple(t_.shape), shp)
+    _chk(wx, 'wx')
+    assert tuple(wx.shape) == (4 * S, fs) and wx.stride(1) == 1
+    ws = _persist_workspace(x.device, _PERSIST_WS_MIN)
+    check(lib.ag_gfront_bwd_persist(_p(gates), _p(cs), _p(x), _p(dacc), _p(whh), _p(wx), wx.stride(0), _p(wp), _p(dgs),
+                                    _p(dxt), _p(ws), ws.numel(), T, B, S, fs, _n_cu(x.device), _stream()),
+          'ag_gfront_bwd_persist')
+
+
 def grufront_fwd_persist(gates, gh, wx, whh, bhn, wp, bp, hs, x):
     """the GRU-front generator's frame loop in ONE persistent launch (ag_grufront_fwd_persist); hs: [T,B,S] (h_t)"""
     T, B, S3 = gates.shape
@@ -874,6 +897,13 @@ def _work_gfront(gates, wx, whh, wp, *a_, **kw):
     S, fs = S4 // 4, wp.size(0)
     return 'gfront_persist_fwd_kernel' + _bf16_tag(), T * 2.0 * B * (S4 * (S + fs) + fs * S), \
         4.0 * (S4 * (S + fs) + fs * S + T * B * (2 * S4 + 2 * S + fs)), 1
+
+
+def _work_gfront_bwd(gates, cs, x, dacc, whh, wx, wp, *a_, **kw):
+    T, B, S4 = gates.shape
+    S, fs = S4 // 4, wp.size(0)
+    return 'gfront_persist_bwd_kernel' + _bf16_tag(), 2.0 * B * ((T - 1) * S4 * (S + fs) + T * fs * S), \
+        4.0 * (S4 * (S + fs) + fs * S + T * B * (2 * S4 + 2 * S + (S + fs) + 2 * fs)), 1
 
 
 def lstm_persist_bwd_ok(B, H, ndir, dev):
@@ -998,7 +1028,7 @@ def _work_seq_bwd_cell(gates, whh, *a_, **kw):
 
 for _n, _w in (('skinny_gemm', _work_skinny), ('lstm_step_fwd', _work_step),
                ('_lstm_seq_fwd_range', _work_seq_fwd), ('_lstm_seq_fwd_persist_call', _work_seq_fwd_persist),
-               ('_lstm_seq_bwd_persist_call', _work_seq_bwd_persist), ('gfront_fwd_persist', _work_gfront),
+               ('_lstm_seq_bwd_persist_call', _work_seq_bwd_persist), ('gfront_fwd_persist', _work_gfront), ('gfront_bwd_persist', _work_gfront_bwd),
                ('grufront_fwd_persist', _work_grufront), ('_lstm_seq_bwd_prod', _work_seq_bwd_prod),
                ('_lstm_seq_bwd_cell', _work_seq_bwd_cell), ('_lstm_seq_bwd_step', _work_seq_bwd_step)):
     _instrument(_n, _w)

@@ -289,9 +289,10 @@ class GFrontFn(torch.autograd.Function):
 
     @staticmethod
     def _bwd_frames_fused(T, B, fs, S, x, dx, ds, gates, cs, w_hh, wx, pw, sw, hs, dws, nl):
-        """single-layer front: TWO launches per frame.  dacc[t] = [dL/dh_t | dL/dx_t] lives in one [B, S+fs]
-        row so that  dacc[t-1] += dgates_t @ [W_hh | W_ih[:, :fs]]  is ONE product, and the tanh backward of the
-        projection, its product and the cell backward are one fused step (ag_lstm_front_bwd_step)."""
+        """single-layer front: ONE persistent launch where the shape fits (ag_gfront_bwd_persist), else TWO launches per
+        frame: dacc[t] = [dL/dh_t | dL/dx_t] lives in one [B, S+fs] row so that  dacc[t-1] += dgates_t @ [W_hh |
+        W_ih[:, :fs]]  is ONE product, and the tanh backward of the projection, its product and the cell backward are one
+        fused step (ag_lstm_front_bwd_step)."""
         dev = x.device
         dacc = torch.zeros(T, B, S + fs, device=dev)
         if dx is not None:
@@ -302,9 +303,13 @@ class GFrontFn(torch.autograd.Function):
                 K.gemm(ds_tb, hs.view(T * B, S), dws[4 * nl + 2], ta=True)
                 K.col_sum(ds_tb, dws[4 * nl + 3])
             K.gemm(ds_tb, sw, dacc.view(T * B, S + fs)[:, :S])
-        wcat = torch.cat([w_hh, wx], 1)                # [4S, S+fs]
         dgs = torch.empty(T, B, 4 * S, device=dev)
         dxt = torch.empty(T, B, fs, device=dev)
+        if K.gfront_bwd_persist_ok(B, S, fs, dev) and wx.stride(1) == 1:
+            # the whole loop in ONE launch, [W_hh | W_x] and W_p resident in registers (ag_gfront_bwd_persist)
+            K.gfront_bwd_persist(gates, cs, x, dacc, w_hh, wx, pw, dgs, dxt)
+            return [dgs], dxt
+        wcat = torch.cat([w_hh, wx], 1)                # [4S, S+fs]
         dcs = [torch.empty(B, S, device=dev), torch.empty(B, S, device=dev)]
         for t in reversed(range(T)):
             K.lstm_front_bwd_step(dacc[t, :, S:], x[:, t * fs:(t + 1) * fs], dxt[t], pw, dacc[t, :, :S], gates[t], cs[t],

@@ -327,6 +327,18 @@ int ag_gfront_fwd_persist(float* gates, const float* w_x, int ldwx, const float*
                           const float* b_p, float* hs, float* cs, float* x, void* ws, int64_t ws_bytes, int T, int B,
                           int S, int fs, int n_cu, void* stream);
 
+/* The frame loop of the Generator front's BACKWARD through time (audiogan.py:437-443 under .backward() :903) in one
+ * persistent launch: per frame gx_t = (dacc_x[t] + dgates_{t+1} W_x)(1 - x_t^2), dh_t = dacc_h[t] + dgates_{t+1} W_hh +
+ * gx_t W_p, dgates_t = cell backward.  ga [T,B,4S] activated gates and c_all [T+1,B,S] as saved by ag_gfront_fwd_persist,
+ * x [B,T*fs], dacc [T,B,S+fs] the external gradient [dL/dh_t | dL/dx_t] (read only), w_hh [4S,S], w_x = W_ih[:, :fs] (row
+ * pitch ldwx), w_p [fs,S]; outputs dgs [T,B,4S] and dxt [T,B,fs] (d pre-tanh of the projection), which the weight-gradient
+ * GEMMs over all frames read.  Supported: (S, fs) as above and ceil(B/32) * (S+fs)/16 <= n_cu (ag_gfront_bwd_persist_ok);
+ * `ws`: the sticky word + 8 KiB header (see ag_lstm_seq_fwd_persist). */
+int ag_gfront_bwd_persist_ok(int B, int S, int fs, int n_cu);
+int ag_gfront_bwd_persist(const float* ga, const float* c_all, const float* x, const float* dacc, const float* w_hh,
+                          const float* w_x, int ldwx, const float* w_p, float* dgs, float* dxt, void* ws,
+                          int64_t ws_bytes, int T, int B, int S, int fs, int n_cu, void* stream);
+
 /* The same frame loop with a GRU cell (BASELINE configs[3]: the audiogan.py Generator with the LSTMCell of :380-386 replaced
  * by a GRU cell, gate order r z n as torch.nn.GRUCell) as ONE persistent launch.  gates [T,B,3S]: in = W_ih[:, fs:] zc_t +
  * b_ih + (b_hr, b_hz, 0), out = activated (r, z, n); gh [T,B,3S]: only its n slot is written (W_hn h_{t-1} + b_hn, what

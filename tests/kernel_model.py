@@ -332,6 +332,11 @@ def gfront_persist_ok(B, S, fs, dev):
     return False
 
 
+def gfront_bwd_persist_ok(B, S, fs, dev):
+    """(likewise for its backward)"""
+    return False
+
+
 # ---- skinny products / fused recurrent steps (same contracts as lstm_step.hip) -----------------
 def skinny_ok(A, B, tb):
     M, Kd = A.shape

@@ -534,7 +534,7 @@ def test_time_moments(K, B, C, L):
     assert not dhd[:, 0].any() and not dhd[:, C + 1:].any()
 
 
-@pytest.mark.parametrize('S,fs,B,T', [(128, 64, 5, 3), (128, 64, 40, 6), (128, 64, 64, 2), (1024, 256, 64, 4), (1024, 256, 33, 3)])
+@pytest.mark.parametrize('S,fs,B,T', [(128, 64, 7, 1), (128, 64, 5, 3), (128, 64, 40, 6), (128, 64, 64, 2), (1024, 256, 64, 4), (1024, 256, 33, 3)])
 def test_gfront_persistent_launch(K, S, fs, B, T):
     """the Generator front's frame loop as ONE persistent launch (lstm_persist.hip) vs one launch per operation: frames,
     stop logits and every gradient (the backward runs on the saved gates / cells / hidden states of either forward)"""
@@ -624,7 +624,7 @@ def test_persistent_workspace_is_never_freed(K):
     assert K._persist_workspace(dev, 1024) is b
 
 
-@pytest.mark.parametrize('S,fs,B,T', [(128, 64, 5, 3), (128, 64, 40, 6), (1024, 256, 64, 4), (1024, 256, 33, 3)])
+@pytest.mark.parametrize('S,fs,B,T', [(128, 64, 7, 1), (128, 64, 5, 3), (128, 64, 40, 6), (1024, 256, 64, 4), (1024, 256, 33, 3)])
 def test_grufront_persistent_launch(K, S, fs, B, T):
     """the GRU-front generator's frame loop (BASELINE configs[3]) as ONE persistent launch vs one launch per operation:
     frames, stop logits and every gradient (the backward runs on the saved gates / hidden states of either forward)"""
