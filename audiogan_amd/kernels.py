@@ -844,8 +844,29 @@ def gfront_fwd_persist(gates, wx, whh, wp, bp, hs, cs, x):
           'ag_gfront_fwd_persist')
 
 
+# the front's backward runs beside the conv trunk's gradient all-reduce in the multi-GPU step (train.GraphedStep, phase
+# g3b; eager: the bucket's hook): a persistent launch wants its CUs to itself, so a generator whose optimiser carries a
+# gradient bucket runs its backward with this switch off (train.g_step / g_backward / GraphedStep)
+PERSIST_FRONT_BWD = [True]
+
+
+class front_bwd_persist(object):
+    """``with K.front_bwd_persist(on): loss.backward()`` - `on` False: the front's backward takes the per-frame form"""
+
+    def __init__(self, on):
+        self.on = bool(on)
+
+    def __enter__(self):
+        self.old = PERSIST_FRONT_BWD[0]
+        PERSIST_FRONT_BWD[0] = self.old and self.on
+
+    def __exit__(self, *exc):
+        PERSIST_FRONT_BWD[0] = self.old
+
+
 def gfront_bwd_persist_ok(B, S, fs, dev):
-    return bool(PERSIST[0] and torch.device(dev).type == 'cuda' and lib.ag_gfront_bwd_persist_ok(B, S, fs, _n_cu(dev)))
+    return bool(PERSIST[0] and PERSIST_FRONT_BWD[0] and torch.device(dev).type == 'cuda'
+                and lib.ag_gfront_bwd_persist_ok(B, S, fs, _n_cu(dev)))
 
 
 def gfront_bwd_persist(gates, cs, x, dacc, whh, wx, wp, dgs, dxt):

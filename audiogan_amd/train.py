@@ -3,6 +3,7 @@
 numbers can be fed to the CPU oracle."""
 import torch
 
+from . import kernels as K
 from .common import frozen
 from .extras import adversarial_movement_d, adversarially_sample_z, calc_dists, feature_penalty
 from .losses import length_mask, masked_bce_mean, only_stopper_trains, stopper_surrogate_loss
@@ -39,6 +40,12 @@ def gd_step(g, d, opt_g, opt_d, real, real_len, c, z, noise_real, noise_fake, dg
         torch.cuda.current_stream().wait_stream(side)
     loss_g = g_step(g, d, opt_g, c, z, noise_fake, ggradclip, grad_hook=hook_g, check=check, pre=pre)[0]
     return loss_d, loss_g
+
+
+def _single_gpu(opt):
+    """no gradient bucket on the optimiser = no collective can run beside this network's backward: the recurrent front's
+    backward may then be a persistent launch (kernels.PERSIST_FRONT_BWD)"""
+    return getattr(opt, 'bucket', None) is None
 
 
 def d_step(g, d, opt_d, real, real_len, c, z, noise_real, noise_fake, dgradclip=1.0, stop='never',
@@ -80,7 +87,8 @@ def g_step(g, d, opt_g, c, z, noise_fake, ggradclip=0.1, g_optim='boundary_seeki
         tgt = 0.5 if g_optim == 'boundary_seeking' else 0.0
         loss, _ = masked_bce_mean(cls_g, tgt, nf_g)
         opt_g.zero_grad()
-        loss.backward()
+        with K.front_bwd_persist(_single_gpu(opt_g)):
+            loss.backward()
     scale = grad_hook() if grad_hook is not None else 1.0
     opt_g.step(clip_norm=ggradclip, grad_scale=scale, check=check)
     return loss.detach(), fake.detach(), cls_g.detach()
@@ -121,7 +129,8 @@ def g_backward(g, d, opt_g, c, z, noise_fake, g_optim='boundary_seeking', stop='
         cls_g, _, _, nf_g = d(fake + noise_fake, fake_len, c)
         loss, _ = masked_bce_mean(cls_g, 0.5 if g_optim == 'boundary_seeking' else 0.0, nf_g)
         opt_g.zero_grad()
-        loss.backward()
+        with K.front_bwd_persist(_single_gpu(opt_g)):
+            loss.backward()
     return loss.detach()
 
 
@@ -369,7 +378,10 @@ class GraphedStep(object):
                 g1b = capture(lambda: d_backward_late(keep))
                 g2 = capture(lambda: opt_d.step(clip_norm=dgradclip, grad_scale=scale))
                 g3a = capture(gen_early)
-                g3b = capture(lambda: g_backward_late(gkeep))
+                # g3b runs beside the all-reduce of the trunk's gradients: no persistent launch in it (a collective's
+                # kernels hold CUs for as long as their peers need; the per-frame form shares the chip with them)
+                with K.front_bwd_persist(self.bg is None):
+                    g3b = capture(lambda: g_backward_late(gkeep))
                 g4 = capture(lambda: opt_g.step(clip_norm=ggradclip, grad_scale=scale))
                 self.phases = (g1a, g1b, g2, g3a, g3b, g4)
             torch.cuda.synchronize()
