@@ -93,6 +93,7 @@ SIGNATURES = {
     'ag_gfront_persist_ws_bytes': (i64, [C.c_int] * 3),
     'ag_gfront_bwd_persist_ok': (C.c_int, [C.c_int] * 4),
     'ag_gfront_bwd_persist': (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, vp, vp, vp, vp, i64] + [C.c_int] * 5 + [vp]),
+    'ag_grufront_bwd_persist': (C.c_int, [vp, vp, vp, vp, vp, vp, vp, C.c_int, vp, vp, vp, vp, vp, i64] + [C.c_int] * 5 + [vp]),
     'ag_gfront_fwd_persist': (C.c_int, [vp, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, i64] + [C.c_int] * 5 + [vp]),
     'ag_grufront_fwd_persist': (C.c_int, [vp, vp, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, i64] + [C.c_int] * 5 + [vp]),
     'ag_convlstm_peephole_fwd': (C.c_int, [vp] * 8 + [C.c_int] * 4 + [vp]),
@@ -129,7 +130,7 @@ def _load():
     return lib
 
 
-ABI_VERSION = 4      # what this package was written against (csrc/api.hip: ag_abi_version)
+ABI_VERSION = 5      # what this package was written against (csrc/api.hip: ag_abi_version)
 
 lib = _load()
 if lib.ag_abi_version() != ABI_VERSION:

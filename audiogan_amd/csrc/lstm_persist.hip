@@ -1070,13 +1070,19 @@ struct FrontBwdP {
   const float* w_p;    // [fs,S]
   float* dgs;          // [T,B,4S] out (and exchange)
   float* dxt;          // [T,B,fs] out (and exchange)
+  // GRU cell (CELL = 1): ga = activated (r, z, n) [T,B,3S], c_all = hs [T+1,B,S] (hs[t] = h_{t-1}), gh [T,B,3S] (its n
+  // slot: W_hn h_{t-1} + b_hn); dgs = dgi [T,B,3S] (what the x tiles multiply by W_x), dgh [T,B,3S] (what the h tiles
+  // multiply by W_hh: the n slot times r).  LSTM: gh unused, dgh = dgs.
+  const float* gh;
+  float* dgh;
   PersistCtl ctl;
   int T, B, ldwx;
 };
 
-template <int S, int FS, bool RB>
+template <int S, int FS, bool RB, int CELL = 0>
 __global__ __launch_bounds__(512) void gfront_persist_bwd_kernel(const FrontBwdP p) {
-  constexpr int K4 = 4 * S, NU = K4 / 128;                  // 16-k units of the big product per wave
+  constexpr int NG = CELL == 1 ? 3 : 4;                     // gate blocks
+  constexpr int K4 = NG * S, NU = K4 / 128;                 // 16-k units of the big product per wave
   constexpr int NHT = S / 16, NXT = FS / 16, NT = NHT + NXT;
   constexpr int NP = FS >= 128 ? FS / 128 : 1;              // 16-k units of the projection product per wave
   static_assert(NU * 128 == K4 && FS % 16 == 0 && S % 16 == 0, "shape");
@@ -1122,7 +1128,7 @@ __global__ __launch_bounds__(512) void gfront_persist_bwd_kernel(const FrontBwdP
   const bool epi = em < B;
   // A operand rows of this lane for the two 16-clip halves (clamped: rows past the batch feed only their own, unwritten outputs)
   const int ar0 = min(m0 + li, B - 1), ar1 = min(m0 + 16 + li, B - 1);
-  float carry = 0.f, dcn = 0.f;
+  float carry = 0.f, dcn = 0.f, direct = 0.f;
   bool alive = true;
 
   for (int t = T - 1; t >= 0; --t) {
@@ -1140,9 +1146,14 @@ __global__ __launch_bounds__(512) void gfront_persist_bwd_kernel(const FrontBwdP
       float ig = 0.f, fg = 0.f, gg = 0.f, og = 0.f, cp = 0.f, cn = 0.f, ext = 0.f;
       if (epi) {
         const float* gr = p.ga + (int64_t)t * BG + (int64_t)em * K4 + n0 + ecol;
-        ig = gr[0]; fg = gr[S]; gg = gr[2 * S]; og = gr[3 * S];
-        cp = p.c_all[(int64_t)t * BH + (int64_t)em * S + n0 + ecol];
-        cn = p.c_all[(int64_t)(t + 1) * BH + (int64_t)em * S + n0 + ecol];
+        ig = gr[0]; fg = gr[S]; gg = gr[2 * S];            // LSTM: i, f, g (, o)   GRU: r, z, n
+        cp = p.c_all[(int64_t)t * BH + (int64_t)em * S + n0 + ecol];              // c_{t-1}  /  h_{t-1}
+        if (CELL == 1) {
+          og = p.gh[(int64_t)t * BG + (int64_t)em * K4 + 2 * S + n0 + ecol];      // W_hn h_{t-1} + b_hn
+        } else {
+          og = gr[3 * S];
+          cn = p.c_all[(int64_t)(t + 1) * BH + (int64_t)em * S + n0 + ecol];
+        }
         ext = p.dacc[(int64_t)t * BA + (int64_t)em * (S + FS) + n0 + ecol];
       }
       if (wid == 0 && alive) {
@@ -1178,20 +1189,37 @@ __global__ __launch_bounds__(512) void gfront_persist_bwd_kernel(const FrontBwdP
         float dhv = ext + carry;
 #pragma unroll
         for (int w = 0; w < 8; ++w) dhv += red[w * 512 + tid];
-        const float tc = tanhf(cn);
-        const float dc = dcn + dhv * og * (1.f - tc * tc);
-        float d0 = dc * gg * ig * (1.f - ig);
-        float d1 = dc * cp * fg * (1.f - fg);
-        float d2 = dc * ig * (1.f - gg * gg);
-        float d3 = dhv * tc * og * (1.f - og);
-        dcn = dc * fg;
-        if (s_dead) { d0 = d1 = d2 = d3 = dcn = __builtin_nanf(""); }   // a wait timed out: poison instead of garbage
         __amdgpu_buffer_rsrc_t orr = __builtin_amdgcn_make_buffer_rsrc(p.dgs + (int64_t)t * BG, 0, (int)(BG * 4), 0x00020000);
         const unsigned o = (unsigned)(((int64_t)em * K4 + n0 + ecol) * 4);
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(d0), orr, o, 0, 16);
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(d1), orr, o + (unsigned)(S * 4), 0, 16);
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(d2), orr, o + (unsigned)(2 * S * 4), 0, 16);
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(d3), orr, o + (unsigned)(3 * S * 4), 0, 16);
+        if (CELL == 1) {
+          // torch.nn.GRUCell backward: r = ig, z = fg, n = gg, hn = og, h_{t-1} = cp
+          float dn = dhv * (1.f - fg) * (1.f - gg * gg);
+          float dz = dhv * (cp - gg) * fg * (1.f - fg);
+          float dr = dn * og * ig * (1.f - ig);
+          float dnr = dn * ig;
+          direct = dhv * fg;                                  // the direct path dh * z, added to frame t-1's dh
+          if (s_dead) { dn = dz = dr = dnr = direct = __builtin_nanf(""); }
+          __amdgpu_buffer_rsrc_t hrr = __builtin_amdgcn_make_buffer_rsrc(p.dgh + (int64_t)t * BG, 0, (int)(BG * 4), 0x00020000);
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dr), orr, o, 0, 16);
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dz), orr, o + (unsigned)(S * 4), 0, 16);
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dn), orr, o + (unsigned)(2 * S * 4), 0, 16);
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dr), hrr, o, 0, 16);
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dz), hrr, o + (unsigned)(S * 4), 0, 16);
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dnr), hrr, o + (unsigned)(2 * S * 4), 0, 16);
+        } else {
+          const float tc = tanhf(cn);
+          const float dc = dcn + dhv * og * (1.f - tc * tc);
+          float d0 = dc * gg * ig * (1.f - ig);
+          float d1 = dc * cp * fg * (1.f - fg);
+          float d2 = dc * ig * (1.f - gg * gg);
+          float d3 = dhv * tc * og * (1.f - og);
+          dcn = dc * fg;
+          if (s_dead) { d0 = d1 = d2 = d3 = dcn = __builtin_nanf(""); }   // a wait timed out: poison instead of garbage
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(d0), orr, o, 0, 16);
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(d1), orr, o + (unsigned)(S * 4), 0, 16);
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(d2), orr, o + (unsigned)(2 * S * 4), 0, 16);
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(d3), orr, o + (unsigned)(3 * S * 4), 0, 16);
+        }
       }
     }
     if (t == 0 && !isx) break;                                // dgates_0 has no reader inside the launch
@@ -1208,7 +1236,7 @@ __global__ __launch_bounds__(512) void gfront_persist_bwd_kernel(const FrontBwdP
     __syncthreads();
     f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
     {
-      __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc(p.dgs + (int64_t)t * BG, 0, (int)(BG * 4), 0x00020000);
+      __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc((isx ? p.dgs : p.dgh) + (int64_t)t * BG, 0, (int)(BG * 4), 0x00020000);
       const unsigned o0 = (unsigned)(((int64_t)ar0 * K4 + wid * NU * 16 + 4 * g) * 4);
       const unsigned o1 = (unsigned)(((int64_t)ar1 * K4 + wid * NU * 16 + 4 * g) * 4);
       constexpr int UB = NU < 4 ? NU : 4;
@@ -1235,7 +1263,7 @@ __global__ __launch_bounds__(512) void gfront_persist_bwd_kernel(const FrontBwdP
 #pragma unroll
       for (int e = 0; e < 4; ++e) red[wid * 512 + (16 * r + 4 * g + e) * 16 + li] = acc[r][e];
     __syncthreads();
-    carry = 0.f;
+    carry = direct;                                           // (GRU h tiles: dh_t * z_t; otherwise 0)
 #pragma unroll
     for (int w = 0; w < 8; ++w) carry += red[w * 512 + tid];
     __syncthreads();                                          // red is written again in the next frame
@@ -1256,10 +1284,33 @@ extern "C" int ag_gfront_bwd_persist_ok(int B, int S, int fs, int n_cu) { return
 // saved by the forward, x [B,T*fs] the front's output, dacc [T,B,S+fs] the external gradient [dL/dh_t | dL/dx_t] (read
 // only), w_hh [4S,S], w_x = W_ih[:, :fs] (row pitch ldwx), w_p [fs,S]; outputs dgs [T,B,4S] (d gate pre-activations) and
 // dxt [T,B,fs] (d pre-tanh of the projection).  `ws`: >= PS_STICKY_BYTES + 8 KiB (status + flags).
+static int front_bwd_launch(int cell, const float* ga, const float* c_all, const float* gh, const float* x, const float* dacc,
+                            const float* w_hh, const float* w_x, int ldwx, const float* w_p, float* dgs, float* dgh,
+                            float* dxt, void* ws, int64_t ws_bytes, int T, int B, int S, int fs, int n_cu, void* stream);
+
 extern "C" int ag_gfront_bwd_persist(const float* ga, const float* c_all, const float* x, const float* dacc,
                                      const float* w_hh, const float* w_x, int ldwx, const float* w_p, float* dgs,
                                      float* dxt, void* ws, int64_t ws_bytes, int T, int B, int S, int fs, int n_cu,
                                      void* stream) {
+  return front_bwd_launch(0, ga, c_all, nullptr, x, dacc, w_hh, w_x, ldwx, w_p, dgs, dgs, dxt, ws, ws_bytes, T, B, S, fs,
+                          n_cu, stream);
+}
+
+// The same for the GRU front (BASELINE configs[3]; torch.nn.GRUCell, gate order r z n): ga [T,B,3S] activated gates, hs
+// [T+1,B,S] (hs[t] = h_{t-1}, hs[0] = 0) and gh [T,B,3S] (n slot) as saved by ag_grufront_fwd_persist; outputs dgi
+// [T,B,3S] (d of the input-side pre-activations), dgh [T,B,3S] (hidden side: the n slot times r) and dxt [T,B,fs].
+extern "C" int ag_grufront_bwd_persist(const float* ga, const float* hs, const float* gh, const float* x,
+                                       const float* dacc, const float* w_hh, const float* w_x, int ldwx,
+                                       const float* w_p, float* dgi, float* dgh, float* dxt, void* ws, int64_t ws_bytes,
+                                       int T, int B, int S, int fs, int n_cu, void* stream) {
+  AG_REQUIRE(gh && dgh, "ag_grufront_bwd_persist: null tensor");
+  return front_bwd_launch(1, ga, hs, gh, x, dacc, w_hh, w_x, ldwx, w_p, dgi, dgh, dxt, ws, ws_bytes, T, B, S, fs, n_cu,
+                          stream);
+}
+
+static int front_bwd_launch(int cell, const float* ga, const float* c_all, const float* gh, const float* x, const float* dacc,
+                            const float* w_hh, const float* w_x, int ldwx, const float* w_p, float* dgs, float* dgh,
+                            float* dxt, void* ws, int64_t ws_bytes, int T, int B, int S, int fs, int n_cu, void* stream) {
   AG_REQUIRE(ga && c_all && x && dacc && w_hh && w_x && w_p && dgs && dxt && ws, "ag_gfront_bwd_persist: null tensor");
   AG_REQUIRE(T > 0, "ag_gfront_bwd_persist: T must be positive");
   if (!front_bwd_shape_ok(B, S, fs, n_cu)) {
@@ -1277,17 +1328,19 @@ extern "C" int ag_gfront_bwd_persist(const float* ga, const float* c_all, const 
   }
   FrontBwdP p;
   p.ga = ga; p.c_all = c_all; p.x = x; p.dacc = dacc; p.w_hh = w_hh; p.w_x = w_x; p.w_p = w_p; p.dgs = dgs; p.dxt = dxt;
+  p.gh = gh; p.dgh = dgh;
   p.ctl = ps_ctl(ws);
   p.T = T; p.B = B; p.ldwx = ldwx;
   const bool rb = ag_precision() == AG_PREC_BF16;
   const int grid = ag_cdiv(B, 32) * ((S + fs) / 16);
-  if (S == 1024) {
-    if (rb) hipLaunchKernelGGL((gfront_persist_bwd_kernel<1024, 256, true>), dim3(grid), dim3(512), 0, st, p);
-    else hipLaunchKernelGGL((gfront_persist_bwd_kernel<1024, 256, false>), dim3(grid), dim3(512), 0, st, p);
-  } else {
-    if (rb) hipLaunchKernelGGL((gfront_persist_bwd_kernel<128, 64, true>), dim3(grid), dim3(512), 0, st, p);
-    else hipLaunchKernelGGL((gfront_persist_bwd_kernel<128, 64, false>), dim3(grid), dim3(512), 0, st, p);
-  }
+  void (*kern)(const FrontBwdP);
+  if (cell == 0)
+    kern = S == 1024 ? (rb ? gfront_persist_bwd_kernel<1024, 256, true, 0> : gfront_persist_bwd_kernel<1024, 256, false, 0>)
+                     : (rb ? gfront_persist_bwd_kernel<128, 64, true, 0> : gfront_persist_bwd_kernel<128, 64, false, 0>);
+  else
+    kern = S == 1024 ? (rb ? gfront_persist_bwd_kernel<1024, 256, true, 1> : gfront_persist_bwd_kernel<1024, 256, false, 1>)
+                     : (rb ? gfront_persist_bwd_kernel<128, 64, true, 1> : gfront_persist_bwd_kernel<128, 64, false, 1>);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), 0, st, p);
   AG_CHECK_LAUNCH("ag_gfront_bwd_persist");
   return AG_OK;
 }

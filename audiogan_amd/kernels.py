@@ -888,6 +888,32 @@ def gfront_bwd_persist(gates, cs, x, dacc, whh, wx, wp, dgs, dxt):
           'ag_gfront_bwd_persist')
 
 
+def grufront_bwd_persist(gates, hs, gh, x, dacc, whh, wx, wp, dgi, dgh, dxt):
+    """the GRU front's backward through time in ONE persistent launch (ag_grufront_bwd_persist); hs [T+1,B,S] with
+    hs[t] = h_{t-1}; dacc [T,B,S+fs] = the external gradient [dL/dh_t | dL/dx_t], read only"""
+    T, B, S3 = gates.shape
+    S = S3 // 3
+    fs = wp.size(0)
+    for t_, n, shp in ((gates, 'gates', (T, B, 3 * S)), (hs, 'hs', (T + 1, B, S)), (gh, 'gh', (T, B, 3 * S)),
+                       (x, 'x', (B, T * fs)), (dacc, 'dacc', (T, B, S + fs)), (whh, 'whh', (3 * S, S)), (wp, 'wp', (fs, S)),
+                       (dgi, 'dgi', (T, B, 3 * S)), (dgh, 'dgh', (T, B, 3 * S)), (dxt, 'dxt', (T, B, fs))):
+        _chk(t_, n)
+        assert t_.is_contiguous() and tuple(t_.shape) == shp, (n, tuple(t_.shape), shp)
+    _chk(wx, 'wx')
+    assert tuple(wx.shape) == (3 * S, fs) and wx.stride(1) == 1
+    ws = _persist_workspace(x.device, _PERSIST_WS_MIN)
+    check(lib.ag_grufront_bwd_persist(_p(gates), _p(hs), _p(gh), _p(x), _p(dacc), _p(whh), _p(wx), wx.stride(0), _p(wp),
+                                      _p(dgi), _p(dgh), _p(dxt), _p(ws), ws.numel(), T, B, S, fs, _n_cu(x.device),
+                                      _stream()), 'ag_grufront_bwd_persist')
+
+
+def _work_grufront_bwd(gates, hs, gh, x, dacc, whh, wx, wp, *a_, **kw):
+    T, B, S3 = gates.shape
+    S, fs = S3 // 3, wp.size(0)
+    return 'gfront_persist_bwd_kernel<gru>', 2.0 * B * ((T - 1) * S3 * (S + fs) + T * fs * S), \
+        4.0 * (S3 * (S + fs) + fs * S + T * B * (4 * S3 + 2 * S + (S + fs) + 2 * fs)), 1
+
+
 def grufront_fwd_persist(gates, gh, wx, whh, bhn, wp, bp, hs, x):
     """the GRU-front generator's frame loop in ONE persistent launch (ag_grufront_fwd_persist); hs: [T,B,S] (h_t)"""
     T, B, S3 = gates.shape
@@ -1049,7 +1075,7 @@ def _work_seq_bwd_cell(gates, whh, *a_, **kw):
 
 for _n, _w in (('skinny_gemm', _work_skinny), ('lstm_step_fwd', _work_step),
                ('_lstm_seq_fwd_range', _work_seq_fwd), ('_lstm_seq_fwd_persist_call', _work_seq_fwd_persist),
-               ('_lstm_seq_bwd_persist_call', _work_seq_bwd_persist), ('gfront_fwd_persist', _work_gfront), ('gfront_bwd_persist', _work_gfront_bwd),
+               ('_lstm_seq_bwd_persist_call', _work_seq_bwd_persist), ('gfront_fwd_persist', _work_gfront), ('gfront_bwd_persist', _work_gfront_bwd), ('grufront_bwd_persist', _work_grufront_bwd),
                ('grufront_fwd_persist', _work_grufront), ('_lstm_seq_bwd_prod', _work_seq_bwd_prod),
                ('_lstm_seq_bwd_cell', _work_seq_bwd_cell), ('_lstm_seq_bwd_step', _work_seq_bwd_step)):
     _instrument(_n, _w)

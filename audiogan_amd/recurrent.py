@@ -447,19 +447,28 @@ class GRUFrontFn(torch.autograd.Function):
         dev = zc.device
         wg = any(ctx.needs_input_grad[2:])
         dws = front.group.zero_dws() if wg else None
-        dxa = dx.contiguous().clone() if dx is not None else torch.zeros(B, T * fs, device=dev)
-        dha = torch.zeros(T + 1, B, S, device=dev)     # dha[t+1] accumulates dL/dh_t
+        persist = T > 0 and K.gfront_bwd_persist_ok(B, S, fs, dev) and wx.stride(1) == 1
+        dgi = torch.empty(T, B, 3 * S, device=dev)
+        dgh = torch.empty(T, B, 3 * S, device=dev)
+        dxt = torch.empty(T, B, fs, device=dev)
+        if persist:
+            # the whole loop in ONE launch (ag_grufront_bwd_persist): dacc[t] = the external gradient [dL/dh_t | dL/dx_t]
+            dacc = torch.zeros(T, B, S + fs, device=dev)
+            if dx is not None:
+                dacc[:, :, S:].copy_(dx.contiguous().view(B, T, fs).transpose(0, 1))
+        else:
+            dxa = dx.contiguous().clone() if dx is not None else torch.zeros(B, T * fs, device=dev)
+            dha = torch.zeros(T + 1, B, S, device=dev)     # dha[t+1] accumulates dL/dh_t
         if ds is not None:
             ds_tb = ds.t().contiguous().view(T * B, 1)
             if wg:
                 K.gemm(ds_tb, hs[1:].view(T * B, S), dws[6], ta=True)
                 K.col_sum(ds_tb, dws[7])
-            K.gemm(ds_tb, sw, dha[1:].view(T * B, S))
-        dgi = torch.empty(T, B, 3 * S, device=dev)
-        dgh = torch.empty(T, B, 3 * S, device=dev)
-        dxt = torch.empty(T, B, fs, device=dev)
-        dh_dir = torch.empty(B, S, device=dev)
-        for t in reversed(range(T)):
+            K.gemm(ds_tb, sw, dacc.view(T * B, S + fs)[:, :S] if persist else dha[1:].view(T * B, S))
+        if persist:
+            K.grufront_bwd_persist(gi, hs, gh, x, dacc, w_hh, wx, pw, dgi, dgh, dxt)
+        dh_dir = None if persist else torch.empty(B, S, device=dev)
+        for t in reversed(range(0 if persist else T)):
             gx = dxt[t]
             K.act_bwd2d(dxa[:, t * fs:(t + 1) * fs], x[:, t * fs:(t + 1) * fs], gx, ACT_TANH)
             _small_acc(gx, pw, dha[t + 1])

@@ -338,6 +338,13 @@ int ag_gfront_bwd_persist_ok(int B, int S, int fs, int n_cu);
 int ag_gfront_bwd_persist(const float* ga, const float* c_all, const float* x, const float* dacc, const float* w_hh,
                           const float* w_x, int ldwx, const float* w_p, float* dgs, float* dxt, void* ws,
                           int64_t ws_bytes, int T, int B, int S, int fs, int n_cu, void* stream);
+/* The same for the GRU-front generator (BASELINE configs[3]; torch.nn.GRUCell backward, gate order r z n): ga [T,B,3S]
+ * activated gates, hs [T+1,B,S] (hs[t] = h_{t-1}, hs[0] = 0) and gh [T,B,3S] (n slot = W_hn h_{t-1} + b_hn) as saved by
+ * ag_grufront_fwd_persist; outputs dgi [T,B,3S] (d of the input-side pre-activations), dgh [T,B,3S] (hidden side: the n slot
+ * times r) and dxt [T,B,fs].  Shapes and workspace as ag_gfront_bwd_persist. */
+int ag_grufront_bwd_persist(const float* ga, const float* hs, const float* gh, const float* x, const float* dacc,
+                            const float* w_hh, const float* w_x, int ldwx, const float* w_p, float* dgi, float* dgh,
+                            float* dxt, void* ws, int64_t ws_bytes, int T, int B, int S, int fs, int n_cu, void* stream);
 
 /* The same frame loop with a GRU cell (BASELINE configs[3]: the audiogan.py Generator with the LSTMCell of :380-386 replaced
  * by a GRU cell, gate order r z n as torch.nn.GRUCell) as ONE persistent launch.  gates [T,B,3S]: in = W_ih[:, fs:] zc_t +
