@@ -614,6 +614,49 @@ def test_persistent_launch_timeout_surfaces(K):
     opt.step(check=True)
 
 
+@pytest.mark.parametrize('cell', ['lstm', 'gru'])
+def test_front_backward_timeout_surfaces(K, cell):
+    """the fronts' persistent backward with one workgroup muted (2 ms timeout): the launch ends, the sticky word is set and
+    what the stalled workgroups wrote is NaN; a healthy launch afterwards gives the healthy result again"""
+    T, B, S, fs = 4, 40, 128, 64
+    ng = 4 if cell == 'lstm' else 3
+    gen = torch.Generator().manual_seed(9)
+    r = lambda *shape: torch.randn(*shape, generator=gen).cuda()      # noqa: E731
+    gates = torch.sigmoid(r(T, B, ng * S))
+    if cell == 'lstm':
+        gates[:, :, 2 * S:3 * S] = torch.tanh(r(T, B, S))
+    else:
+        gates[:, :, 2 * S:] = torch.tanh(r(T, B, S))
+    state, gh, x, dacc = r(T + 1, B, S) * 0.5, r(T, B, ng * S) * 0.5, torch.tanh(r(B, T * fs)), r(T, B, S + fs) * 0.1
+    whh, wih, wp = r(ng * S, S) * 0.1, r(ng * S, fs + 8) * 0.1, r(fs, S) * 0.1
+    wx = wih[:, :fs]
+
+    def run():
+        dgs, dgh, dxt = torch.empty(T, B, ng * S).cuda(), torch.empty(T, B, ng * S).cuda(), torch.empty(T, B, fs).cuda()
+        if cell == 'lstm':
+            K.gfront_bwd_persist(gates, state, x, dacc, whh, wx, wp, dgs, dxt)
+        else:
+            K.grufront_bwd_persist(gates, state, gh, x, dacc, whh, wx, wp, dgs, dgh, dxt)
+        torch.cuda.synchronize()
+        return dgs, dxt
+
+    assert K.gfront_bwd_persist_ok(B, S, fs, torch.device('cuda', 0))
+    K.lstm_persist_status(reset=True)
+    ok = run()
+    assert K.lstm_persist_status() == 0 and all(bool(torch.isfinite(t).all()) for t in ok)
+    try:
+        K.persist_debug(timeout_ticks=200000, mute_block=0)          # 2 ms; block 0 (an h tile) never raises its flag
+        bad = run()
+    finally:
+        K.persist_debug(0, -1)
+    st = K.lstm_persist_status()
+    assert st & 0x80000000, hex(st)
+    assert bool(torch.isnan(bad[0]).any()) and bool(torch.isnan(bad[1]).any()), 'workgroups that gave up must poison their outputs'
+    again = run()
+    assert all(torch.equal(a, b) for a, b in zip(again, ok)) and K.lstm_persist_status() == st
+    K.lstm_persist_status(reset=True)
+
+
 def test_persistent_workspace_is_never_freed(K):
     """a larger request after a buffer was handed out must not free that buffer (a captured graph keeps its pointer)"""
     dev = torch.device('cuda', torch.cuda.current_device())
