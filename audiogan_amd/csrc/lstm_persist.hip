@@ -1093,7 +1093,17 @@ __global__ __launch_bounds__(512) void gfront_persist_bwd_kernel(const FrontBwdP
   const int li = lane & 15, g = lane >> 4;
   if (tid == 0) s_dead = 0;
   __syncthreads();
-  const int bt = blockIdx.x / NT, ct = blockIdx.x % NT;
+  // placement: workgroup ids go round-robin over the 8 XCDs; with nbt clip tiles (8 % nbt == 0) a clip tile's NT workgroups
+  // are put on 8 / nbt XCDs, so a frame's dgates rows are pulled into that many L2s instead of all 8 (speed only)
+  int bt = blockIdx.x / NT, ct = blockIdx.x % NT;
+  {
+    const int nbt = gridDim.x / NT, per = nbt <= 8 ? 8 / nbt : 0;
+    if (per > 0 && per * nbt == 8 && NT % per == 0) {
+      const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;       // q < NT / per
+      bt = xcd / per;
+      ct = (xcd % per) * (NT / per) + q;
+    }
+  }
   const bool isx = ct >= NHT;
   const int m0 = bt * 32;
   const int n0 = (isx ? ct - NHT : ct) * 16;                // first column inside W_hh / W_x
