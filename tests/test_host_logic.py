@@ -273,3 +273,41 @@ def test_aligned_shapes_take_fused_paths_and_match_oracle():
             if k.split('.')[-1].startswith('bias') and k.endswith('_v'):
                 continue
             np.testing.assert_allclose(p.grad.numpy(), q.grad.numpy(), rtol=5e-4, atol=2e-5, err_msg=k)
+
+
+def test_front_backward_persistence_follows_the_gradient_bucket(monkeypatch):
+    """a generator whose optimiser carries a gradient bucket (multi-GPU: a collective may run beside its backward) runs the
+    recurrent front's backward in the per-frame form; without a bucket the persistent launch stays allowed.  The switch is
+    restored afterwards, also when the backward raises (kernels.front_bwd_persist / train._single_gpu)"""
+    from audiogan_amd import kernels as K, train
+    seen = []
+
+    class _Loss(object):
+        def __init__(self, fail=False):
+            self.fail = fail
+
+        def backward(self):
+            seen.append(K.PERSIST_FRONT_BWD[0])
+            if self.fail:
+                raise RuntimeError('boom')
+
+    class _Opt(object):
+        bucket = None
+
+    assert K.PERSIST_FRONT_BWD[0] is True
+    o = _Opt()
+    with K.front_bwd_persist(train._single_gpu(o)):
+        _Loss().backward()
+    o.bucket = object()
+    with K.front_bwd_persist(train._single_gpu(o)):
+        _Loss().backward()
+        with K.front_bwd_persist(True):                 # an inner "on" cannot override an outer "off"
+            _Loss().backward()
+    with pytest.raises(RuntimeError):
+        with K.front_bwd_persist(False):
+            _Loss(fail=True).backward()
+    assert seen == [True, False, False, False] and K.PERSIST_FRONT_BWD[0] is True
+    # and the shape query honours it (no GPU here: the device check comes first, so use the flag path only)
+    monkeypatch.setattr(K, 'PERSIST', [True])
+    with K.front_bwd_persist(False):
+        assert K.gfront_bwd_persist_ok(64, 1024, 256, torch.device('cpu')) is False
