@@ -136,6 +136,14 @@ __device__ __forceinline__ float ag_apply_act(float v, int act, float slope) {
   return v;
 }
 
+// the tail of a GEMM epilogue.  AG_ACT_LEAKY_GATE: `res` is not added - it is the SAVED OUTPUT of a LeakyReLU whose
+// derivative scales this result (the activation backward rides in the epilogue of the product that feeds it)
+__device__ __forceinline__ float ag_res_act(float v, bool has_res, float r, int act, float slope) {
+  if (act == AG_ACT_LEAKY_GATE) return r > 0.f ? v : v * slope;
+  if (has_res) v += r;
+  return ag_apply_act(v, act, slope);
+}
+
 __device__ __forceinline__ float ag_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }
 
 // single-input-channel convolutions (conv_c1.hip): taken by ag_conv1d_engine / ag_conv1d_wgrad for the layer shapes they

@@ -288,8 +288,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
         for (int j = 0; j < TN; ++j) {
           float v = p.alpha * acc[i][j][e] + bj[j];
           if (hbeta) v += p.beta * dst[32 * j];
-          if (hr) v += rs[32 * j];
-          dst[32 * j] = ag_apply_act(v, p.act, p.slope);
+          dst[32 * j] = ag_res_act(v, hr, hr ? rs[32 * j] : 0.f, p.act, p.slope);
         }
       }
     return;
@@ -320,8 +319,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
         }
         if (p.beta != 0.f) v += p.beta * *dst;
         if (p.bias) v += p.bias[col];
-        if (p.res) v += p.res[(int64_t)row * p.ldres + col];
-        *dst = ag_apply_act(v, p.act, p.slope);
+        *dst = ag_res_act(v, p.res != nullptr, p.res ? p.res[(int64_t)row * p.ldres + col] : 0.f, p.act, p.slope);
       }
     }
 }
@@ -459,8 +457,7 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmP p) {
         for (int j = 0; j < 2; ++j) {
           float v = p.alpha * acc[i][j][e] + bj[j];
           if (hbeta) v += p.beta * dst[32 * j];
-          if (hr) v += rs[32 * j];
-          dst[32 * j] = ag_apply_act(v, p.act, p.slope);
+          dst[32 * j] = ag_res_act(v, hr, hr ? rs[32 * j] : 0.f, p.act, p.slope);
         }
       }
     return;
@@ -491,8 +488,7 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmP p) {
         }
         if (p.beta != 0.f) v += p.beta * *dst;
         if (p.bias) v += p.bias[col];
-        if (p.res) v += p.res[(int64_t)row * p.ldres + col];
-        *dst = ag_apply_act(v, p.act, p.slope);
+        *dst = ag_res_act(v, p.res != nullptr, p.res ? p.res[(int64_t)row * p.ldres + col] : 0.f, p.act, p.slope);
       }
     }
 }
@@ -723,8 +719,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmP p) {
         }
         if (p.beta != 0.f) v += p.beta * *dst;
         if (p.bias) v += p.bias[col];
-        if (p.res) v += p.res[(int64_t)row * p.ldres + col];
-        *dst = ag_apply_act(v, p.act, p.slope);
+        *dst = ag_res_act(v, p.res != nullptr, p.res ? p.res[(int64_t)row * p.ldres + col] : 0.f, p.act, p.slope);
       }
     }
 }
@@ -833,6 +828,7 @@ extern "C" int ag_gemm(const float* A, int lda, int ta, const float* B, int ldb,
   AG_REQUIRE((ta == 0 || ta == 1) && (tb == 0 || tb == 1), "ag_gemm: bad transpose flag");
   AG_REQUIRE(lda >= (ta ? M : K) && ldb >= (tb ? K : N) && ldc >= N, "ag_gemm: bad leading dim");
   AG_REQUIRE(ag_cdiv(M, 64) <= 65535, "ag_gemm: M too large");
+  AG_REQUIRE(act != AG_ACT_LEAKY_GATE || res, "ag_gemm: AG_ACT_LEAKY_GATE needs the saved activation in `res`");
   GemmP p;
   p.A = A; p.B = B; p.C = C; p.bias = bias; p.res = res;
   p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldres = ldres;

@@ -241,6 +241,17 @@ class DHead(object):
         self.group = WNGroup()
 
 
+_EYE = {}
+
+
+def _eye(w):
+    """cached identity of w's (square) shape on w's device"""
+    key = (w.device, w.size(0))
+    if key not in _EYE:
+        _EYE[key] = torch.eye(w.size(0), device=w.device, dtype=w.dtype)
+    return _EYE[key]
+
+
 class DHeadFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, rows, head, *params):
@@ -281,22 +292,31 @@ class DHeadFn(torch.autograd.Function):
         if wg:
             K.gemm(dout, hmid, dws[2 * nr + 2], ta=True)
             K.col_sum(dout, dws[2 * nr + 3])
+        # every LeakyReLU backward rides in the epilogue of the product that feeds it (ACT_LEAKY_GATE: res = the saved
+        # activation), so dh / da below are d(pre-activation) as they leave the GEMM
         dh = torch.empty_like(hmid)
-        K.gemm(dout, w1, dh)
-        K.act_bwd(dh, hmid, dh, ACT_LEAKY)
+        K.gemm(dout, w1, dh, res=hmid, act=ACT_LEAKY_GATE)
         # classifier[0]
         if wg:
             K.gemm(dh, acts[nr], dws[2 * nr], ta=True)
             K.col_sum(dh, dws[2 * nr + 1])
         da = torch.empty_like(acts[nr])
-        K.gemm(dh, w0, da)
+        if nr > 0:
+            K.gemm(dh, w0, da, res=acts[nr], act=ACT_LEAKY_GATE)
+        else:
+            K.gemm(dh, w0, da)
         for i in reversed(range(nr)):
-            K.act_bwd(da, acts[i + 1], da, ACT_LEAKY)      # da = d(pre-activation)
             if wg:
                 K.gemm(da, acts[i], dws[2 * i], ta=True)
                 K.col_sum(da, dws[2 * i + 1])
             dprev = torch.empty_like(acts[i])
-            K.gemm(da, prep[2 * i].w, dprev, res=da)       # W^T da + da (skip connection)
+            # d(input of residual i) = W^T da + da (skip connection) = (W + I)^T da: with the identity folded into the
+            # weight the skip needs no second epilogue tensor and `res` is free for the gate of the residual below
+            wi = prep[2 * i].w
+            if i > 0:
+                K.gemm(da, wi + _eye(wi), dprev, res=acts[i], act=ACT_LEAKY_GATE)
+            else:
+                K.gemm(da, wi, dprev, res=da)
             da = dprev
         grads = head.group.backward(dws) if wg else [None] * (2 * len(head.group.items))
         return (da if ctx.needs_input_grad[0] else None, None) + tuple(grads)

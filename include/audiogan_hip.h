@@ -175,6 +175,9 @@ int ag_leaky_bwd(const float* dy, int64_t dy_bs, int64_t dy_cs, const float* y, 
  *   C[M,N] = act( alpha * op(A)[M,K] * op(B)[K,N] + beta * C + bias[N] + res[M,N] )
  * ta: 0 -> A is [M,K] row-major (lda), 1 -> A is stored [K,M]
  * tb: 0 -> B is [K,N] row-major (ldb), 1 -> B is stored [N,K]   (Linear weight)
+ * act = AG_ACT_LEAKY_GATE: `res` is not added; it is the saved OUTPUT of a LeakyReLU and the result is scaled by that
+ * LeakyReLU's derivative (1 where res > 0, slope elsewhere): the activation backward of the heads (audiogan.py:261,:510
+ * under .backward()) rides in the epilogue of the backward-data product.
  * ------------------------------------------------------------------------- */
 int ag_gemm(const float* A, int lda, int ta, const float* B, int ldb, int tb, float* C, int ldc,
             int M, int N, int K, float alpha, float beta, const float* bias, const float* res,

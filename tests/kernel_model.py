@@ -180,9 +180,11 @@ def gemm(A, B, Cm, ta=False, tb=False, alpha=1.0, beta=0.0, bias=None, res=None,
         out = out + beta * Cm
     if bias is not None:
         out = out + bias.view(1, -1)
-    if res is not None:
+    if act == ACT_LEAKY_GATE:        # res = the saved LeakyReLU output whose derivative scales the result (not added)
+        out = out * torch.where(res > 0, torch.ones_like(res), torch.full_like(res, slope))
+    elif res is not None:
         out = out + res
-    Cm.copy_(_act(out, act, slope))
+    Cm.copy_(_act(out, act if act != ACT_LEAKY_GATE else ACT_NONE, slope))
 
 
 def col_sum(X, out):

@@ -197,6 +197,27 @@ def test_gemm(K, shape, ta, tb):
     close(Cd, ref)
 
 
+@pytest.mark.parametrize('shape,ta,tb', [((8192, 1024, 1024), False, False), ((8192, 512, 1024), False, True), ((130, 70, 24), False, False),
+                                         ((37, 53, 32), True, True), ((64, 256, 1024), False, True)])
+@pytest.mark.parametrize('prec', ['f32', 'bf16'])
+def test_gemm_leaky_gate_epilogue(K, shape, ta, tb, prec):
+    """ACT_LEAKY_GATE: the product scaled by the derivative of the LeakyReLU whose saved OUTPUT is passed as `res` (not
+    added) - every GEMM kernel (128-tile DMA / register-staged, 64-tile, bf16 MFMA), interior and ragged tiles"""
+    M, N, Kd = shape
+    gen = torch.Generator().manual_seed(16)
+    A = torch.randn((Kd, M) if ta else (M, Kd), generator=gen) / Kd ** 0.5
+    Bm = torch.randn((N, Kd) if tb else (Kd, N), generator=gen)
+    bias, y = torch.randn(N, generator=gen), torch.randn(M, N, generator=gen)
+    rb = (lambda t: t.to(torch.bfloat16).float()) if prec == 'bf16' else (lambda t: t)
+    ref = ((rb(A).t() if ta else rb(A)) @ (rb(Bm).t() if tb else rb(Bm)) + bias) * torch.where(y > 0, 1.0, 0.01)
+    Cd = torch.full((M, N), float('nan')).cuda()
+    with K.precision(prec):
+        K.gemm(dev(A), dev(Bm), Cd, ta=ta, tb=tb, bias=dev(bias), res=dev(y), act=K.ACT_LEAKY_GATE)
+        with pytest.raises(Exception):
+            K.gemm(dev(A), dev(Bm), Cd.clone(), ta=ta, tb=tb, act=K.ACT_LEAKY_GATE)       # the gate needs `res`
+    close(Cd, ref, rtol=2e-3 if prec == 'bf16' else 1e-3, atol=1e-4 if prec == 'bf16' else 1e-5)
+
+
 def test_gemm_strided_views(K):
     gen = torch.Generator().manual_seed(7)
     big = torch.randn(64, 456, generator=gen)
