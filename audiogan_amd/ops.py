@@ -305,6 +305,7 @@ class DHeadFn(torch.autograd.Function):
             K.gemm(dh, w0, da, res=acts[nr], act=ACT_LEAKY_GATE)
         else:
             K.gemm(dh, w0, da)
+        fold = K.get_precision() != 'bf16'
         for i in reversed(range(nr)):
             if wg:
                 K.gemm(da, acts[i], dws[2 * i], ta=True)
@@ -312,11 +313,15 @@ class DHeadFn(torch.autograd.Function):
             dprev = torch.empty_like(acts[i])
             # d(input of residual i) = W^T da + da (skip connection) = (W + I)^T da: with the identity folded into the
             # weight the skip needs no second epilogue tensor and `res` is free for the gate of the residual below
+            # (not in bf16 mode: rounding 1 + w_ii to bfloat16 would lose the diagonal weights; there the skip stays an
+            # exact fp32 add in the epilogue and the gate a pass of its own)
             wi = prep[2 * i].w
-            if i > 0:
+            if i > 0 and fold:
                 K.gemm(da, wi + _eye(wi), dprev, res=acts[i], act=ACT_LEAKY_GATE)
             else:
                 K.gemm(da, wi, dprev, res=da)
+                if i > 0:
+                    K.act_bwd(dprev, acts[i], dprev, ACT_LEAKY)
             da = dprev
         grads = head.group.backward(dws) if wg else [None] * (2 * len(head.group.items))
         return (da if ctx.needs_input_grad[0] else None, None) + tuple(grads)
