@@ -42,6 +42,8 @@ class OptDesc(C.Structure):
 # name -> (restype, argtypes); must list EVERY symbol of include/audiogan_hip.h
 SIGNATURES = {
     'ag_abi_version': (C.c_int, []),
+    'ag_defer_reduces': (C.c_int, [C.c_int]),
+    'ag_flush_reduces': (C.c_int, [vp]),
     'ag_arch': (C.c_char_p, []),
     'ag_last_error': (C.c_char_p, []),
     'ag_weight_norm_fwd': (C.c_int, [vp, C.c_int, C.c_int, vp]),
@@ -130,7 +132,7 @@ def _load():
     return lib
 
 
-ABI_VERSION = 5      # what this package was written against (csrc/api.hip: ag_abi_version)
+ABI_VERSION = 6      # what this package was written against (csrc/api.hip: ag_abi_version)
 
 lib = _load()
 if lib.ag_abi_version() != ABI_VERSION:

@@ -16,7 +16,7 @@ void ag_set_error(const char* fmt, ...) {
 // bumped whenever an entry point, a struct layout or the meaning of an argument changes (round 3: sticky persistent status,
 // AG_ACT_LEAKY_GATE, AG_PREC_F32X3, GRU front, Conv2DLSTMCell pieces): audiogan_amd/_lib.py refuses a library of another
 // version, so Python that relies on a new mode can never drive an older build
-extern "C" int ag_abi_version(void) { return 5; }
+extern "C" int ag_abi_version(void) { return 6; }
 extern "C" const char* ag_arch(void) { return "gfx950"; }
 extern "C" const char* ag_last_error(void) { return g_err; }
 
@@ -91,8 +91,83 @@ __global__ __launch_bounds__(256) void slab_reduce4_kernel(const f32x4* __restri
   if (threadIdx.x < 32 && i < n4) dst[i] = accumulate ? dst[i] + t : t;
 }
 
+// ---- deferred second stages --------------------------------------------------------------------------------------
+// A network's backward issues one second stage per weight-gradient / bias-sum launch (35+ per step, ~5 us each, nothing
+// reads their results before the weight-norm backward at the end).  Between ag_defer_reduces(1) and ag_flush_reduces()
+// ag_slab_reduce only RECORDS its arguments (thread-local: the autograd thread that runs the backward); the flush sums
+// every recorded output in ONE launch, each output in exactly the order the single launches use (bitwise the same
+// result).  The caller keeps the partial-sum workspaces alive until the flush.
+struct SlabDesc {
+  const float* ws;
+  float* dst;
+  int64_t n;     // outputs (floats)
+  int Z, acc, vec, blk0;
+};
+#define SLAB_MAXD 40
+struct SlabMulti {
+  SlabDesc d[SLAB_MAXD];
+  int nd;
+};
+static thread_local bool g_defer = false;
+static thread_local SlabMulti g_multi = {};
+static thread_local int g_multi_blocks = 0;
+
+__global__ __launch_bounds__(256) void slab_reduce_multi_kernel(const SlabMulti m) {
+  __shared__ f32x4 sh[256];
+  // (constant indices only: a run-time index into the by-value argument would put all of it into scratch)
+  SlabDesc D = m.d[0];
+#pragma unroll
+  for (int k = 1; k < SLAB_MAXD; ++k)
+    if (k < m.nd && (int)blockIdx.x >= m.d[k].blk0) D = m.d[k];
+  const int64_t i = (int64_t)((int)blockIdx.x - D.blk0) * 32 + (threadIdx.x & 31);
+  if (D.vec) {
+    const int64_t n4 = D.n >> 2;
+    const f32x4 t = slab_sum<f32x4>((const f32x4*)D.ws, D.Z, n4, i, threadIdx.x >> 5, i < n4, sh);
+    f32x4* dst = (f32x4*)D.dst;
+    if (threadIdx.x < 32 && i < n4) dst[i] = D.acc ? dst[i] + t : t;
+  } else {
+    const float t = slab_sum<float>(D.ws, D.Z, D.n, i, threadIdx.x >> 5, i < D.n, (float*)sh);
+    if (threadIdx.x < 32 && i < D.n) D.dst[i] = D.acc ? D.dst[i] + t : t;
+  }
+}
+
+static int slab_flush(hipStream_t st) {
+  if (g_multi.nd > 0) {
+    hipLaunchKernelGGL(slab_reduce_multi_kernel, dim3((unsigned)g_multi_blocks), dim3(256), 0, st, g_multi);
+    g_multi.nd = 0;
+    g_multi_blocks = 0;
+    AG_CHECK_LAUNCH("ag_flush_reduces");
+  }
+  return AG_OK;
+}
+
+extern "C" int ag_defer_reduces(int on) {
+  AG_REQUIRE(!(g_defer && !on && g_multi.nd > 0), "ag_defer_reduces: %d recorded second stages were never flushed", g_multi.nd);
+  g_defer = on != 0;
+  if (on) { g_multi.nd = 0; g_multi_blocks = 0; }
+  return AG_OK;
+}
+
+extern "C" int ag_flush_reduces(void* stream) { return slab_flush((hipStream_t)stream); }
+
 int ag_slab_reduce(const float* ws, int Z, int64_t n, float* dst, int accumulate, hipStream_t st) {
   if (n <= 0 || Z <= 0) return AG_OK;
+  if (g_defer) {
+    // two recorded stages must not write the same floats in one launch, and a launch holds SLAB_MAXD of them
+    bool clash = g_multi.nd == SLAB_MAXD;
+    for (int k = 0; k < g_multi.nd && !clash; ++k)
+      clash = dst < g_multi.d[k].dst + g_multi.d[k].n && g_multi.d[k].dst < dst + n;
+    if (clash) {
+      const int rc = slab_flush(st);
+      if (rc != AG_OK) return rc;
+    }
+    SlabDesc& D = g_multi.d[g_multi.nd++];
+    D.ws = ws; D.dst = dst; D.n = n; D.Z = Z; D.acc = accumulate;
+    D.vec = ((n & 3) == 0 && (((uintptr_t)ws | (uintptr_t)dst) & 15) == 0) ? 1 : 0;
+    D.blk0 = g_multi_blocks;
+    g_multi_blocks += (int)ag_cdiv64(D.vec ? n >> 2 : n, 32);
+    return AG_OK;
+  }
   if ((n & 3) == 0 && (((uintptr_t)ws | (uintptr_t)dst) & 15) == 0) {
     const int64_t n4 = n >> 2;
     hipLaunchKernelGGL(slab_reduce4_kernel, dim3((unsigned)ag_cdiv64(n4, 32)), dim3(256), 0, st, (const f32x4*)ws, Z, n4,

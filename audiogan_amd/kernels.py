@@ -56,6 +56,37 @@ DETERMINISTIC = [_os0.environ.get('AG_DETERMINISTIC', '1') != '0']
 _SMALL_WS = 1 << 17        # floats; enough for the bias / channel / column sums at every BASELINE size
 
 
+import threading as _threading
+
+_DEFER = _threading.local()      # .keep: list of workspaces a deferred-reduction scope keeps alive (absent / None: not deferring)
+
+
+class deferred_reduces(object):
+    """``with K.deferred_reduces(): ...`` - the second stages of every two-stage reduction issued inside (conv weight
+    gradients, bias / channel sums) run as ONE launch at the end of the block instead of one each (ag_defer_reduces /
+    ag_flush_reduces; same results bit for bit).  Nothing inside the block may read those outputs.  The partial-sum
+    workspaces are kept alive until the flush.  Per thread, like the C side."""
+
+    def __enter__(self):
+        self.nested = getattr(_DEFER, 'keep', None) is not None
+        if not self.nested:
+            check(lib.ag_defer_reduces(1), 'ag_defer_reduces')
+            _DEFER.keep = []
+        return self
+
+    def __exit__(self, et, ev, tb):
+        if self.nested:
+            return False
+        try:
+            if et is None:
+                check(lib.ag_flush_reduces(_stream()), 'ag_flush_reduces')
+        finally:
+            _DEFER.keep = None
+            lib.ag_defer_reduces(1)        # drops whatever is still recorded (error path) ...
+            lib.ag_defer_reduces(0)        # ... and turns deferral off
+        return False
+
+
 def _bind_ws(numel, dev):
     """bind `numel` floats of scratch for the NEXT reducing call (ag_bind_workspace); the tensor comes from torch's
     stream-ordered caching allocator, so it is safe to drop it as soon as the call has been enqueued"""
@@ -64,6 +95,8 @@ def _bind_ws(numel, dev):
         return None
     ws = torch.empty(int(numel), dtype=torch.float32, device=dev)
     check(lib.ag_bind_workspace(_p(ws), int(numel)), 'ag_bind_workspace')
+    if getattr(_DEFER, 'keep', None) is not None:
+        _DEFER.keep.append(ws)
     return ws
 
 

@@ -127,6 +127,14 @@ class GTrunkFn(torch.autograd.Function):
         wg = any(ctx.needs_input_grad[2:])
         dws = trunk.group.zero_dws() if wg else None
         dslab = torch.empty_like(slab)
+        with K.deferred_reduces():      # every weight-gradient / bias-sum second stage of this backward in ONE launch
+            GTrunkFn._backward_layers(trunk, prep, slab, hids, dy, dslab, dws, wg, ctot)
+        grads = trunk.group.backward(dws) if wg else [None] * (2 * len(trunk.group.items))
+        dx0 = dslab[:, 0, :].contiguous() if ctx.needs_input_grad[0] else None
+        return (dx0, None) + tuple(grads)
+
+    @staticmethod
+    def _backward_layers(trunk, prep, slab, hids, dy, dslab, dws, wg, ctot):
         # final conv (no activation)
         if wg:
             conv_wgrad(trunk.final, slab, dy, dws[-2], dws[-1])
@@ -152,9 +160,6 @@ class GTrunkFn(torch.autograd.Function):
             if wg:
                 conv_wgrad(cs, slab[:, :cin], dhid, dws[4 * i], None)
             conv_bwd_data(cs, pw, dhid, dslab[:, :cin], accumulate=True)
-        grads = trunk.group.backward(dws) if wg else [None] * (2 * len(trunk.group.items))
-        dx0 = dslab[:, 0, :].contiguous() if ctx.needs_input_grad[0] else None
-        return (dx0, None) + tuple(grads)
 
 
 # --------------------------------------------------------------------------------------
@@ -197,34 +202,35 @@ class DConvStackFn(torch.autograd.Function):
         dws = stack.group.zero_dws() if wg else None
         n = len(stack.specs)
         d, gated = None, False
-        for i in reversed(range(n)):
-            sp = stack.specs[i]
-            g = dacts[i]
-            if d is None:
-                if g is None:
-                    continue
-                d = torch.empty_like(acts[i])
-                K.leaky_bwd(g.contiguous(), acts[i], d, lens=ctx.lens_list[i],     # out of place: no clone
-                            bias_grad=dws[2 * i + 1] if wg else None)
-            elif not gated:
-                if g is not None:
-                    K.axpby(g.contiguous(), d, 1.0, 1.0)
-                K.leaky_bwd(d, acts[i], d, lens=ctx.lens_list[i], bias_grad=dws[2 * i + 1] if wg else None)
-            elif wg:
-                K.channel_sum(d, dws[2 * i + 1])          # (d already is d(pre-activation): see below)
-            xin = acts[i - 1] if i > 0 else x.contiguous().view(B, 1, L)
-            if wg:
-                conv_wgrad(sp, xin, d, dws[2 * i], None)
-            if i > 0 or ctx.needs_input_grad[0]:
-                dx = torch.empty_like(xin)
-                # when the layer below receives no other gradient its LeakyReLU + length-mask backward rides in this
-                # launch's epilogue (dx = d(pre-activation) of layer i - 1) instead of a pass of its own
-                gated = i > 0 and dacts[i - 1] is None
-                conv_bwd_data(sp, prep[2 * i], d, dx, gate=acts[i - 1] if gated else None,
-                              lens=ctx.lens_list[i - 1] if gated else None)
-                d = dx
-            else:
-                d = None
+        with K.deferred_reduces():      # every weight-gradient / bias-sum second stage of this backward in ONE launch
+            for i in reversed(range(n)):
+                sp = stack.specs[i]
+                g = dacts[i]
+                if d is None:
+                    if g is None:
+                        continue
+                    d = torch.empty_like(acts[i])
+                    K.leaky_bwd(g.contiguous(), acts[i], d, lens=ctx.lens_list[i],     # out of place: no clone
+                                bias_grad=dws[2 * i + 1] if wg else None)
+                elif not gated:
+                    if g is not None:
+                        K.axpby(g.contiguous(), d, 1.0, 1.0)
+                    K.leaky_bwd(d, acts[i], d, lens=ctx.lens_list[i], bias_grad=dws[2 * i + 1] if wg else None)
+                elif wg:
+                    K.channel_sum(d, dws[2 * i + 1])          # (d already is d(pre-activation): see below)
+                xin = acts[i - 1] if i > 0 else x.contiguous().view(B, 1, L)
+                if wg:
+                    conv_wgrad(sp, xin, d, dws[2 * i], None)
+                if i > 0 or ctx.needs_input_grad[0]:
+                    dx = torch.empty_like(xin)
+                    # when the layer below receives no other gradient its LeakyReLU + length-mask backward rides in this
+                    # launch's epilogue (dx = d(pre-activation) of layer i - 1) instead of a pass of its own
+                    gated = i > 0 and dacts[i - 1] is None
+                    conv_bwd_data(sp, prep[2 * i], d, dx, gate=acts[i - 1] if gated else None,
+                                  lens=ctx.lens_list[i - 1] if gated else None)
+                    d = dx
+                else:
+                    d = None
         grads = stack.group.backward(dws) if wg else [None] * (2 * len(stack.group.items))
         dx0 = d.view(B, L) if (ctx.needs_input_grad[0] and d is not None) else None
         return (dx0, None, None) + tuple(grads)

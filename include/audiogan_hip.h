@@ -245,6 +245,14 @@ int ag_get_precision(void);
 int ag_bind_workspace(float* ws, int64_t numel);
 int64_t ag_conv1d_wgrad_ws_numel(int B, int A, int Lsh, int C, int K);
 int64_t ag_gemm_ws_numel(int M, int N, int K, int act);
+
+/* Deferred second stages.  Between ag_defer_reduces(1) and ag_flush_reduces() every two-stage reduction of the calling
+ * thread (conv weight gradients, bias / channel sums - not the split-K GEMM, whose second stage carries an epilogue) only
+ * records its second stage; the flush sums all recorded outputs in ONE launch, each in the order its own launch would use
+ * (bitwise the same results).  The caller keeps every bound workspace alive until the flush and turns deferral off again
+ * with ag_defer_reduces(0) (an error if recorded stages were never flushed).  Thread-local, like ag_bind_workspace. */
+int ag_defer_reduces(int on);
+int ag_flush_reduces(void* stream);
 int64_t ag_skinny_ws_numel(int M, int N, int K);
 
 /* Skinny product for the sequential part of the recurrent layers (M = clips per call <= 256):

@@ -130,6 +130,57 @@ def test_conv_forward_backward_data(K, layer):
         close(y3, ref, msg='forward, aligned layout')
 
 
+def test_deferred_second_stages_are_bitwise_the_same(K):
+    """K.deferred_reduces(): the second stages of many two-stage reductions in ONE launch at the end of the block - every
+    output bit for bit what the single launches give (also when two of them write the same tensor: flushed in between),
+    nothing written before the flush, and an error path that leaves deferral off"""
+    gen = torch.Generator().manual_seed(44)
+    layers = (G_LAYERS + D_LAYERS)[:9]
+    B = 5
+    data = []
+    for kind, cin, cout, k, s, p, lin in layers:
+        w, x = _mk(kind, cin, cout, k, s, p, lin, B, 3)
+        y = F.conv1d(x, w, None, s, p) if kind == 'conv' else F.conv_transpose1d(x, w, None, s, p)
+        data.append((kind, k, s, p, dev(x), dev(torch.randn(y.shape, generator=gen)), w.shape, cout))
+
+    def run(deferred):
+        outs = [(torch.zeros(shp).cuda(), torch.zeros(cout).cuda()) for *_, shp, cout in data]
+        shared = torch.zeros(data[0][7]).cuda()
+
+        def body():
+            for (kind, k, s, p, x, gy, shp, cout), (dw, db) in zip(data, outs):
+                if kind == 'conv':
+                    K.conv_wgrad(gy, x, dw, k, s, p)
+                else:
+                    K.conv_wgrad(x, gy, dw, k, s, p)
+                K.channel_sum(gy, db)
+            if deferred:
+                torch.cuda.synchronize()
+                pending = sum(not bool(t.any()) for pair in outs for t in pair)
+                assert pending >= len(outs), 'second stages ran before the flush (%d outputs still zero)' % pending
+            K.channel_sum(data[0][5], shared)            # the same output twice: must not share a launch
+            K.channel_sum(data[0][5], shared)
+        if deferred:
+            with K.deferred_reduces():
+                body()
+        else:
+            body()
+        torch.cuda.synchronize()
+        return [t for pair in outs for t in pair] + [shared]
+
+    plain, deferred = run(False), run(True)
+    assert all(bool(t.any()) for t in plain)
+    for a, b in zip(plain, deferred):
+        assert torch.equal(a, b)
+    with pytest.raises(RuntimeError):
+        with K.deferred_reduces():
+            K.channel_sum(data[0][5], torch.zeros(data[0][7]).cuda())
+            raise RuntimeError('boom')
+    again = run(False)                                   # deferral is off again, nothing stale is flushed later
+    for a, b in zip(plain, again):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize('layer', G_LAYERS + D_LAYERS + EDGE_LAYERS)
 def test_conv_weight_bias_grad(K, layer):
     kind, cin, cout, k, s, p, lin = layer
