@@ -114,18 +114,22 @@ class WNGroup(object):
         self._bufs = bufs
         self._key = None
 
-    def prepare(self):
+    def _current_key(self):
+        """(key of the parameters as they are now); allocates the buffers on first use"""
         dev = self.items[0]['v'].device
         if self._bufs is None or self._bufs[0].w.device != dev:
             self._alloc(dev)
-        key = (capture_tag(dev),) + tuple((it['v'].data_ptr(), it['v']._version, param_epoch(it['v']), it['g'].data_ptr(),
-                                           it['g']._version, param_epoch(it['g'])) for it in self.items)
+        return (capture_tag(dev),) + tuple((it['v'].data_ptr(), it['v']._version, param_epoch(it['v']), it['g'].data_ptr(),
+                                            it['g']._version, param_epoch(it['g'])) for it in self.items)
+
+    def _entries(self):
+        return [dict(v=it['v'].data, g=it['g'].data.view(-1), w=p.w, wpa=p.wpa, wpb=p.wpb, stride=it['stride'],
+                     pad=it.get('pad', 0)) for it, p in zip(self.items, self._bufs)]
+
+    def prepare(self):
+        key = self._current_key()
         if key != self._key:
-            ents = []
-            for it, p in zip(self.items, self._bufs):
-                ents.append(dict(v=it['v'].data, g=it['g'].data.view(-1), w=p.w, wpa=p.wpa, wpb=p.wpb,
-                                 stride=it['stride'], pad=it.get('pad', 0)))
-            K.weight_norm_fwd(ents)
+            K.weight_norm_fwd(self._entries())
             self._key = key
         return self._bufs
 
@@ -167,6 +171,28 @@ class WNGroup(object):
         if ents:
             K.weight_norm_bwd(ents)
         return outs
+
+
+def prepare_groups(groups):
+    """materialise every STALE group of `groups` with ONE weight-norm launch (a network's blocks are otherwise prepared one
+    launch each at their first use; a launch of this size is ~25 us of latency whatever it carries).  Groups on different
+    devices, or with nothing stale, fall back to / cost nothing."""
+    stale, ents = [], []
+    for gr in groups:
+        if not gr.items:
+            continue
+        key = gr._current_key()
+        if key != gr._key:
+            stale.append((gr, key))
+            ents += gr._entries()
+    if ents:
+        if len(set(e['v'].device for e in ents)) > 1:
+            for gr, _ in stale:
+                gr.prepare()
+            return
+        K.weight_norm_fwd(ents)
+        for gr, key in stale:
+            gr._key = key
 
 
 def _zeros_like_list(tensors):

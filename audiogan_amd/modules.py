@@ -9,6 +9,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
+from .common import prepare_groups
 from .ops import ConvSpec
 
 
@@ -179,8 +180,7 @@ class Generator(nn.Module):
         module on two streams calls it before the fork: otherwise the first forward to be ENQUEUED would rewrite
         the shared weight buffers on its stream while the other stream's forward (which finds the cache key
         up to date and skips the rewrite) reads them unordered."""
-        self._front.group.prepare()
-        self._trunk.group.prepare()
+        prepare_groups([self._front.group, self._trunk.group])      # ONE launch for both blocks
 
     def early_params(self):
         """parameters whose gradients are complete BEFORE the recurrent front's backward runs (the conv trunk,
@@ -194,6 +194,7 @@ class Generator(nn.Module):
         backward later with ``cut['x'].backward(cut['x_cut'].grad)`` (train.g_backward_early / _late)."""
         fs, ns, es = self._frame_size, self._noise_size, self._embed_size
         dev = c.device
+        self.prepare_weights()
         if z is None:
             nframes = div_roundup(length, fs)
             z = torch.randn(batch_size, nframes, ns, device=dev)
@@ -309,7 +310,13 @@ class Discriminator(nn.Module):
         conv = set(id(p) for p in self.cnn.parameters())
         return [p for p in self.parameters() if id(p) not in conv]
 
+    def prepare_weights(self):
+        """materialise the weight-normed weights of the conv stack and the heads with ONE launch (no-op when they are up to
+        date); features() / classify() called on their own prepare their block at its first use"""
+        prepare_groups([self._stack.group, self._head.group])
+
     def forward(self, x, length, c, percent_used=0.1):
+        self.prepare_weights()
         acts, lens_list = self.features(x, length)
         n = lens_list[-1]
         return self.classify(acts[-1], n, c), list(acts), lens_list, n
