@@ -626,3 +626,42 @@ extern "C" int ag_time_moments_bwd(const float* h, int64_t bs, int64_t cs, const
   AG_CHECK_LAUNCH("ag_time_moments_bwd");
   return AG_OK;
 }
+
+// ------------------------------------------------------------------------------------------
+// Batched 2-D transpose through LDS: out[b][j][i] = in[b][i][j], inner index contiguous on both sides.  The critic hands
+// its conv features [B,C,T'] to the biLSTM as [T',B,C] (audiogan.py:542) and back (:544 under .backward()): as a strided
+// elementwise copy one side of that is uncoalesced (45 us for 33 MB); 32 x 32 tiles staged in LDS read and write rows.
+//   in : element (b, i, j) at in  + b*ibs + i*irs + j        (i < R, j < Cc)
+//   out: element (b, j, i) at out + b*obs + j*ors + i
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void transpose_batched_kernel(const float* __restrict__ in, int64_t ibs, int64_t irs,
+                                                                float* __restrict__ out, int64_t obs, int64_t ors,
+                                                                int R, int Cc) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.z, i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
+  const float* src = in + (int64_t)b * ibs;
+  float* dst = out + (int64_t)b * obs;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int i = i0 + ty + 8 * k, j = j0 + tx;
+    tile[ty + 8 * k][tx] = (i < R && j < Cc) ? src[(int64_t)i * irs + j] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int j = j0 + ty + 8 * k, i = i0 + tx;
+    if (j < Cc && i < R) dst[(int64_t)j * ors + i] = tile[tx][ty + 8 * k];
+  }
+}
+
+extern "C" int ag_transpose_batched(const float* in, int64_t ibs, int64_t irs, float* out, int64_t obs, int64_t ors,
+                                    int B, int R, int Cc, void* stream) {
+  AG_REQUIRE(in && out && B > 0 && R > 0 && Cc > 0 && B <= 65535, "ag_transpose_batched: bad args");
+  AG_REQUIRE(irs >= Cc && ors >= R, "ag_transpose_batched: a row pitch is smaller than its row");
+  AG_REQUIRE(ag_cdiv(R, 32) <= 65535, "ag_transpose_batched: too many rows");
+  hipLaunchKernelGGL(transpose_batched_kernel, dim3(ag_cdiv(Cc, 32), ag_cdiv(R, 32), B), dim3(256), 0, (hipStream_t)stream,
+                     in, ibs, irs, out, obs, ors, R, Cc);
+  AG_CHECK_LAUNCH("ag_transpose_batched");
+  return AG_OK;
+}

@@ -465,6 +465,29 @@ def act_bwd(dy, y, dx, act, slope=LEAKY_SLOPE):
     check(lib.ag_act_bwd(_p(dy), _p(y), _p(dx), dy.numel(), act, slope, _stream()), 'ag_act_bwd')
 
 
+def bct_to_tbc(x, out=None):
+    """[B,C,T] (any batch / channel pitch, time contiguous) -> contiguous [T,B,C] (ag_transpose_batched)"""
+    _chk(x, 'x')
+    B, Cc, T = x.shape
+    assert x.stride(2) == 1
+    if out is None:
+        out = torch.empty(T, B, Cc, device=x.device)
+    check(lib.ag_transpose_batched(_p(x), x.stride(0), x.stride(1), _p(out), Cc, B * Cc, B, Cc, T, _stream()),
+          'ag_transpose_batched')
+    return out
+
+
+def tbc_to_bct(x, out=None):
+    """contiguous [T,B,C] -> contiguous [B,C,T] (ag_transpose_batched)"""
+    _chk(x, 'x')
+    T, B, Cc = x.shape
+    assert x.is_contiguous()
+    if out is None:
+        out = torch.empty(B, Cc, T, device=x.device)
+    check(lib.ag_transpose_batched(_p(x), Cc, B * Cc, _p(out), Cc * T, T, B, T, Cc, _stream()), 'ag_transpose_batched')
+    return out
+
+
 def axpby(x, y, a, b):
     """y = a*x + b*y (contiguous)"""
     _chk(x, 'x'); _chk(y, 'y')

@@ -297,9 +297,9 @@ class Discriminator(nn.Module):
         ss, es = self._state_size, self._embed_size
         b, tq = a.size(0), a.size(2)
         # layer 0 sees cat([features_t, c]) at every frame (:541): c goes in as the layer's time-invariant input
-        seq = a.permute(2, 0, 1)
+        seq = ops.TimeMajorFn.apply(a)                    # [T',B,C], contiguous
         for layer in range(self._num_layers):
-            seq = ops.LSTMSeqFn.apply(seq.contiguous(), n, 2, c if layer == 0 else None, *self._rnn_weights(layer))
+            seq = ops.LSTMSeqFn.apply(seq, n, 2, c if layer == 0 else None, *self._rnn_weights(layer))
         # the heads are per-row: keep the LSTM's (time, clip) row order and transpose only the logits
         logits = ops.DHeadFn.apply(seq.reshape(tq * b, ss), self._head, *self._head.group.params())
         return logits.view(tq, b).t()

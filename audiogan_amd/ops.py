@@ -247,6 +247,21 @@ class DHead(object):
         self.group = WNGroup()
 
 
+class TimeMajorFn(torch.autograd.Function):
+    """[B,C,T] -> contiguous [T,B,C] (what the biLSTM reads, audiogan.py:542) and the gradient's way back, each ONE tiled
+    transpose launch instead of a strided elementwise copy"""
+
+    @staticmethod
+    def forward(ctx, a):
+        if a.stride(2) != 1:
+            a = a.contiguous()
+        return K.bct_to_tbc(a)
+
+    @staticmethod
+    def backward(ctx, g):
+        return K.tbc_to_bct(g.contiguous())
+
+
 _EYE = {}
 
 

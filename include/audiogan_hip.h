@@ -246,6 +246,12 @@ int ag_bind_workspace(float* ws, int64_t numel);
 int64_t ag_conv1d_wgrad_ws_numel(int B, int A, int Lsh, int C, int K);
 int64_t ag_gemm_ws_numel(int M, int N, int K, int act);
 
+/* Batched 2-D transpose through LDS: out[b][j][i] = in[b][i][j] for i < R, j < Cc; in element (b,i,j) at in + b*ibs + i*irs + j,
+ * out element (b,j,i) at out + b*obs + j*ors + i (inner index contiguous on both sides).  The critic's conv features
+ * [B,C,T'] -> time-major [T',B,C] for the biLSTM (audiogan.py:542) and the gradient's way back. */
+int ag_transpose_batched(const float* in, int64_t ibs, int64_t irs, float* out, int64_t obs, int64_t ors, int B, int R,
+                         int Cc, void* stream);
+
 /* Deferred second stages.  Between ag_defer_reduces(1) and ag_flush_reduces() every two-stage reduction of the calling
  * thread (conv weight gradients, bias / channel sums - not the split-K GEMM, whose second stage carries an epilogue) only
  * records its second stage; the flush sums all recorded outputs in ONE launch, each in the order its own launch would use

@@ -334,6 +334,22 @@ def gfront_persist_ok(B, S, fs, dev):
     return False
 
 
+def bct_to_tbc(x, out=None):
+    r = x.permute(2, 0, 1).contiguous()
+    if out is not None:
+        out.copy_(r)
+        return out
+    return r
+
+
+def tbc_to_bct(x, out=None):
+    r = x.permute(1, 2, 0).contiguous()
+    if out is not None:
+        out.copy_(r)
+        return out
+    return r
+
+
 class deferred_reduces(object):
     """(no second stages in the model)"""
 

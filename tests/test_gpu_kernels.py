@@ -269,6 +269,23 @@ def test_gemm_leaky_gate_epilogue(K, shape, ta, tb, prec):
     close(Cd, ref, rtol=2e-3 if prec == 'bf16' else 1e-3, atol=1e-4 if prec == 'bf16' else 1e-5)
 
 
+@pytest.mark.parametrize('B,C,T', [(128, 512, 128), (3, 70, 33), (1, 1, 1), (5, 32, 100)])
+def test_time_major_transposes(K, B, C, T):
+    """[B,C,T] <-> [T,B,C] through the tiled transpose (ag_transpose_batched), also from a channel slice of a wider slab"""
+    gen = torch.Generator().manual_seed(12)
+    wide = torch.randn(B, C + 3, T, generator=gen).cuda()
+    x = wide[:, 1:C + 1]
+    y = K.bct_to_tbc(x)
+    assert y.is_contiguous() and torch.equal(y, x.permute(2, 0, 1))
+    back = K.tbc_to_bct(y)
+    assert back.is_contiguous() and torch.equal(back, x)
+    from audiogan_amd import ops
+    a = x.clone().requires_grad_(True)
+    g = torch.randn(T, B, C, generator=gen).cuda()
+    ops.TimeMajorFn.apply(a).backward(g)
+    assert torch.equal(a.grad, g.permute(1, 2, 0))
+
+
 def test_gemm_strided_views(K):
     gen = torch.Generator().manual_seed(7)
     big = torch.randn(64, 456, generator=gen)
