@@ -42,6 +42,8 @@ class OptDesc(C.Structure):
 # name -> (restype, argtypes); must list EVERY symbol of include/audiogan_hip.h
 SIGNATURES = {
     'ag_abi_version': (C.c_int, []),
+    'ag_bce_logits_fwd_strided': (C.c_int, [vp, i64, i64, C.c_float, vp, vp, vp, vp, C.c_float, C.c_int, C.c_int, vp]),
+    'ag_bce_logits_bwd_strided': (C.c_int, [vp, i64, i64, C.c_float, vp, vp, vp, C.c_float, vp, i64, i64, C.c_int, C.c_int, vp]),
     'ag_transpose_batched': (C.c_int, [vp, i64, i64, vp, i64, i64, C.c_int, C.c_int, C.c_int, vp]),
     'ag_defer_reduces': (C.c_int, [C.c_int]),
     'ag_flush_reduces': (C.c_int, [vp]),
@@ -133,7 +135,7 @@ def _load():
     return lib
 
 
-ABI_VERSION = 7      # what this package was written against (csrc/api.hip: ag_abi_version)
+ABI_VERSION = 8      # what this package was written against (csrc/api.hip: ag_abi_version)
 
 lib = _load()
 if lib.ag_abi_version() != ABI_VERSION:

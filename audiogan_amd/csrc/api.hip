@@ -16,7 +16,7 @@ void ag_set_error(const char* fmt, ...) {
 // bumped whenever an entry point, a struct layout or the meaning of an argument changes (round 3: sticky persistent status,
 // AG_ACT_LEAKY_GATE, AG_PREC_F32X3, GRU front, Conv2DLSTMCell pieces): audiogan_amd/_lib.py refuses a library of another
 // version, so Python that relies on a new mode can never drive an older build
-extern "C" int ag_abi_version(void) { return 7; }
+extern "C" int ag_abi_version(void) { return 8; }
 extern "C" const char* ag_arch(void) { return "gfx950"; }
 extern "C" const char* ag_last_error(void) { return g_err; }
 

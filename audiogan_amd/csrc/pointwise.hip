@@ -268,6 +268,82 @@ extern "C" int ag_bce_logits_bwd(const float* x, int ldx, float target, const in
   return AG_OK;
 }
 
+// The same loss in ONE launch on logits of any (row, column) pitch, with an optional target per row: the critic iteration
+// scores real and fake clips in one pass (targets 0.9 / 0 per row), and the logits arrive as a transposed view
+// [B,T'] of the heads' [T',B] rows - no contiguous copy, no zero fill, no finishing launch, no slicing in autograd.
+//   per[b] = sum_{t < n_b} bce(x[b,t], tgt_b);   loss[0] = scale * sum_b per[b] / n_b      (written, not accumulated)
+// One workgroup: wave w takes rows w, w + 16, ...; the 16 partial sums are added in wave order (fixed order).
+__global__ __launch_bounds__(1024) void bce_fwd_one_kernel(const float* __restrict__ x, int64_t sxb, int64_t sxt, float target,
+                                                           const float* __restrict__ tgt_rows,
+                                                           const int64_t* __restrict__ nfr, float* __restrict__ per,
+                                                           float* __restrict__ loss, float scale, int B, int T) {
+  __shared__ float wsum[16];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  float acc = 0.f;
+  for (int b = wid; b < B; b += 16) {
+    const int64_t n = nfr ? nfr[b] : T;
+    const int lim = n < T ? (int)n : T;
+    const float tg = tgt_rows ? tgt_rows[b] : target;
+    float s = 0.f;
+    for (int t = lane; t < lim; t += 64) {
+      const float v = x[(int64_t)b * sxb + (int64_t)t * sxt];
+      const float m = fmaxf(-v, 0.f);
+      s += v - v * tg + m + logf(expf(-m) + expf(-v - m));
+    }
+    s = ag_wave_sum(s);
+    if (lane == 0 && per) per[b] = s;
+    acc += s / (float)n;
+  }
+  if (lane == 0) wsum[wid] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int w = 0; w < 16; ++w) t += wsum[w];
+    loss[0] = scale * t;
+  }
+}
+
+extern "C" int ag_bce_logits_fwd_strided(const float* x, int64_t sxb, int64_t sxt, float target, const float* target_rows,
+                                         const int64_t* nframes_i64, float* per_sample, float* loss, float scale, int B,
+                                         int T, void* stream) {
+  AG_REQUIRE(x && loss && B > 0 && T > 0, "ag_bce_logits_fwd_strided: bad args");
+  hipLaunchKernelGGL(bce_fwd_one_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, x, sxb, sxt, target, target_rows,
+                     nframes_i64, per_sample, loss, scale, B, T);
+  AG_CHECK_LAUNCH("ag_bce_logits_fwd_strided");
+  return AG_OK;
+}
+
+__global__ __launch_bounds__(256) void bce_bwd_strided_kernel(const float* __restrict__ x, int64_t sxb, int64_t sxt,
+                                                              float target, const float* __restrict__ tgt_rows,
+                                                              const int64_t* __restrict__ nfr,
+                                                              const float* __restrict__ gscale, float scale,
+                                                              float* __restrict__ dx, int64_t sdb, int64_t sdt, int B, int T,
+                                                              int tfast) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)B * T) return;
+  // consecutive threads walk whichever index is contiguous in dx
+  const int b = tfast ? (int)(i / T) : (int)(i % B), t = tfast ? (int)(i % T) : (int)(i / B);
+  const int64_t n = nfr ? nfr[b] : T;
+  float g = 0.f;
+  if (t < n) {
+    const float gs = gscale ? gscale[0] : 1.f;
+    g = gs * scale / (float)n * (ag_sigmoid(x[(int64_t)b * sxb + (int64_t)t * sxt]) - (tgt_rows ? tgt_rows[b] : target));
+  }
+  dx[(int64_t)b * sdb + (int64_t)t * sdt] = g;
+}
+
+extern "C" int ag_bce_logits_bwd_strided(const float* x, int64_t sxb, int64_t sxt, float target, const float* target_rows,
+                                         const int64_t* nframes_i64, const float* gscale_dev, float scale, float* dx,
+                                         int64_t sdb, int64_t sdt, int B, int T, void* stream) {
+  AG_REQUIRE(x && dx && B > 0 && T > 0, "ag_bce_logits_bwd_strided: bad args");
+  const int64_t n = (int64_t)B * T;
+  AG_REQUIRE(ag_cdiv64(n, 256) < ((int64_t)1 << 31), "ag_bce_logits_bwd_strided: too large");
+  hipLaunchKernelGGL(bce_bwd_strided_kernel, dim3((unsigned)ag_cdiv64(n, 256)), dim3(256), 0, (hipStream_t)stream, x, sxb,
+                     sxt, target, target_rows, nframes_i64, gscale_dev, scale, dx, sdb, sdt, B, T, sdt == 1 ? 1 : 0);
+  AG_CHECK_LAUNCH("ag_bce_logits_bwd_strided");
+  return AG_OK;
+}
+
 // ------------------------------------------------------------------------------------------
 // activations / axpby on contiguous buffers
 // ------------------------------------------------------------------------------------------

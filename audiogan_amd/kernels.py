@@ -451,6 +451,28 @@ def bce_logits_bwd(x, target, nframes, gscale, scale, dx):
                                 _p(dx), lddx, B, T, _stream()), 'ag_bce_logits_bwd')
 
 
+def bce_logits_fwd_strided(x, target, nframes, per_sample, loss, scale, target_rows=None):
+    """x [B,T] of any strides; per_sample[b] = masked sum (optional); loss[0] = scale * sum_b per_sample[b]/n[b] (written);
+    target_rows: optional [B] targets (else `target` for every row)"""
+    _chk(x, 'x'); _chk(nframes, 'nframes', torch.int64); _chk(per_sample, 'per_sample'); _chk(loss, 'loss')
+    _chk(target_rows, 'target_rows')
+    B, T = x.shape
+    assert target_rows is None or (target_rows.is_contiguous() and target_rows.numel() == B)
+    assert nframes is None or (nframes.is_contiguous() and nframes.numel() == B)
+    assert per_sample is None or (per_sample.is_contiguous() and per_sample.numel() == B)
+    check(lib.ag_bce_logits_fwd_strided(_p(x), x.stride(0), x.stride(1), float(target), _p(target_rows), _p(nframes),
+                                        _p(per_sample), _p(loss), float(scale), B, T, _stream()), 'ag_bce_logits_fwd_strided')
+
+
+def bce_logits_bwd_strided(x, target, nframes, gscale, scale, dx, target_rows=None):
+    _chk(x, 'x'); _chk(dx, 'dx'); _chk(nframes, 'nframes', torch.int64); _chk(gscale, 'gscale'); _chk(target_rows, 'target_rows')
+    B, T = x.shape
+    assert tuple(dx.shape) == (B, T)
+    check(lib.ag_bce_logits_bwd_strided(_p(x), x.stride(0), x.stride(1), float(target), _p(target_rows), _p(nframes),
+                                        _p(gscale), float(scale), _p(dx), dx.stride(0), dx.stride(1), B, T, _stream()),
+          'ag_bce_logits_bwd_strided')
+
+
 def act_fwd(x, y, act, slope=LEAKY_SLOPE):
     _chk(x, 'x'); _chk(y, 'y')
     assert x.is_contiguous() and y.is_contiguous() and x.numel() == y.numel()

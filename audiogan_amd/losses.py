@@ -42,10 +42,23 @@ class _PerSample(torch.autograd.Function):
         return dx * (dper * n.float()).view(B, 1), None, None
 
 
-def masked_bce_mean(logits, target, nframes):
+def masked_bce_mean(logits, target, nframes, scale=None):
     """mean_b( sum_{t<n_b} bce(x[b,t], target) / n_b )  --  the loss assembly at
-    audiogan.py:739-740, :766+:780, :864+:897 in one kernel.  Returns (loss, per_sample_sums)."""
-    return ops.BCEFn.apply(logits, float(target), nframes)
+    audiogan.py:739-740, :766+:780, :864+:897 in one kernel.  Returns (loss, per_sample_sums).  ``target``: a float, or
+    a [B] tensor of per-row targets; ``scale``: replaces the 1 / B of the mean (e.g. 2 / B when real and fake clips are
+    scored in one call and the loss is the SUM of their means)."""
+    return ops.BCEFn.apply(logits, target if torch.is_tensor(target) else float(target), nframes, scale)
+
+
+_TARGET_ROWS = {}
+
+
+def real_fake_targets(batch, device, real=0.9, fake=0.0):
+    """cached [2 * batch] per-row targets: `real` for the first half, `fake` for the second"""
+    key = (int(batch), str(device), float(real), float(fake))
+    if key not in _TARGET_ROWS:
+        _TARGET_ROWS[key] = torch.cat([torch.full((batch,), float(real)), torch.full((batch,), float(fake))]).to(device)
+    return _TARGET_ROWS[key]
 
 
 def length_mask(size, length):

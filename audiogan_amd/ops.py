@@ -355,26 +355,35 @@ from .recurrent import LSTMSeqFn, GFront, GFrontFn, GRUFront, GRUFrontFn  # noqa
 # masked BCE-with-logits, / nframes, mean over batch
 # --------------------------------------------------------------------------------------
 class BCEFn(torch.autograd.Function):
-    """loss = mean_b( sum_{t<n_b} bce(x[b,t], target) / n_b ); also returns the per-sample sums."""
+    """loss = scale * sum_b( sum_{t<n_b} bce(x[b,t], target_b) / n_b ), scale = 1 / B unless given; also returns the
+    per-sample sums.  x: [B,T] of ANY strides (the heads hand over a transposed view: no copy); target: a float or a [B]
+    tensor of per-row targets.  One launch forward, one backward (ag_bce_logits_*_strided)."""
 
     @staticmethod
-    def forward(ctx, x, target, nframes):
+    def forward(ctx, x, target, nframes, scale=None):
         B, T = x.shape
-        x = x.contiguous()
+        rows = target if torch.is_tensor(target) else None
+        tgt = 0.0 if rows is not None else float(target)
+        if rows is not None:
+            rows = rows.to(device=x.device, dtype=torch.float32).contiguous()
+        if nframes is not None:
+            nframes = nframes.contiguous()
+        sc = 1.0 / B if scale is None else float(scale)
         per = torch.empty(B, device=x.device)
-        loss = torch.zeros(1, device=x.device)
-        K.bce_logits_fwd(x, target, nframes, per, loss, 1.0 / B)
-        ctx.target = target
-        ctx.save_for_backward(x, nframes if nframes is not None else x.new_empty(0))
-        ctx.has_n = nframes is not None
+        loss = torch.empty(1, device=x.device)
+        K.bce_logits_fwd_strided(x, tgt, nframes, per, loss, sc, target_rows=rows)
+        ctx.target, ctx.scale = tgt, sc
+        ctx.save_for_backward(x, nframes if nframes is not None else x.new_empty(0),
+                              rows if rows is not None else x.new_empty(0))
+        ctx.has_n, ctx.has_rows = nframes is not None, rows is not None
         ctx.mark_non_differentiable(per)
         return loss.view(()), per
 
     @staticmethod
     def backward(ctx, dloss, _dper):
-        x, nfr = ctx.saved_tensors
-        B, T = x.shape
-        dx = torch.empty_like(x)
+        x, nfr, rows = ctx.saved_tensors
+        dx = torch.empty_like(x)          # (keeps x's memory layout: the gradient flows back through the same view)
         g = dloss.contiguous().view(1).float()
-        K.bce_logits_bwd(x, ctx.target, nfr if ctx.has_n else None, g, 1.0 / B, dx)
-        return dx, None, None
+        K.bce_logits_bwd_strided(x, ctx.target, nfr if ctx.has_n else None, g, ctx.scale, dx,
+                                 target_rows=rows if ctx.has_rows else None)
+        return dx, None, None, None

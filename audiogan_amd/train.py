@@ -6,7 +6,7 @@ import torch
 from . import kernels as K
 from .common import frozen
 from .extras import adversarial_movement_d, adversarially_sample_z, calc_dists, feature_penalty
-from .losses import length_mask, masked_bce_mean, only_stopper_trains, stopper_surrogate_loss
+from .losses import length_mask, masked_bce_mean, only_stopper_trains, real_fake_targets, stopper_surrogate_loss
 
 _SIDE = {}
 
@@ -61,13 +61,16 @@ def d_step(g, d, opt_d, real, real_len, c, z, noise_real, noise_fake, dgradclip=
         # 2B clips halves the number of strictly sequential biLSTM steps of the critic iteration
         cls, _, _, nf = d(torch.cat([real + noise_real, fake], 0), torch.cat([real_len.to(fake_len.device), fake_len], 0),
                           torch.cat([c, c], 0))
-        cls_d, cls_g, nf_d, nf_g = cls[:B], cls[B:], nf[:B], nf[B:]
+        cls_d, cls_g = cls[:B], cls[B:]
+        # mean over the real clips + mean over the fake clips = (1 / B) * the sum over all 2B rows, targets 0.9 / 0 per row:
+        # ONE loss launch forward and backward (no slices for autograd to reassemble)
+        loss, _ = masked_bce_mean(cls, real_fake_targets(B, cls.device), nf, scale=1.0 / B)
     else:
         cls_d, _, _, nf_d = d(real + noise_real, real_len, c)
         cls_g, _, _, nf_g = d(fake, fake_len, c)
-    loss_d, _ = masked_bce_mean(cls_d, 0.9, nf_d.contiguous())
-    loss_g, _ = masked_bce_mean(cls_g, 0.0, nf_g.contiguous())
-    loss = loss_d + loss_g
+        loss_d, _ = masked_bce_mean(cls_d, 0.9, nf_d.contiguous())
+        loss_g, _ = masked_bce_mean(cls_g, 0.0, nf_g.contiguous())
+        loss = loss_d + loss_g
     opt_d.zero_grad()
     loss.backward()
     scale = grad_hook() if grad_hook is not None else 1.0
@@ -109,13 +112,13 @@ def d_backward(g, d, opt_d, real, real_len, c, z, noise_real, noise_fake, stop='
     if batch_real_fake and fake.size(1) == real.size(1):
         cls, _, _, nf = d(torch.cat([real + noise_real, fake], 0),
                           torch.cat([real_len.to(fake_len.device), fake_len], 0), torch.cat([c, c], 0))
-        cls_d, cls_g, nf_d, nf_g = cls[:B], cls[B:], nf[:B], nf[B:]
+        loss, _ = masked_bce_mean(cls, real_fake_targets(B, cls.device), nf, scale=1.0 / B)     # (see d_step)
     else:
         cls_d, _, _, nf_d = d(real + noise_real, real_len, c)
         cls_g, _, _, nf_g = d(fake, fake_len, c)
-    loss_d, _ = masked_bce_mean(cls_d, 0.9, nf_d.contiguous())
-    loss_g, _ = masked_bce_mean(cls_g, 0.0, nf_g.contiguous())
-    loss = loss_d + loss_g
+        loss_d, _ = masked_bce_mean(cls_d, 0.9, nf_d.contiguous())
+        loss_g, _ = masked_bce_mean(cls_g, 0.0, nf_g.contiguous())
+        loss = loss_d + loss_g
     opt_d.zero_grad()
     loss.backward()
     return loss.detach()
@@ -148,9 +151,7 @@ def d_backward_early(g, d, opt_d, real, real_len, c, z, noise_real, noise_fake, 
     a_cut = acts[-1].detach().requires_grad_(True)
     nf = lens_list[-1]
     cls = d.classify(a_cut, nf, torch.cat([c, c], 0))
-    loss_d, _ = masked_bce_mean(cls[:B], 0.9, nf[:B].contiguous())
-    loss_g, _ = masked_bce_mean(cls[B:], 0.0, nf[B:].contiguous())
-    loss = loss_d + loss_g
+    loss, _ = masked_bce_mean(cls, real_fake_targets(B, cls.device), nf, scale=1.0 / B)     # (see d_step)
     opt_d.zero_grad()
     loss.backward()
     keep['acts'], keep['a_cut'] = acts, a_cut

@@ -397,6 +397,16 @@ int ag_bce_logits_bwd(const float* x, int ldx, float target, const int64_t* nfra
                       const float* gscale_dev, float scale, float* dx, int lddx, int B, int T,
                       void* stream);
 
+/* The same loss on logits of any (row, column) pitch (element strides sxb, sxt), an optional target per row (target_rows,
+ * NULL = `target` for every row) and loss[0] WRITTEN (= scale * sum_b per[b] / n[b]) by one launch; per_sample may be NULL.
+ * The critic iteration scores real and fake clips in one pass (audiogan.py:739-740 + :766 + :780: targets 0.9 and 0). */
+int ag_bce_logits_fwd_strided(const float* x, int64_t sxb, int64_t sxt, float target, const float* target_rows,
+                              const int64_t* nframes_i64, float* per_sample, float* loss, float scale, int B, int T,
+                              void* stream);
+int ag_bce_logits_bwd_strided(const float* x, int64_t sxb, int64_t sxt, float target, const float* target_rows,
+                              const int64_t* nframes_i64, const float* gscale_dev, float scale, float* dx, int64_t sdb,
+                              int64_t sdt, int B, int T, void* stream);
+
 /* ---------------------------------------------------------------------------
  * Elementwise helpers
  * ------------------------------------------------------------------------- */

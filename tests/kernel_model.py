@@ -257,6 +257,26 @@ def bce_logits_bwd(x, target, nframes, gscale, scale, dx):
     dx.copy_(gs * scale / n.float().view(B, 1) * (torch.sigmoid(x) - target) * mask)
 
 
+def bce_logits_fwd_strided(x, target, nframes, per_sample, loss, scale, target_rows=None):
+    B, T = x.shape
+    n = nframes if nframes is not None else torch.full((B,), T, dtype=torch.long)
+    mask = (torch.arange(T).view(1, T) < n.view(B, 1)).float()
+    tg = target_rows.view(B, 1) if target_rows is not None else target
+    per = (_bce_elem(x, tg) * mask).sum(1)
+    if per_sample is not None:
+        per_sample.copy_(per)
+    loss.copy_((scale * (per / n.float()).sum()).view(1))
+
+
+def bce_logits_bwd_strided(x, target, nframes, gscale, scale, dx, target_rows=None):
+    B, T = x.shape
+    n = nframes if nframes is not None else torch.full((B,), T, dtype=torch.long)
+    mask = (torch.arange(T).view(1, T) < n.view(B, 1)).float()
+    gs = gscale.view(()) if gscale is not None else 1.0
+    tg = target_rows.view(B, 1) if target_rows is not None else target
+    dx.copy_(gs * scale / n.float().view(B, 1) * (torch.sigmoid(x) - tg) * mask)
+
+
 def act_fwd(x, y, act, slope=LEAKY_SLOPE):
     y.copy_(_act(x, act, slope))
 

@@ -391,6 +391,40 @@ def test_bce(K):
             close(dx, dx_r, rtol=1e-5, atol=1e-9)
 
 
+@pytest.mark.parametrize('B,T', [(128, 128), (5, 37), (1, 1), (70, 200)])
+def test_bce_strided_rows(K, B, T):
+    """the one-launch loss on a TRANSPOSED view (what the heads hand over), with per-row targets and a caller's scale:
+    against torch's binary_cross_entropy_with_logits in float64, forward (per-sample sums, loss WRITTEN over garbage) and
+    backward (into a gradient of the same transposed layout); and through ops.BCEFn / autograd"""
+    gen = torch.Generator().manual_seed(13)
+    base = torch.randn(T, B, generator=gen) * 4                    # memory layout [T,B]; the op sees [B,T]
+    n = torch.randint(1, T + 1, (B,), generator=gen)
+    rows = torch.where(torch.arange(B) < (B + 1) // 2, 0.9, 0.0)
+    mask = (torch.arange(T).view(1, T) < n.view(B, 1)).double()
+    for tr, tgt, nn_ in ((rows, 0.0, n), (None, 0.5, n), (rows, 0.0, None)):
+        x64 = base.t().double().requires_grad_(True)
+        tg = (tr.view(B, 1).expand(B, T) if tr is not None else torch.full((B, T), tgt)).double()
+        m = mask if nn_ is not None else torch.ones(B, T, dtype=torch.float64)
+        nn64 = nn_.double() if nn_ is not None else torch.full((B,), float(T), dtype=torch.float64)
+        per64 = (F.binary_cross_entropy_with_logits(x64, tg, reduction='none') * m).sum(1)
+        loss64 = (2.0 / B) * (per64 / nn64).sum()
+        loss64.backward()
+        xd = dev(base).t()                                         # strides (1, B)
+        per, loss = torch.empty(B).cuda(), torch.full((1,), float('nan')).cuda()
+        K.bce_logits_fwd_strided(xd, tgt, dev(nn_), per, loss, 2.0 / B, target_rows=dev(tr))
+        close(per, per64.float(), rtol=1e-5, atol=1e-6); close(loss, loss64.float().view(1), rtol=1e-5)
+        dx = torch.empty_like(xd)
+        assert dx.stride() == xd.stride()
+        K.bce_logits_bwd_strided(xd, tgt, dev(nn_), dev(torch.tensor([0.7])), 2.0 / B, dx, target_rows=dev(tr))
+        close(dx, 0.7 * x64.grad.float(), rtol=1e-5, atol=1e-9)
+        from audiogan_amd import ops
+        xa = dev(base).requires_grad_(True)
+        l2, _ = ops.BCEFn.apply(xa.t(), dev(tr) if tr is not None else tgt, dev(nn_), 2.0 / B)
+        l2.backward()
+        close(l2.view(1), loss64.float().view(1), rtol=1e-5)
+        close(xa.grad, x64.grad.float().t(), rtol=1e-5, atol=1e-9)
+
+
 def test_elementwise(K):
     gen = torch.Generator().manual_seed(11)
     x, dy = torch.randn(100003, generator=gen), torch.randn(100003, generator=gen)
