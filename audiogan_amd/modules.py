@@ -207,7 +207,7 @@ class Generator(nn.Module):
             assert stop == 'never'
             t_eff = nframes
             stops = None
-            out_len = torch.full((batch_size,), nframes * fs, dtype=torch.long, device=dev)
+            out_len, never = _never_stop_constants(batch_size, nframes, fs, dev)
         else:
             if stop is None:
                 stops = torch.bernoulli(torch.sigmoid(s.detach())).long()
@@ -221,13 +221,25 @@ class Generator(nn.Module):
             out_len = first * fs
         if t_eff < nframes:
             x, s = x[:, :t_eff * fs], s[:, :t_eff]
-        stop_list = ([stops[:, t:t + 1] for t in range(t_eff)] if stops is not None else
-                     list(torch.zeros(t_eff, batch_size, 1, dtype=torch.long, device=dev).unbind(0)))
+        stop_list = [stops[:, t:t + 1] for t in range(t_eff)] if stops is not None else list(never)
         if cut is not None:
             cut['x'] = x
             x = cut['x_cut'] = x.detach().requires_grad_(True)
         wave = ops.GTrunkFn.apply(x, self._trunk, *self._trunk.group.params())
         return wave, s, stop_list, out_len
+
+
+_NEVER = {}
+
+
+def _never_stop_constants(batch_size, nframes, fs, dev):
+    """what ``stop='never'`` returns besides the audio: the full length per clip and the all-zero stop draws.  Constants of
+    (batch, frames, frame size, device), built once (two fills per forward otherwise) - treat them as read-only."""
+    key = (int(batch_size), int(nframes), int(fs), str(dev))
+    if key not in _NEVER:
+        _NEVER[key] = (torch.full((batch_size,), nframes * fs, dtype=torch.long, device=dev),
+                       tuple(torch.zeros(nframes, batch_size, 1, dtype=torch.long, device=dev).unbind(0)))
+    return _NEVER[key]
 
 
 class Discriminator(nn.Module):
@@ -269,9 +281,9 @@ class Discriminator(nn.Module):
     def _stride_prods(self, dev):
         # built once per device (a host->device copy inside forward would break hipGraph capture)
         t = getattr(self, '_prods', None)
-        if t is None or t.device != dev:
-            t = torch.tensor(list(_cumprod([s for _, s, _ in self.cnn_struct])), device=dev).view(-1, 1)
-            self._prods = t
+        if t is None or t[0].device != dev:
+            p = torch.tensor(list(_cumprod([s for _, s, _ in self.cnn_struct])), device=dev).view(-1, 1)
+            t = self._prods = (p, p - 1)
         return t
 
     def _rnn_weights(self, layer):
@@ -286,8 +298,8 @@ class Discriminator(nn.Module):
         length = length.to(x.device).long()
         # nframes after layer i = ceil(... ceil(length / s_1) ... / s_i) = ceil(length / (s_1 ... s_i)):
         # all layers in one broadcast op instead of one tiny kernel pair per layer (:533)
-        prods = self._stride_prods(x.device)
-        lens_all = (length.view(1, -1) + prods - 1) // prods
+        prods, prods_m1 = self._stride_prods(x.device)
+        lens_all = torch.div(length.view(1, -1) + prods_m1, prods, rounding_mode='floor')
         lens_list = [lens_all[i] for i in range(lens_all.size(0))]
         acts = ops.DConvStackFn.apply(x, self._stack, lens_list, *self._stack.group.params())
         return acts, lens_list

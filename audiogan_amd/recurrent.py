@@ -214,7 +214,6 @@ class GFrontFn(torch.autograd.Function):
         gates = [torch.empty(T, B, 4 * S, device=dev) for _ in range(nl)]
         hs = [torch.empty(T, B, S, device=dev) for _ in range(nl)]
         cs = [torch.empty(T + 1, B, S, device=dev) for _ in range(nl)]
-        h0 = torch.zeros(B, S, device=dev)
         for l in range(nl):
             cs[l][0].zero_()
         bsum = [lw[l][2] + lw[l][3] for l in range(nl)]
@@ -224,6 +223,7 @@ class GFrontFn(torch.autograd.Function):
         K.gemm(zc.contiguous().view(T * B, Fz), wz, gates[0].view(T * B, 4 * S), tb=True, bias=bsum[0])
         fused0 = K.lstm_step_ok(B, S, x[:, :fs], wx)
         persist = nl == 1 and K.gfront_persist_ok(B, S, fs, dev)
+        h0 = None if persist else torch.zeros(B, S, device=dev)      # (only the per-frame path reads it)
         if persist:
             # the whole frame loop (LSTMCell step + projection, fed back) in ONE launch, weights resident in registers
             K.gfront_fwd_persist(gates[0], wx, lw[0][1], pw, pb, hs[0], cs[0], x)
