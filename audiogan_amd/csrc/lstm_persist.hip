@@ -68,7 +68,7 @@ static PersistCtl ps_ctl(void* ws) {
 struct PersistDir {
   float* pre;          // [T,B,4H] in: x-projection (+ biases); out: activated gates
   const float* whh;    // [4H,H]
-  float* c_all;        // [T+1,B,H]  (c_all[0] = 0 on entry)
+  float* c_all;        // [T+1,B,H]  (c_all[0] is written 0 by the launch)
   const float* cb;     // optional [B,4H] time-invariant part of the pre-activations
 };
 
@@ -297,6 +297,7 @@ __global__ __launch_bounds__(512) void lstm_persist_fwd_kernel(const PersistFwdP
         float* pr = D.pre + ((int64_t)t * B + em) * 4 * H + eu;
         pr[0] = sv_ig; pr[H] = sv_fg; pr[2 * H] = sv_gg; pr[3 * H] = sv_og;
       }
+      if (k == 0) D.c_all[(int64_t)em * H + eu] = 0.f;         // c_0 = 0: written here, so the caller need not fill it
       D.c_all[((int64_t)(k + 1) * B + em) * H + eu] = creg;
       p.y[((int64_t)t * B + em) * p.ndir * H + (int64_t)dir * H + eu] = sv_y;
     }
@@ -642,7 +643,7 @@ struct FrontFwdP {
   const float* wp;     // [fs, S]
   const float* bp;     // [fs]
   float* hs;           // [T,B,S]
-  float* cs;           // [T+1,B,S]  (cs[0] = 0 on entry)
+  float* cs;           // [T+1,B,S]  (cs[0] is written 0 by the launch)
   float* x;            // [B, T*fs]
   float* gh;           // GRU cell only: [T,B,3S], the n slot receives W_hn h + b_hn (what the backward needs)
   const float* bhn;    // GRU cell only: b_hh[2S:3S]
@@ -888,6 +889,7 @@ __global__ __launch_bounds__(512) void gfront_persist_fwd_kernel(const FrontFwdP
       } else {
         float* pr = p.gates + ((int64_t)t * B + em) * 4 * S + eu;
         pr[0] = ig; pr[S] = fg; pr[2 * S] = gg; pr[3 * S] = og;
+        if (t == 0) p.cs[(int64_t)em * S + eu] = 0.f;               // c_0 = 0: written here, so the caller need not fill it
         p.cs[((int64_t)(t + 1) * B + em) * S + eu] = creg;
       }
       p.hs[((int64_t)t * B + em) * S + eu] = hreg;
@@ -967,7 +969,7 @@ extern "C" int64_t ag_gfront_persist_ws_bytes(int B, int S, int fs) {
 
 // One launch for the whole frame loop of the Generator front (one LSTMCell layer).  gates [T,B,4S]: in = the z/c
 // part of the pre-activations + both biases, out = activated gates; w_x = W_ih[:, :fs] (row pitch ldwx), w_hh [4S,S],
-// w_p [fs,S], b_p [fs]; outputs hs [T,B,S], cs [T+1,B,S] (cs[0] = 0 on entry), x [B,T*fs].  Shapes: ag_gfront_persist_ok.
+// w_p [fs,S], b_p [fs]; outputs hs [T,B,S], cs [T+1,B,S] (cs[0] is written 0 by the launch), x [B,T*fs].  Shapes: ag_gfront_persist_ok.
 extern "C" int ag_gfront_fwd_persist(float* gates, const float* w_x, int ldwx, const float* w_hh, const float* w_p,
                                      const float* b_p, float* hs, float* cs, float* x, void* ws, int64_t ws_bytes,
                                      int T, int B, int S, int fs, int n_cu, void* stream) {

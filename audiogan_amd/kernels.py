@@ -783,7 +783,7 @@ def _n_cu(dev):
 
 
 def lstm_persist_ok(B, H, ndir, dev):
-    return bool(PERSIST[0] and lib.ag_lstm_persist_ok(B, H, ndir, _n_cu(dev)))
+    return bool(PERSIST[0] and torch.device(dev).type == 'cuda' and lib.ag_lstm_persist_ok(B, H, ndir, _n_cu(dev)))
 
 
 _PERSIST_WS_MIN = 8 << 20      # covers every BASELINE shape (biLSTM at 256 clips, H 768: 3.2 MB; the generator front: 0.7 MB)

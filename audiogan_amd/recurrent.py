@@ -79,7 +79,8 @@ class LSTMSeqFn(torch.autograd.Function):
             else:
                 K.gemm(x2, w_ih.data, g.view(T * B, 4 * H), tb=True, bias=bsum)
             c = torch.empty(T + 1, B, H, device=dev)   # c[k+1] = cell after the k-th processed step
-            c[0].zero_()
+            if not (fused and K.lstm_persist_ok(B, H, ndir, dev)):
+                c[0].zero_()                           # (the persistent launch writes c_0 = 0 itself)
             gates_all.append(g)
             c_all.append(c)
             whh.append(w_hh.data.contiguous())
@@ -214,8 +215,6 @@ class GFrontFn(torch.autograd.Function):
         gates = [torch.empty(T, B, 4 * S, device=dev) for _ in range(nl)]
         hs = [torch.empty(T, B, S, device=dev) for _ in range(nl)]
         cs = [torch.empty(T + 1, B, S, device=dev) for _ in range(nl)]
-        for l in range(nl):
-            cs[l][0].zero_()
         bsum = [lw[l][2] + lw[l][3] for l in range(nl)]
         w_ih0 = lw[0][0]
         wx, wz = w_ih0[:, :fs], w_ih0[:, fs:]
@@ -223,6 +222,9 @@ class GFrontFn(torch.autograd.Function):
         K.gemm(zc.contiguous().view(T * B, Fz), wz, gates[0].view(T * B, 4 * S), tb=True, bias=bsum[0])
         fused0 = K.lstm_step_ok(B, S, x[:, :fs], wx)
         persist = nl == 1 and K.gfront_persist_ok(B, S, fs, dev)
+        if not persist:
+            for l in range(nl):
+                cs[l][0].zero_()                       # (the persistent launch writes c_0 = 0 itself)
         h0 = None if persist else torch.zeros(B, S, device=dev)      # (only the per-frame path reads it)
         if persist:
             # the whole frame loop (LSTMCell step + projection, fed back) in ONE launch, weights resident in registers

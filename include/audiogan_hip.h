@@ -335,7 +335,7 @@ int ag_lstm_seq_bwd_persist(const float* const* gates, const float* const* whh, 
 /* The Generator front's whole frame loop (audiogan.py:428-460, one LSTMCell layer + tanh(proj) fed back) as ONE
  * persistent launch with every weight resident in registers (csrc/lstm_persist.hip).  gates [T,B,4S]: in = the z / c
  * part of the gate pre-activations + both biases (one GEMM over all frames), out = activated gates; w_x = W_ih[:, :fs]
- * (row pitch ldwx), w_hh [4S,S], w_p [fs,S], b_p [fs]; outputs hs [T,B,S], cs [T+1,B,S] (cs[0] = 0 on entry) and the
+ * (row pitch ldwx), w_hh [4S,S], w_p [fs,S], b_p [fs]; outputs hs [T,B,S], cs [T+1,B,S] (cs[0] is written 0 by the launch) and the
  * frames x [B,T*fs].  Supported: (S, fs) in {(1024, 256), (128, 64)}, B <= 64 (ag_gfront_persist_ok); `ws` =
  * ag_gfront_persist_ws_bytes() bytes, used as for ag_lstm_seq_fwd_persist. */
 int ag_gfront_persist_ok(int B, int S, int fs, int n_cu);

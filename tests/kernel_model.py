@@ -349,6 +349,11 @@ def install(monkeypatch):
         monkeypatch.setattr(K, n, globals()[n])
 
 
+def lstm_persist_ok(B, H, ndir, dev):
+    """(the model's lstm_seq_fwd walks the steps: the caller zero-fills c_0)"""
+    return False
+
+
 def gfront_persist_ok(B, S, fs, dev):
     """the persistent Generator-front launch has no CPU model: the host logic takes the frame-by-frame path"""
     return False
