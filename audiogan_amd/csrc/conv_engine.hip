@@ -992,7 +992,14 @@ extern "C" int ag_conv1d_engine(const ag_conv_args* args, void* stream) {
   if (p.Mrows <= 32) return launch_cfg<1, 2, 1, 4>(p, st);   // 32 x 256
   // A transposed conv with pad % stride != 0 has n_cnt = L/s + 1 columns: give the ragged last
   // column(s) to a narrow tile instead of a whole extra 128-wide one.
-  const int tail = p.n_cnt % 128, main_cols = p.n_cnt - tail;
+  // Inside a replayed graph that second launch costs ~20 us of its own (a node never takes less than ~5, and each of its
+  // workgroups stages a full weight panel for one column) while one more column of tiles costs 1 / (number of column
+  // tiles) of the main launch: measured at batch 64, G2-G4.deconv forward 88 / 88 / 76 -> 81 / 81 / 68 us without the
+  // tail, G1.deconv (8 column tiles) 82 -> 84.  So: a tail only when the main launch has fewer than 8 column tiles
+  // (AG_CONV_TAIL=1: always, for A/B runs).
+  static const bool g_tail_always = [] { const char* e = getenv("AG_CONV_TAIL"); return e && e[0] == '1'; }();
+  const int tail0 = p.n_cnt % 128;
+  const int tail = (g_tail_always || (p.n_cnt - tail0) / 128 < 8) ? tail0 : 0, main_cols = p.n_cnt - tail;
   if (p.Mrows <= 64) {
     if (tail > 0 && tail <= 32 && main_cols > 0) {
       ConvP qm = p, qt = p;
