@@ -308,42 +308,43 @@ class DHeadFn(torch.autograd.Function):
         wg = any(ctx.needs_input_grad[2:])
         dws = head.group.zero_dws() if wg else None
         dout = dout.contiguous()
-        w0, w1 = prep[2 * nr].w, prep[2 * nr + 2].w
-        # classifier[2]: out = hmid @ w1^T + b1
-        if wg:
-            K.gemm(dout, hmid, dws[2 * nr + 2], ta=True)
-            K.col_sum(dout, dws[2 * nr + 3])
-        # every LeakyReLU backward rides in the epilogue of the product that feeds it (ACT_LEAKY_GATE: res = the saved
-        # activation), so dh / da below are d(pre-activation) as they leave the GEMM
-        dh = torch.empty_like(hmid)
-        K.gemm(dout, w1, dh, res=hmid, act=ACT_LEAKY_GATE)
-        # classifier[0]
-        if wg:
-            K.gemm(dh, acts[nr], dws[2 * nr], ta=True)
-            K.col_sum(dh, dws[2 * nr + 1])
-        da = torch.empty_like(acts[nr])
-        if nr > 0:
-            K.gemm(dh, w0, da, res=acts[nr], act=ACT_LEAKY_GATE)
-        else:
-            K.gemm(dh, w0, da)
-        fold = K.get_precision() != 'bf16'
-        for i in reversed(range(nr)):
+        with K.deferred_reduces():      # the bias sums' second stages in ONE launch (nothing below reads them)
+            w0, w1 = prep[2 * nr].w, prep[2 * nr + 2].w
+            # classifier[2]: out = hmid @ w1^T + b1
             if wg:
-                K.gemm(da, acts[i], dws[2 * i], ta=True)
-                K.col_sum(da, dws[2 * i + 1])
-            dprev = torch.empty_like(acts[i])
-            # d(input of residual i) = W^T da + da (skip connection) = (W + I)^T da: with the identity folded into the
-            # weight the skip needs no second epilogue tensor and `res` is free for the gate of the residual below
-            # (not in bf16 mode: rounding 1 + w_ii to bfloat16 would lose the diagonal weights; there the skip stays an
-            # exact fp32 add in the epilogue and the gate a pass of its own)
-            wi = prep[2 * i].w
-            if i > 0 and fold:
-                K.gemm(da, wi + _eye(wi), dprev, res=acts[i], act=ACT_LEAKY_GATE)
+                K.gemm(dout, hmid, dws[2 * nr + 2], ta=True)
+                K.col_sum(dout, dws[2 * nr + 3])
+            # every LeakyReLU backward rides in the epilogue of the product that feeds it (ACT_LEAKY_GATE: res = the saved
+            # activation), so dh / da below are d(pre-activation) as they leave the GEMM
+            dh = torch.empty_like(hmid)
+            K.gemm(dout, w1, dh, res=hmid, act=ACT_LEAKY_GATE)
+            # classifier[0]
+            if wg:
+                K.gemm(dh, acts[nr], dws[2 * nr], ta=True)
+                K.col_sum(dh, dws[2 * nr + 1])
+            da = torch.empty_like(acts[nr])
+            if nr > 0:
+                K.gemm(dh, w0, da, res=acts[nr], act=ACT_LEAKY_GATE)
             else:
-                K.gemm(da, wi, dprev, res=da)
-                if i > 0:
-                    K.act_bwd(dprev, acts[i], dprev, ACT_LEAKY)
-            da = dprev
+                K.gemm(dh, w0, da)
+            fold = K.get_precision() != 'bf16'
+            for i in reversed(range(nr)):
+                if wg:
+                    K.gemm(da, acts[i], dws[2 * i], ta=True)
+                    K.col_sum(da, dws[2 * i + 1])
+                dprev = torch.empty_like(acts[i])
+                # d(input of residual i) = W^T da + da (skip connection) = (W + I)^T da: with the identity folded into the
+                # weight the skip needs no second epilogue tensor and `res` is free for the gate of the residual below
+                # (not in bf16 mode: rounding 1 + w_ii to bfloat16 would lose the diagonal weights; there the skip stays an
+                # exact fp32 add in the epilogue and the gate a pass of its own)
+                wi = prep[2 * i].w
+                if i > 0 and fold:
+                    K.gemm(da, wi + _eye(wi), dprev, res=acts[i], act=ACT_LEAKY_GATE)
+                else:
+                    K.gemm(da, wi, dprev, res=da)
+                    if i > 0:
+                        K.act_bwd(dprev, acts[i], dprev, ACT_LEAKY)
+                da = dprev
         grads = head.group.backward(dws) if wg else [None] * (2 * len(head.group.items))
         return (da if ctx.needs_input_grad[0] else None, None) + tuple(grads)
 

@@ -358,24 +358,26 @@ class GFrontFn(torch.autograd.Function):
             dgs, dxt = GFrontFn._bwd_frames(T, B, fs, S, nl, x, dx, ds, gates, cs, lw, wx, pw, sw, hs, dws)
         # parameter gradients, one GEMM per tensor over all frames
         dxt2 = dxt.view(T * B, fs)
-        if wg:
-            K.gemm(dxt2, hs[-1].view(T * B, S), dws[4 * nl], ta=True)
-            K.col_sum(dxt2, dws[4 * nl + 1])
-        for l in range(nl if wg else 0):
-            dg2 = dgs[l].view(T * B, 4 * S)
-            dwih = dws[4 * l]
-            if l == 0:
-                K.gemm(dg2, zc.contiguous().view(T * B, Fz), dwih[:, fs:], ta=True)
+        with K.deferred_reduces():      # the bias sums' second stages in ONE launch (read only after the block)
+            if wg:
+                K.gemm(dxt2, hs[-1].view(T * B, S), dws[4 * nl], ta=True)
+                K.col_sum(dxt2, dws[4 * nl + 1])
+            for l in range(nl if wg else 0):
+                dg2 = dgs[l].view(T * B, 4 * S)
+                dwih = dws[4 * l]
+                if l == 0:
+                    K.gemm(dg2, zc.contiguous().view(T * B, Fz), dwih[:, fs:], ta=True)
+                    if T > 1:
+                        xprev = x.view(B, T, fs)[:, :T - 1].transpose(0, 1).contiguous().view((T - 1) * B, fs)
+                        K.gemm(dgs[0][1:].view((T - 1) * B, 4 * S), xprev, dwih[:, :fs], ta=True)
+                else:
+                    K.gemm(dg2, hs[l - 1].view(T * B, S), dwih, ta=True)
                 if T > 1:
-                    xprev = x.view(B, T, fs)[:, :T - 1].transpose(0, 1).contiguous().view((T - 1) * B, fs)
-                    K.gemm(dgs[0][1:].view((T - 1) * B, 4 * S), xprev, dwih[:, :fs], ta=True)
-            else:
-                K.gemm(dg2, hs[l - 1].view(T * B, S), dwih, ta=True)
-            if T > 1:
-                K.gemm(dgs[l][1:].view((T - 1) * B, 4 * S), hs[l][:T - 1].view((T - 1) * B, S),
-                       dws[4 * l + 1], ta=True)
-            K.col_sum(dg2, dws[4 * l + 2])
-            dws[4 * l + 3].copy_(dws[4 * l + 2])
+                    K.gemm(dgs[l][1:].view((T - 1) * B, 4 * S), hs[l][:T - 1].view((T - 1) * B, S),
+                           dws[4 * l + 1], ta=True)
+                K.col_sum(dg2, dws[4 * l + 2])
+        for l in range(nl if wg else 0):
+            dws[4 * l + 3].copy_(dws[4 * l + 2])              # b_hh sees the same gradient as b_ih
         dzc = None
         if ctx.needs_input_grad[0]:
             dzc = torch.empty(T * B, Fz, device=dev)
