@@ -63,10 +63,12 @@ class LSTMSeqFn(torch.autograd.Function):
         y = torch.empty(T, B, ndir * H, device=dev)
         gates_all, c_all, whh, cbs = [], [], [], []
         fused = K.lstm_step_ok(B, H)
+        # b_ih + b_hh of every direction in ONE launch
+        bsums = torch._foreach_add([w[4 * d + 2].data for d in range(ndir)], [w[4 * d + 3].data for d in range(ndir)])
         for d in range(ndir):
             w_ih, w_hh, b_ih, b_hh = w[4 * d:4 * d + 4]
             g = torch.empty(T, B, 4 * H, device=dev)
-            bsum = b_ih.data + b_hh.data
+            bsum = bsums[d]
             if st is not None:
                 cb = torch.empty(B, 4 * H, device=dev)
                 K.gemm(st, w_ih.data[:, Fx:], cb, tb=True, bias=bsum)
