@@ -19,7 +19,28 @@ def _path(prefix, role, iteration):
     return '%s-%s-%05d' % (prefix, role, iteration)
 
 
+def _plain(x, where='extra'):
+    """``extra`` must survive ``torch.load(weights_only=True)``: tensors and plain Python containers / scalars only (numpy
+    scalars and 0-d arrays are converted; anything else is refused here, at save time, not at the next resume)"""
+    import numbers
+    if x is None or isinstance(x, (bool, int, float, str, bytes)) or torch.is_tensor(x):
+        return x
+    if isinstance(x, dict):
+        return {_plain(k, where): _plain(v, '%s[%r]' % (where, k)) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return type(x)(_plain(v, where + '[...]') for v in x)
+    if hasattr(x, 'dtype') and hasattr(x, 'shape'):          # numpy scalar / array
+        import numpy as np
+        a = np.asarray(x)
+        return a.item() if a.ndim == 0 else torch.from_numpy(np.ascontiguousarray(a))
+    if isinstance(x, numbers.Number):
+        return x.real if isinstance(x, numbers.Real) else complex(x)
+    raise TypeError('checkpoint.save: %s holds a %s; only tensors, numpy arrays and plain Python values can be stored '
+                    '(the file must load with weights_only=True)' % (where, type(x).__name__))
+
+
 def save(prefix, iteration, d=None, g=None, e_g=None, e_d=None, opt_d=None, opt_g=None, extra=None):
+    extra = _plain(extra)
     mods = dict(d=d, g=g, e_g=e_g, e_d=e_d)
     written = []
     for role, key in _ROLES:
@@ -40,9 +61,12 @@ def save(prefix, iteration, d=None, g=None, e_g=None, e_d=None, opt_d=None, opt_
 def _read(path, allow_pickle):
     """state_dict files (what ``save`` writes) load with ``weights_only=True``.  The reference's whole-module pickles
     execute code when unpickled: they are read only when the caller says so (``allow_pickle=True``)."""
+    import pickle
     try:
         return torch.load(path, map_location='cpu', weights_only=True)
-    except Exception as e:  # noqa: BLE001  (pickle.UnpicklingError and friends)
+    except pickle.UnpicklingError as e:
+        # (torch's weights_only unpickler raises UnpicklingError for every global it does not allow; a missing or truncated
+        # file raises FileNotFoundError / EOFError / RuntimeError and is NOT an invitation to unpickle arbitrary code)
         if not allow_pickle:
             raise RuntimeError('%s is not a plain state_dict checkpoint (%s: %s).  If it is a whole-module pickle written '
                                'by the reference (audiogan.py:936-939) and you trust it, pass allow_pickle=True.'

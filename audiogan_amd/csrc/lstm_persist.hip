@@ -38,10 +38,12 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #define PS_HDR_BYTES 8192
 #define PS_TIMEOUT_TICKS 300000000ull   // 3 s of the 100 MHz realtime counter
 
-// test hooks (ag_persist_debug): a shorter timeout and one workgroup that never publishes its flags, to exercise the
-// give-up path on purpose
-static unsigned long long g_ps_timeout = PS_TIMEOUT_TICKS;
-static int g_ps_mute = -1;
+// test hook (ag_persist_debug): a shorter timeout and one workgroup that never publishes its flags, to exercise the
+// give-up path on purpose.  ONE-SHOT and per thread: it arms the NEXT persistent launch issued by the calling thread and
+// is consumed by it (like ag_bind_workspace), so a test that dies between arming and launching cannot leave a 2-ms
+// timeout behind for the rest of the process.
+static thread_local unsigned long long g_ps_timeout = PS_TIMEOUT_TICKS;
+static thread_local int g_ps_mute = -1;
 
 extern "C" int ag_persist_debug(int64_t timeout_ticks, int mute_block) {
   g_ps_timeout = timeout_ticks > 0 ? (unsigned long long)timeout_ticks : PS_TIMEOUT_TICKS;
@@ -62,6 +64,8 @@ static PersistCtl ps_ctl(void* ws) {
   c.hdr = (unsigned*)((char*)ws + PS_STICKY_BYTES);
   c.timeout = g_ps_timeout;
   c.mute = g_ps_mute;
+  g_ps_timeout = PS_TIMEOUT_TICKS;      // consumed: the hook arms one launch
+  g_ps_mute = -1;
   return c;
 }
 

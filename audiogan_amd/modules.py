@@ -171,8 +171,8 @@ class Generator(nn.Module):
         """does the frame loop of a forward at this batch size run as ONE persistent launch (all CUs, one such launch at
         a time per device)?  Callers that want to run two forwards side by side on two streams must not when it does."""
         from . import kernels as K
-        return self._num_layers == 1 and type(self) is Generator and \
-            K.gfront_persist_ok(batch_size, self._state_size, self._frame_size, dev)
+        # (LSTM front: single layer only; the GRU front of GRUGenerator is always one layer - both take the same launch)
+        return self._num_layers == 1 and K.gfront_persist_ok(batch_size, self._state_size, self._frame_size, dev)
 
     def prepare_weights(self):
         """materialise the weight-normed weights of every block NOW, on the current stream (no-op when the
@@ -208,6 +208,8 @@ class Generator(nn.Module):
             t_eff = nframes
             stops = None
             out_len, never = _never_stop_constants(batch_size, nframes, fs, dev)
+            if not (dev.type == 'cuda' and torch.cuda.is_current_stream_capturing()):
+                out_len = out_len.clone()       # eager callers get their own copy (an in-place edit must not reach the cache)
         else:
             if stop is None:
                 stops = torch.bernoulli(torch.sigmoid(s.detach())).long()

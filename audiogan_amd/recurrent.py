@@ -223,7 +223,7 @@ class GFrontFn(torch.autograd.Function):
         # all frames at once: zc_t @ W_ih[:, fs:]^T + b_ih + b_hh
         K.gemm(zc.contiguous().view(T * B, Fz), wz, gates[0].view(T * B, 4 * S), tb=True, bias=bsum[0])
         fused0 = K.lstm_step_ok(B, S, x[:, :fs], wx)
-        persist = nl == 1 and K.gfront_persist_ok(B, S, fs, dev)
+        persist = nl == 1 and T > 0 and wx.stride(1) == 1 and K.gfront_persist_ok(B, S, fs, dev)
         if not persist:
             for l in range(nl):
                 cs[l][0].zero_()                       # (the persistent launch writes c_0 = 0 itself)
@@ -309,7 +309,7 @@ class GFrontFn(torch.autograd.Function):
             K.gemm(ds_tb, sw, dacc.view(T * B, S + fs)[:, :S])
         dgs = torch.empty(T, B, 4 * S, device=dev)
         dxt = torch.empty(T, B, fs, device=dev)
-        if K.gfront_bwd_persist_ok(B, S, fs, dev) and wx.stride(1) == 1:
+        if T > 0 and wx.stride(1) == 1 and K.gfront_bwd_persist_ok(B, S, fs, dev):
             # the whole loop in ONE launch, [W_hh | W_x] and W_p resident in registers (ag_gfront_bwd_persist)
             K.gfront_bwd_persist(gates, cs, x, dacc, w_hh, wx, pw, dgs, dxt)
             return [dgs], dxt
@@ -418,7 +418,7 @@ class GRUFrontFn(torch.autograd.Function):
         gh = torch.empty(T, B, 3 * S, device=dev)      # h-part incl. b_hh (n slot needed for backward)
         hs = torch.empty(T + 1, B, S, device=dev)      # hs[t+1] = h_t, hs[0] = 0
         hs[0].zero_()
-        persist = K.gfront_persist_ok(B, S, fs, dev)
+        persist = T > 0 and wx.stride(1) == 1 and K.gfront_persist_ok(B, S, fs, dev)
         if persist:
             # the whole frame loop (GRU step + projection, fed back) in ONE launch, weights resident in registers: the r / z
             # halves of b_hh ride with the precomputed input part, b_hn stays apart (it sits inside r * (...))

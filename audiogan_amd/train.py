@@ -177,9 +177,14 @@ def g_backward_early(g, d, opt_g, c, z, noise_fake, keep, g_optim='boundary_seek
     return loss.detach()
 
 
-def g_backward_late(keep):
-    """the recurrent front's backward from the cut gradient (weight gradients of rnn / proj / stopper)"""
-    keep['x'].backward(keep['x_cut'].grad)
+def g_backward_late(keep, persist=False):
+    """the recurrent front's backward from the cut gradient (weight gradients of rnn / proj / stopper).  ``persist``: may
+    this backward be ONE persistent launch?  Default False: the phase-split form exists to run beside the asynchronous
+    all-reduce of the trunk's gradients, and a collective's kernels hold compute units for as long as their peers need
+    while a persistent launch wants all of its workgroups resident - pass True only when no collective is in flight
+    (``GraphedStep`` does when it has no gradient bucket)."""
+    with K.front_bwd_persist(bool(persist)):
+        keep['x'].backward(keep['x_cut'].grad)
 
 
 # --------------------------------------------------------------------------------------
@@ -381,8 +386,7 @@ class GraphedStep(object):
                 g3a = capture(gen_early)
                 # g3b runs beside the all-reduce of the trunk's gradients: no persistent launch in it (a collective's
                 # kernels hold CUs for as long as their peers need; the per-frame form shares the chip with them)
-                with K.front_bwd_persist(self.bg is None):
-                    g3b = capture(lambda: g_backward_late(gkeep))
+                g3b = capture(lambda: g_backward_late(gkeep, persist=self.bg is None))
                 g4 = capture(lambda: opt_g.step(clip_norm=ggradclip, grad_scale=scale))
                 self.phases = (g1a, g1b, g2, g3a, g3b, g4)
             torch.cuda.synchronize()

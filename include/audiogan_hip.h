@@ -313,8 +313,9 @@ int ag_lstm_seq_bwd(const float* const* gates, const float* const* whh, const fl
  * workgroup that gave up writes NaN into everything it produces from then on, so the failure also reaches the loss.
  * ONE persistent launch per device at a time.
  * Tensors as for ag_lstm_seq_fwd (no hbuf: the state stays in registers). */
-/* test hook: timeout of the bounded spins in ticks of the 100 MHz realtime counter (<= 0: the default 3 s) and one
- * block index that never publishes its flags (-1: none), applied to the persistent launches enqueued afterwards */
+/* test hook, ONE-SHOT and per thread: timeout of the bounded spins in ticks of the 100 MHz realtime counter (<= 0: the
+ * default 3 s) and one block index that never publishes its flags (-1: none), applied to the NEXT persistent launch the
+ * calling thread enqueues and consumed by it (every later launch runs with the defaults again) */
 int ag_persist_debug(int64_t timeout_ticks, int mute_block);
 int ag_lstm_persist_ok(int B, int H, int ndir, int n_cu);
 int64_t ag_lstm_persist_ws_bytes(int B, int H, int ndir);

@@ -93,15 +93,19 @@ def test_gru_generator_gpu():
 
 
 @pytest.mark.gpu
-def test_c4_c5_at_c2_widths_gpu():
-    """BASELINE configs[3] / [4] at the C2 widths (state 1024, frame 256, default structs, 8192-sample clips): one
-    GRU-front + conv-critic BCE step (train.c4_step) and one WGAN-GP step (train.wgan_gp_step) vs the oracle's
-    statements; losses, the generated waveforms and the parameters after the step"""
+@pytest.mark.parametrize('B', [4, 64])
+def test_c4_c5_at_c2_widths_gpu(B):
+    """BASELINE configs[3] / [4] at the C2 widths (state 1024, frame 256, default structs, 8192-sample clips), at a small
+    batch and at their BASELINE per-GPU batch of 64: one GRU-front + conv-critic BCE step (train.c4_step) and one WGAN-GP
+    step (train.wgan_gp_step) vs the oracle's statements; losses, every per-parameter gradient norm of both networks (as
+    the fused optimiser measured them), and the generated waveforms after the step"""
+    import os
     import audiogan_amd as A
     from audiogan_amd import optim, train
     dev = torch.device('cuda')
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
     cfg = [(16, 7, 2), (32, 7, 2), (64, 7, 2), (128, 7, 2), (256, 7, 2), (512, 7, 2)]
-    B, T, fs = 4, 32, 256
+    T, fs = 32, 256
     gen = torch.Generator().manual_seed(52)
     real = torch.rand(B, T * fs, generator=gen) * 2 - 1
     c, z = torch.randn(B, 100, generator=gen), torch.randn(B, T, 100, generator=gen)
@@ -119,13 +123,48 @@ def test_c4_c5_at_c2_widths_gpu():
         g.to(dev); cr.to(dev)
         ogo, odo = O.make_optimizer(list(go.parameters()), 'adam', 1e-4), O.make_optimizer(list(co.parameters()), 'adam', 1e-4)
         og, od = optim.make_optimizer(list(g.parameters()), 'adam', 1e-4), optim.make_optimizer(list(cr.parameters()), 'adam', 1e-4)
+        # the oracle's per-parameter gradient norms: where it clips (c4: before clip_grad rescales them in place), else
+        # (c5: no clipping) as its optimisers see them when they step
+        rec = {}
+        orig = O.clip_grad
+
+        def record(params, clip_norm, rec=rec, orig=orig):
+            rec[id(params[0])] = [float(p.grad.norm()) if p.grad is not None else None for p in params]
+            return orig(params, clip_norm)
+
+        def wrap_step(opt, rec=rec):
+            step = opt.step
+            params = [p for gr in opt.param_groups for p in gr['params']]
+
+            def stepped(*a, **k):
+                rec.setdefault(id(params[0]), [float(p.grad.norm()) if p.grad is not None else None for p in params])
+                return step(*a, **k)
+            opt.step = stepped
+        wrap_step(ogo); wrap_step(odo)
+        O.clip_grad = record
+        try:
+            if wl == 'c4':
+                lo = O.c4_step(go, co, ogo, odo, real, c, z, nr, nf, 1.0, 0.1, stop=stop)
+            else:
+                lo = O.wgan_gp_step(go, co, ogo, odo, real, c, z, eps, 10.0, stop=stop)
+        finally:
+            O.clip_grad = orig
+        rec = [rec[id(next(co.parameters()))], rec[id(next(go.parameters()))]]
         if wl == 'c4':
-            lo = O.c4_step(go, co, ogo, odo, real, c, z, nr, nf, 1.0, 0.1, stop=stop)
             l = train.c4_step(g, cr, og, od, to(real), to(c), to(z), to(nr), to(nf), 1.0, 0.1, check=True)
         else:
-            lo = O.wgan_gp_step(go, co, ogo, odo, real, c, z, eps, 10.0, stop=stop)
             l = train.wgan_gp_step(g, cr, og, od, to(real), to(c), to(z), to(eps), 10.0, check=True)
         np.testing.assert_allclose([float(l[0]), float(l[1])], [float(lo[0]), float(lo[1])], rtol=1e-3, err_msg=wl)
+        # per-parameter gradient norms of the critic and the generator iteration (oracle: recorded where it clips)
+        for mod, opt, ref_norms in ((cr, od, rec[0]), (g, og, rec[1])):
+            live = [k for k, q in mod.named_parameters() if q.grad is not None]
+            names = [k for k, _ in mod.named_parameters()]
+            got = opt._state['norms'].cpu()
+            for i, k in enumerate(live):
+                r_ = ref_norms[names.index(k)]
+                if (k.split('.')[-1].startswith('bias') and k.endswith('_v')) or r_ is None:
+                    continue
+                np.testing.assert_allclose(float(got[i]), r_, rtol=2e-3, atol=1e-7, err_msg='%s B=%d grad norm %s' % (wl, B, k))
         xo = go(z=z, c=c, stop=stop)[0]
         x = g(z=to(z), c=to(c), stop='never')[0]
         np.testing.assert_allclose(x.detach().cpu().numpy(), xo.detach().numpy(), rtol=2e-3,

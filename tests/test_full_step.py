@@ -16,16 +16,30 @@ def _close(a, b, rtol=1e-3, atol_scale=1e-5, msg=''):
     np.testing.assert_allclose(a, b, rtol=rtol, atol=atol_scale * max(1e-3, float(np.abs(b).max())), err_msg=msg)
 
 
-def _run(dev, A, kind='rmsprop'):
+def _run(dev, A, kind='rmsprop', wide=False):
+    """``wide``: the C2 widths (default structs, state 1024, frame 256, embed / noise 100, char embedding 50 as audiogan.py
+    :620-637 builds them), 8 clips of 8192 samples, ragged real lengths and ragged stop draws"""
     from audiogan_amd import optim, train
     torch.manual_seed(71)
-    gcfg = dict(frame_size=32, embed_size=8, noise_size=8, state_size=64, num_layers=1,
-                struct=[[17, 8, 16, 8], [9, 4, 16, 8]])
-    dcfg = dict(state_size=64, embed_size=8, num_layers=1, cnn_struct=[[7, 2, 8], [7, 2, 16]])
+    if wide:
+        import os
+        torch.set_num_threads(min(32, os.cpu_count() or 1))
+        gcfg = dict(frame_size=256, embed_size=100, noise_size=100, state_size=1024, num_layers=1)
+        dcfg = dict(state_size=1024, embed_size=100, num_layers=1)
+        ecfg = dict(output_size=100, char_embed_size=50, num_layers=1, num_chars=256)
+        B, T, fs, ns, nchar = 8, 32, 256, 100, 256
+        rl = torch.tensor([8192, 6000, 8192, 4100, 7777, 8192, 2048, 5000])
+    else:
+        gcfg = dict(frame_size=32, embed_size=8, noise_size=8, state_size=64, num_layers=1,
+                    struct=[[17, 8, 16, 8], [9, 4, 16, 8]])
+        dcfg = dict(state_size=64, embed_size=8, num_layers=1, cnn_struct=[[7, 2, 8], [7, 2, 16]])
+        ecfg = dict(output_size=8, char_embed_size=6, num_chars=32)
+        B, T, fs, ns, nchar = 4, 4, 32, 8, 32
+        rl = torch.tensor([128, 100, 128, 64])
     go, do = O.Generator(**gcfg), O.Discriminator(**dcfg)
-    ego, edo = O.Embedder(8, 6, num_chars=32), O.Embedder(8, 6, num_chars=32)
+    ego, edo = O.Embedder(**ecfg), O.Embedder(**ecfg)
     g, d = A.Generator(**gcfg), A.Discriminator(**dcfg)
-    eg, ed = A.Embedder(8, 6, num_chars=32), A.Embedder(8, 6, num_chars=32)
+    eg, ed = A.Embedder(**ecfg), A.Embedder(**ecfg)
     for m, mo in ((g, go), (d, do), (eg, ego), (ed, edo)):
         m.load_state_dict(mo.state_dict())
         m.to(dev)
@@ -35,21 +49,27 @@ def _run(dev, A, kind='rmsprop'):
     opt_do = O.make_optimizer(list(do.parameters()) + list(edo.parameters()), kind, lr)
     opt_g = optim.make_optimizer(list(g.parameters()) + list(eg.parameters()), kind, lr)
     opt_d = optim.make_optimizer(list(d.parameters()) + list(ed.parameters()), kind, lr)
-    B, T, fs = 4, 4, 32
     gen = torch.Generator().manual_seed(72)
-    real, rl = torch.randn(B, T * fs, generator=gen), torch.tensor([128, 100, 128, 64])
+    real = torch.randn(B, T * fs, generator=gen)
+    if wide:
+        real = real / real.abs().max(1, keepdim=True)[0]          # peak-normalised clips (dataset.py:68-71)
+        for i in range(B):
+            real[i, int(rl[i]):] = 0
     to = lambda t: t.to(dev)  # noqa: E731
     baseline_o = baseline = None
     for it in (1, 2):
-        cs, cl = torch.randint(0, 32, (B, 7), generator=gen), torch.tensor([7, 3, 5, 2])
-        cs2, cl2 = torch.randint(0, 32, (B, 7), generator=gen), torch.tensor([4, 7, 1, 6])
-        z = torch.randn(B, T, 8, generator=gen)
+        cs, cl = torch.randint(0, nchar, (B, 7), generator=gen), torch.tensor([7, 3, 5, 2, 6, 1, 7, 4][:B])
+        cs2, cl2 = torch.randint(0, nchar, (B, 7), generator=gen), torch.tensor([4, 7, 1, 6, 2, 7, 3, 5][:B])
+        z = torch.randn(B, T, ns, generator=gen)
         nr, nf = torch.randn(B, T * fs, generator=gen) * 0.01, torch.randn(B, T * fs, generator=gen) * 0.01
         na = torch.randn(B, T * fs, generator=gen) * 0.01
         stop = torch.zeros(B, T, dtype=torch.long)
         stop[1, 2] = 1; stop[3, 1] = 1; stop[0, 3] = 1          # ragged generated lengths
         stop_adv = torch.zeros(B, T, dtype=torch.long)
         stop_adv[2, 1] = 1
+        if wide:
+            stop[5, 20] = 1; stop[6, T - 1] = 1; stop[7, 9] = 1
+            stop_adv[4, 17] = 1
         # ---- critic iteration (odd: FGSM branch, even: instance noise)
         ro = O.d_step_full(go, do, ego, edo, opt_do, it, real, rl, cs, cl, cs2, cl2, z, nr, nf, 1.0, stop=stop)
         r = train.d_step_full(g, d, eg, ed, opt_d, it, to(real), to(rl), to(cs), to(cl), to(cs2), to(cl2), to(z),
@@ -115,6 +135,16 @@ def test_full_step_reference_fixture_host_logic(monkeypatch, golden_dir):
     kernel_model.install(monkeypatch)
     import audiogan_amd as A
     _run_reference_fixture(torch.device('cpu'), A, golden_dir)
+
+
+@pytest.mark.gpu
+def test_full_step_at_c2_widths_gpu():
+    """the reference's CURRENT iterations (FGSM input-gradient passes, adversarial z, feature penalty over the six conv
+    activations up to 512 x 128, two Embedder biLSTMs beside the persistent launches, REINFORCE surrogate) at the C2
+    widths: 8 ragged clips of 8192 samples, an odd (FGSM) and an even (instance noise) critic iteration and two generator
+    iterations against the oracle's restatement"""
+    import audiogan_amd as A
+    _run(torch.device('cuda'), A, 'rmsprop', wide=True)
 
 
 @pytest.mark.gpu

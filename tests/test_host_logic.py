@@ -311,3 +311,36 @@ def test_front_backward_persistence_follows_the_gradient_bucket(monkeypatch):
     monkeypatch.setattr(K, 'PERSIST', [True])
     with K.front_bwd_persist(False):
         assert K.gfront_bwd_persist_ok(64, 1024, 256, torch.device('cpu')) is False
+
+
+def test_g_backward_late_is_per_frame_unless_the_caller_opts_in():
+    """the eager phase-split path (bucket.all_reduce(async_op=True, part='early'); g_backward_late(keep))
+    must not start a persistent front backward beside the collective - the guard lives in g_backward_late itself"""
+    from audiogan_amd import kernels as K, train
+    seen = []
+
+    class _X(object):
+        def backward(self, grad):
+            seen.append(K.PERSIST_FRONT_BWD[0])
+
+    class _Cut(object):
+        grad = None
+
+    keep = dict(x=_X(), x_cut=_Cut())
+    train.g_backward_late(keep)
+    train.g_backward_late(keep, persist=True)
+    assert seen == [False, True] and K.PERSIST_FRONT_BWD[0] is True
+
+
+def test_gru_generator_reports_its_persistent_front(monkeypatch):
+    """GRUGenerator's frame loop is a persistent launch too, so gd_step / GraphedStep must not fork its
+    forward onto a second stream beside the critic's persistent biLSTM (front_is_persistent used to test the exact type)"""
+    import audiogan_amd as A
+    from audiogan_amd import kernels as K
+    g = A.GRUGenerator(frame_size=32, embed_size=8, noise_size=8, state_size=64, struct=[[17, 8, 16, 8]])
+    g2 = A.Generator(frame_size=32, embed_size=8, noise_size=8, state_size=64, num_layers=2, struct=[[17, 8, 16, 8]])
+    monkeypatch.setattr(K, 'gfront_persist_ok', lambda B, S, fs, dev: True)
+    assert g.front_is_persistent(4, torch.device('cpu')) is True
+    assert g2.front_is_persistent(4, torch.device('cpu')) is False       # stacked LSTM cells take the per-frame path
+    monkeypatch.setattr(K, 'gfront_persist_ok', lambda B, S, fs, dev: False)
+    assert g.front_is_persistent(4, torch.device('cpu')) is False
