@@ -61,14 +61,14 @@ SIGNATURES = {
     'ag_conv1d_o1_bwd_data': (C.c_int, [vp, i64, vp, vp, i64, i64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                         C.c_int, vp]),
     'ag_conv1d_o1_wgrad': (C.c_int, [vp, i64, vp, i64, i64, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
-    'ag_channel_sum': (C.c_int, [vp, i64, i64, vp, C.c_int, C.c_int, C.c_int, vp]),
+    'ag_channel_sum': (C.c_int, [vp, i64, i64, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     'ag_lstm_front_bwd_step': (C.c_int, [vp, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int, vp, vp, C.c_int, vp, vp, vp,
                                          vp, vp, vp, C.c_int, C.c_int, vp]),
     'ag_leaky_bwd': (C.c_int, [vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, vp, C.c_int,
                                C.c_int, C.c_int, f32, vp]),
     'ag_gemm': (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp, C.c_int, C.c_int,
                           C.c_int, C.c_int, f32, f32, vp, vp, C.c_int, C.c_int, f32, vp]),
-    'ag_col_sum': (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, vp]),
+    'ag_col_sum': (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp]),
     'ag_lstm_cell_fwd': (C.c_int, [vp, C.c_int, vp, C.c_int, vp, C.c_int, vp, C.c_int, vp, C.c_int,
                                    vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp]),
     'ag_lstm_cell_bwd': (C.c_int, [vp, C.c_int, vp, C.c_int, vp, C.c_int, vp, C.c_int, vp, C.c_int,
@@ -93,14 +93,20 @@ SIGNATURES = {
     'ag_lstm_persist_ws_bytes': (i64, [C.c_int, C.c_int, C.c_int]),
     'ag_lstm_seq_fwd_persist': (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     'ag_lstm_persist_bwd_ok': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
-    'ag_lstm_seq_bwd_persist': (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    'ag_lstm_seq_bwd_persist': (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, i64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    'ag_rowdot_fwd': (C.c_int, [vp, C.c_int, vp, vp, vp, i64, C.c_int, C.c_int, vp]),
+    'ag_rowdot_bwd_ws_numel': (i64, [C.c_int, C.c_int]),
+    'ag_rowdot_bwd': (C.c_int, [vp, i64, vp, C.c_int, vp, vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, f32, vp]),
     'ag_gfront_persist_ok': (C.c_int, [C.c_int] * 4),
     'ag_gfront_persist_ws_bytes': (i64, [C.c_int] * 3),
     'ag_gfront_bwd_persist_ok': (C.c_int, [C.c_int] * 4),
-    'ag_gfront_bwd_persist': (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, vp, vp, vp, vp, i64] + [C.c_int] * 5 + [vp]),
-    'ag_grufront_bwd_persist': (C.c_int, [vp, vp, vp, vp, vp, vp, vp, C.c_int, vp, vp, vp, vp, vp, i64] + [C.c_int] * 5 + [vp]),
-    'ag_gfront_fwd_persist': (C.c_int, [vp, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, i64] + [C.c_int] * 5 + [vp]),
-    'ag_grufront_fwd_persist': (C.c_int, [vp, vp, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, i64] + [C.c_int] * 5 + [vp]),
+    'ag_gfront_bwd_persist': (C.c_int, [vp, vp, vp, i64, vp, vp, i64, vp, vp, C.c_int, vp, vp, vp, vp, i64] + [C.c_int] * 5 + [vp]),
+    'ag_grufront_bwd_persist': (C.c_int, [vp, vp, vp, vp, i64, vp, vp, i64, vp, vp, C.c_int, vp, vp, vp, vp, vp, i64] + [C.c_int] * 5 + [vp]),
+    'ag_gfront_fwd_persist': (C.c_int, [vp, vp, C.c_int, vp, vp, vp, vp, vp, vp, i64, vp, vp, i64] + [C.c_int] * 5 + [vp]),
+    'ag_grufront_fwd_persist': (C.c_int, [vp, vp, vp, C.c_int, vp, vp, vp, vp, vp, vp, i64, vp, vp, i64] + [C.c_int] * 5 + [vp]),
+    'ag_build_zc': (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    'ag_critic_batch': (C.c_int, [vp, i64, vp, i64, C.c_int, vp, i64, vp, i64, C.c_int, C.c_int, vp, vp, vp,
+                                  C.POINTER(i32), C.c_int, vp, vp, vp, C.c_int, vp, vp]),
     'ag_convlstm_peephole_fwd': (C.c_int, [vp] * 8 + [C.c_int] * 4 + [vp]),
     'ag_convlstm_peephole_bwd': (C.c_int, [vp] * 11 + [C.c_int] * 4 + [vp]),
     'ag_convlstm_cell_fwd': (C.c_int, [vp] * 6 + [f32, vp, vp] + [C.c_int] * 4 + [vp]),
@@ -117,8 +123,8 @@ SIGNATURES = {
     'ag_time_moments_bwd': (C.c_int, [vp, i64, i64, vp, vp, vp, vp, vp, i64, i64, C.c_int, C.c_int, C.c_int, vp]),
     'ag_act_bwd2d': (C.c_int, [vp, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, f32, vp]),
     'ag_axpby': (C.c_int, [vp, vp, i64, f32, f32, vp]),
-    'ag_grad_norms': (C.c_int, [vp, C.c_int, vp, vp, vp, f32, vp, vp]),
-    'ag_opt_step': (C.c_int, [vp, C.c_int, vp, C.c_int, f32, f32, f32, f32, f32, f32, C.c_int, vp, vp]),
+    'ag_grad_norms': (C.c_int, [vp, C.c_int, vp, vp, vp, f32, vp, C.c_int, vp]),
+    'ag_opt_step': (C.c_int, [vp, C.c_int, vp, C.c_int, f32, f32, f32, f32, f32, f32, C.c_int, vp, vp, vp, vp, vp, vp]),
 }
 
 
@@ -135,7 +141,7 @@ def _load():
     return lib
 
 
-ABI_VERSION = 8      # what this package was written against (csrc/api.hip: ag_abi_version)
+ABI_VERSION = 9      # what this package was written against (csrc/api.hip: ag_abi_version)
 
 lib = _load()
 if lib.ag_abi_version() != ABI_VERSION:

@@ -74,6 +74,50 @@ class frozen(object):
             p.requires_grad_(r)
 
 
+# Network-level backward scope.  ``with network_backward(): loss.backward()`` - every second stage the backward's blocks
+# defer (kernels.deferred_reduces) is summed by ONE launch when the whole backward is over, and the weight-norm backward of
+# EVERY block of the network (dW -> dv, dg, accumulated straight into ``.grad``) runs as ONE launch behind it, instead of
+# one pair per autograd Function.  Blocks whose parameters have no ``.grad`` buffer yet (they return fresh gradient tensors
+# to autograd) finish on the spot, as they do outside a scope.
+_WN_PENDING = dict(ents=None, keep=None, groups=None)
+
+
+def finish_pending():
+    """inside a network scope: make everything deferred so far final NOW (one flush + one weight-norm backward launch);
+    the scope stays open.  A block whose backward runs a SECOND time inside one scope (the critic applied to real and to
+    generated clips in two passes) calls this before it reuses its dW scratch."""
+    ents = _WN_PENDING['ents']
+    if ents is None:
+        return
+    K.flush_reduces()
+    if ents:
+        K.weight_norm_bwd(ents)
+    _WN_PENDING['ents'], _WN_PENDING['keep'], _WN_PENDING['groups'] = [], [], set()
+
+
+class network_backward(object):
+    def __enter__(self):
+        self.dr = K.deferred_reduces(outer=True)
+        self.dr.__enter__()
+        self.owner = self.dr.role == 'owner'
+        if self.owner:
+            _WN_PENDING['ents'], _WN_PENDING['keep'], _WN_PENDING['groups'] = [], [], set()
+        return self
+
+    def __exit__(self, et, ev, tb):
+        if not self.owner:
+            return self.dr.__exit__(et, ev, tb)
+        ents = _WN_PENDING['ents']
+        _WN_PENDING['ents'] = None
+        try:
+            self.dr.__exit__(et, ev, tb)           # the one flush: every deferred sum is final behind it
+            if et is None and ents:
+                K.weight_norm_bwd(ents)
+        finally:
+            _WN_PENDING['keep'] = _WN_PENDING['groups'] = None
+        return False
+
+
 class Prepared(object):
     __slots__ = ('w', 'wpa', 'wpb', 'pad')
 
@@ -139,6 +183,8 @@ class WNGroup(object):
         descriptor table of the weight-norm backward is built once and a captured graph needs no upload node for it:
         under replay such an upload runs as ~24 serial 64-byte blits per table, 0.35 ms per step)"""
         dev = self.items[0]['v'].device
+        if _WN_PENDING['groups'] and id(self) in _WN_PENDING['groups']:
+            finish_pending()        # second backward of this block inside one scope: the first one's dW must be consumed first
         if getattr(self, '_dws', None) is None or self._dws[0].device != dev:
             n = sum(it['v'].numel() for it in self.items)
             flat = torch.empty(n, device=dev, dtype=torch.float32)
@@ -168,8 +214,18 @@ class WNGroup(object):
             dg = torch.empty_like(it['g'].data)
             ents.append(dict(v=it['v'].data, g=it['g'].data.view(-1), dw=dw, dv=dv, dg=dg.view(-1)))
             outs += [dv, dg]
-        if ents:
-            K.weight_norm_bwd(ents)
+        if not ents:
+            return outs
+        if _WN_PENDING['ents'] is not None and K.reduces_outer() and all(o is None for o in outs):
+            # inside a network-level scope and every gradient goes straight into ``.grad``: dW is final only when that
+            # scope flushes, and nothing reads dv / dg before the optimiser - join the network's one launch
+            _WN_PENDING['ents'] += ents
+            _WN_PENDING['keep'].append(dws)
+            _WN_PENDING['groups'].add(id(self))
+            return outs
+        if K.reduces_outer():
+            K.flush_reduces()       # fresh gradient tensors go back to autograd now: they must be final now
+        K.weight_norm_bwd(ents)
         return outs
 
 

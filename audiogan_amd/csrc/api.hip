@@ -14,9 +14,10 @@ void ag_set_error(const char* fmt, ...) {
 }
 
 // bumped whenever an entry point, a struct layout or the meaning of an argument changes (round 3: sticky persistent status,
-// AG_ACT_LEAKY_GATE, AG_PREC_F32X3, GRU front, Conv2DLSTMCell pieces): audiogan_amd/_lib.py refuses a library of another
+// AG_ACT_LEAKY_GATE, AG_PREC_F32X3, GRU front, Conv2DLSTMCell pieces; round 4: v9 - pitched x / split external gradients of
+// the front's persistent launches, process-wide deferral with pause / resume, ag_build_zc, ag_critic_batch): audiogan_amd/_lib.py refuses a library of another
 // version, so Python that relies on a new mode can never drive an older build
-extern "C" int ag_abi_version(void) { return 8; }
+extern "C" int ag_abi_version(void) { return 9; }
 extern "C" const char* ag_arch(void) { return "gfx950"; }
 extern "C" const char* ag_last_error(void) { return g_err; }
 
@@ -92,25 +93,31 @@ __global__ __launch_bounds__(256) void slab_reduce4_kernel(const f32x4* __restri
 }
 
 // ---- deferred second stages --------------------------------------------------------------------------------------
-// A network's backward issues one second stage per weight-gradient / bias-sum launch (35+ per step, ~5 us each, nothing
-// reads their results before the weight-norm backward at the end).  Between ag_defer_reduces(1) and ag_flush_reduces()
-// ag_slab_reduce only RECORDS its arguments (thread-local: the autograd thread that runs the backward); the flush sums
-// every recorded output in ONE launch, each output in exactly the order the single launches use (bitwise the same
-// result).  The caller keeps the partial-sum workspaces alive until the flush.
+// A network's backward issues one second stage per weight-gradient / bias-sum launch (50+ per step, ~5 us each, nothing
+// reads their results before the weight-norm backward / the optimiser at the end).  Between ag_defer_reduces(1) and
+// ag_flush_reduces() ag_slab_reduce only RECORDS its arguments; the flush sums every recorded output in ONE launch, each
+// output in exactly the order the single launches use (bitwise the same result).  The caller keeps the partial-sum
+// workspaces alive until the flush.  The state is process-wide (round 4; it was per thread): a scope is opened by the
+// thread that calls loss.backward() and the recording calls come from torch's autograd thread - never concurrently, the
+// opener blocks inside backward() - so one scope can span every block of a network's backward.
+// ag_defer_reduces modes: 1 = start recording (drops anything recorded), 0 = stop (an error while stages are pending),
+// 2 = pause (stages issued now run at once, recorded ones stay), 3 = resume.
 struct SlabDesc {
   const float* ws;
   float* dst;
   int64_t n;     // outputs (floats)
   int Z, acc, vec, blk0;
+  int ncol, ld;  // dst is a [n / ncol, ncol] block of rows of pitch ld (ld == ncol: contiguous)
 };
 #define SLAB_MAXD 40
 struct SlabMulti {
   SlabDesc d[SLAB_MAXD];
   int nd;
 };
-static thread_local bool g_defer = false;
-static thread_local SlabMulti g_multi = {};
-static thread_local int g_multi_blocks = 0;
+static bool g_defer = false;          // recording
+static bool g_defer_open = false;     // a scope exists (recording or paused)
+static SlabMulti g_multi = {};
+static int g_multi_blocks = 0;
 
 __global__ __launch_bounds__(256) void slab_reduce_multi_kernel(const SlabMulti m) {
   __shared__ f32x4 sh[256];
@@ -123,11 +130,17 @@ __global__ __launch_bounds__(256) void slab_reduce_multi_kernel(const SlabMulti 
   if (D.vec) {
     const int64_t n4 = D.n >> 2;
     const f32x4 t = slab_sum<f32x4>((const f32x4*)D.ws, D.Z, n4, i, threadIdx.x >> 5, i < n4, sh);
-    f32x4* dst = (f32x4*)D.dst;
-    if (threadIdx.x < 32 && i < n4) dst[i] = D.acc ? dst[i] + t : t;
+    if (threadIdx.x < 32 && i < n4) {
+      const int64_t e = 4 * i;
+      f32x4* dst = (f32x4*)(D.dst + (D.ld == D.ncol ? e : (e / D.ncol) * D.ld + e % D.ncol));
+      *dst = D.acc ? *dst + t : t;
+    }
   } else {
     const float t = slab_sum<float>(D.ws, D.Z, D.n, i, threadIdx.x >> 5, i < D.n, (float*)sh);
-    if (threadIdx.x < 32 && i < D.n) D.dst[i] = D.acc ? D.dst[i] + t : t;
+    if (threadIdx.x < 32 && i < D.n) {
+      float* dst = D.dst + (D.ld == D.ncol ? i : (i / D.ncol) * D.ld + i % D.ncol);
+      *dst = D.acc ? *dst + t : t;
+    }
   }
 }
 
@@ -141,33 +154,60 @@ static int slab_flush(hipStream_t st) {
   return AG_OK;
 }
 
-extern "C" int ag_defer_reduces(int on) {
-  AG_REQUIRE(!(g_defer && !on && g_multi.nd > 0), "ag_defer_reduces: %d recorded second stages were never flushed", g_multi.nd);
-  g_defer = on != 0;
-  if (on) { g_multi.nd = 0; g_multi_blocks = 0; }
+extern "C" int ag_defer_reduces(int mode) {
+  AG_REQUIRE(mode >= 0 && mode <= 3, "ag_defer_reduces: mode must be 0 (off), 1 (on), 2 (pause) or 3 (resume)");
+  if (mode == 0) {
+    AG_REQUIRE(g_multi.nd == 0, "ag_defer_reduces: %d recorded second stages were never flushed", g_multi.nd);
+    g_defer = g_defer_open = false;
+  } else if (mode == 1) {
+    g_defer = g_defer_open = true;
+    g_multi.nd = 0;
+    g_multi_blocks = 0;
+  } else if (mode == 2) {
+    g_defer = false;
+  } else {
+    AG_REQUIRE(g_defer_open, "ag_defer_reduces: resume without a scope");
+    g_defer = true;
+  }
   return AG_OK;
 }
 
+// is ag_slab_reduce recording right now?  (ag_gemm asks before it hands a split-K second stage over)
+bool ag_reduces_deferred() { return g_defer; }
+
 extern "C" int ag_flush_reduces(void* stream) { return slab_flush((hipStream_t)stream); }
+
+// record one second stage: dst = a [rows, ncol] block of pitch ld (the floats it spans: (rows - 1) * ld + ncol)
+static int slab_record(const float* ws, int Z, int64_t n, float* dst, int ncol, int ld, int accumulate, hipStream_t st) {
+  const int64_t span = (n / ncol - 1) * (int64_t)ld + ncol;
+  // two recorded stages must not write the same floats in one launch, and a launch holds SLAB_MAXD of them (spans of
+  // pitched blocks are compared whole: conservative)
+  bool clash = g_multi.nd == SLAB_MAXD;
+  for (int k = 0; k < g_multi.nd && !clash; ++k) {
+    const SlabDesc& E = g_multi.d[k];
+    const int64_t espan = (E.n / E.ncol - 1) * (int64_t)E.ld + E.ncol;
+    clash = dst < E.dst + espan && E.dst < dst + span;
+  }
+  if (clash) {
+    const int rc = slab_flush(st);
+    if (rc != AG_OK) return rc;
+  }
+  SlabDesc& D = g_multi.d[g_multi.nd++];
+  D.ws = ws; D.dst = dst; D.n = n; D.Z = Z; D.acc = accumulate; D.ncol = ncol; D.ld = ld;
+  D.vec = ((n & 3) == 0 && (ncol & 3) == 0 && (ld & 3) == 0 && (((uintptr_t)ws | (uintptr_t)dst) & 15) == 0) ? 1 : 0;
+  D.blk0 = g_multi_blocks;
+  g_multi_blocks += (int)ag_cdiv64(D.vec ? n >> 2 : n, 32);
+  return AG_OK;
+}
+
+// the second stage of a split-K product into a [M, N] block of row pitch ldc, inside a recording scope only
+int ag_slab_defer_2d(const float* ws, int Z, int M, int N, float* dst, int ldc, int accumulate, hipStream_t st) {
+  return slab_record(ws, Z, (int64_t)M * N, dst, N, ldc, accumulate, st);
+}
 
 int ag_slab_reduce(const float* ws, int Z, int64_t n, float* dst, int accumulate, hipStream_t st) {
   if (n <= 0 || Z <= 0) return AG_OK;
-  if (g_defer) {
-    // two recorded stages must not write the same floats in one launch, and a launch holds SLAB_MAXD of them
-    bool clash = g_multi.nd == SLAB_MAXD;
-    for (int k = 0; k < g_multi.nd && !clash; ++k)
-      clash = dst < g_multi.d[k].dst + g_multi.d[k].n && g_multi.d[k].dst < dst + n;
-    if (clash) {
-      const int rc = slab_flush(st);
-      if (rc != AG_OK) return rc;
-    }
-    SlabDesc& D = g_multi.d[g_multi.nd++];
-    D.ws = ws; D.dst = dst; D.n = n; D.Z = Z; D.acc = accumulate;
-    D.vec = ((n & 3) == 0 && (((uintptr_t)ws | (uintptr_t)dst) & 15) == 0) ? 1 : 0;
-    D.blk0 = g_multi_blocks;
-    g_multi_blocks += (int)ag_cdiv64(D.vec ? n >> 2 : n, 32);
-    return AG_OK;
-  }
+  if (g_defer && n < ((int64_t)1 << 30)) return slab_record(ws, Z, n, dst, (int)n, (int)n, accumulate, st);
   if ((n & 3) == 0 && (((uintptr_t)ws | (uintptr_t)dst) & 15) == 0) {
     const int64_t n4 = n >> 2;
     hipLaunchKernelGGL(slab_reduce4_kernel, dim3((unsigned)ag_cdiv64(n4, 32)), dim3(256), 0, st, (const f32x4*)ws, Z, n4,

@@ -24,6 +24,9 @@ struct AgWs {
 AgWs ag_ws_take();
 // dst[i] (+)= sum_{z=0}^{Z-1} ws[z*n + i], z ascending
 int ag_slab_reduce(const float* ws, int Z, int64_t n, float* dst, int accumulate, hipStream_t st);
+bool ag_reduces_deferred();   // inside a recording ag_defer_reduces scope (api.hip)
+// record (scope recording only) the second stage of a split-K product into a [M,N] block of row pitch ldc
+int ag_slab_defer_2d(const float* ws, int Z, int M, int N, float* dst, int ldc, int accumulate, hipStream_t st);
 
 // C[row*ldc+col] = beta*C + sum_{z<Z} part[z*pitch + row*N+col] + bias[col] + res[row*ldres+col]   (gemm.hip)
 int ag_splitk_reduce(const float* part, int Z, int64_t pitch, int M, int N, float* C, int ldc, float beta,

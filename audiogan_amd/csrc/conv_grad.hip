@@ -22,7 +22,7 @@ struct WgP {
   int lgp;      // LDS pitch of one lg channel row (odd)
   int maxch;    // channel rows staged per tile
   int vec;      // sh rows may be read with 16-byte loads
-  float* part;  // two-stage reduction: slab z = blockIdx.z of [A][CK] partial sums (plain stores); NULL -> atomics
+  float* part;  // two-stage reduction: slab z = blockIdx.z of [A][CK] partial sums (plain stores); never NULL: there is no float-atomic path
   int rb;       // AG_PREC_BF16: both operands rounded to bf16 while staging
 };
 
@@ -280,8 +280,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgP p) {
       for (int j = 0; j < TN; ++j) {
         const int ck = ck0 + wn * 32 * TN + 32 * j + l31;
         if (ck >= p.CK) continue;
-        if (p.part) p.part[((int64_t)bz * p.A + a) * p.CK + ck] = acc[i][j][e];
-        else atomicAdd(p.dw + (int64_t)a * p.CK + ck, acc[i][j][e]);
+        p.part[((int64_t)bz * p.A + a) * p.CK + ck] = acc[i][j][e];
       }
     }
 }
@@ -478,8 +477,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_bf16_kernel(const WgP p) {
       for (int j = 0; j < TN; ++j) {
         const int ck = ck0 + wn * 32 * TN + 32 * j + l31;
         if (ck >= p.CK) continue;
-        if (p.part) p.part[((int64_t)bz * p.A + a) * p.CK + ck] = acc[i][j][e];
-        else atomicAdd(p.dw + (int64_t)a * p.CK + ck, acc[i][j][e]);
+        p.part[((int64_t)bz * p.A + a) * p.CK + ck] = acc[i][j][e];
       }
     }
 }
@@ -522,18 +520,15 @@ static int launch_wgrad_bf16(WgP& p, hipStream_t st, AgWs ws) {
   const int total = p.B * p.nchunk;
   int gz = wgrad_slices(p.A, p.CK, AT, NT, total);
   const int64_t n_out = (int64_t)p.A * p.CK;
-  p.part = nullptr;
-  if (ws.p && ws.numel >= n_out) {         // two-stage, fixed-order reduction
-    if ((int64_t)gz * n_out > ws.numel) gz = (int)(ws.numel / n_out);
-    p.part = ws.p;
-  }
+  AG_REQUIRE(ws.p && ws.numel >= n_out, "%s: this reduction spans several workgroups and needs a workspace of >= %lld floats bound with ag_bind_workspace (sums are two-stage, in a fixed order; there is no float-atomic accumulation)", "ag_conv1d_wgrad", (long long)n_out);
+  if ((int64_t)gz * n_out > ws.numel) gz = (int)(ws.numel / n_out);     // two-stage, fixed-order reduction
+  p.part = ws.p;
   auto kern = conv_wgrad_bf16_kernel<TA, TN, WA, WN>;
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(kern, dim3(gx, gy, gz), dim3(512), lds, st, p);
   AG_CHECK_LAUNCH("ag_conv1d_wgrad(bf16)");
-  if (p.part) return ag_slab_reduce(p.part, gz, n_out, p.dw, 1, st);
-  return AG_OK;
+  return ag_slab_reduce(p.part, gz, n_out, p.dw, 1, st);
 }
 
 template <int TA, int TN, int WA, int WN>
@@ -559,19 +554,16 @@ static int launch_wgrad(WgP& p, hipStream_t st, AgWs ws) {
   const int total = p.B * p.nchunk;
   int gz = wgrad_slices(p.A, p.CK, AT, NT, total);
   const int64_t n_out = (int64_t)p.A * p.CK;
-  p.part = nullptr;
-  if (ws.p && ws.numel >= n_out) {         // two-stage, fixed-order reduction
-    if ((int64_t)gz * n_out > ws.numel) gz = (int)(ws.numel / n_out);
-    p.part = ws.p;
-  }
+  AG_REQUIRE(ws.p && ws.numel >= n_out, "%s: this reduction spans several workgroups and needs a workspace of >= %lld floats bound with ag_bind_workspace (sums are two-stage, in a fixed order; there is no float-atomic accumulation)", "ag_conv1d_wgrad", (long long)n_out);
+  if ((int64_t)gz * n_out > ws.numel) gz = (int)(ws.numel / n_out);     // two-stage, fixed-order reduction
+  p.part = ws.p;
   auto kern = conv_wgrad_kernel<TA, TN, WA, WN>;
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds);
   hipLaunchKernelGGL(kern, dim3(gx, gy, gz), dim3(512), lds, st, p);
   AG_CHECK_LAUNCH("ag_conv1d_wgrad");
-  if (p.part) return ag_slab_reduce(p.part, gz, n_out, p.dw, 1, st);
-  return AG_OK;
+  return ag_slab_reduce(p.part, gz, n_out, p.dw, 1, st);
 }
 
 // Single-input-channel layer with a short kernel (D1: 1 -> 16 k7 s2): dw is 16 x 7 values, an MFMA tile would be
@@ -626,8 +618,7 @@ __global__ __launch_bounds__(256) void conv_c1_wgrad_kernel(const float* __restr
     const int i = threadIdx.x / KMAX, k = threadIdx.x % KMAX;
     if (k < K && a0 + i < A) {
       const float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-      if (part) part[((int64_t)(blockIdx.z * gridDim.x + blockIdx.x) * A + a0 + i) * K + k] = v;
-      else atomicAdd(dw + (a0 + i) * K + k, v);
+      part[((int64_t)(blockIdx.z * gridDim.x + blockIdx.x) * A + a0 + i) * K + k] = v;
     }
   }
 }
@@ -663,18 +654,15 @@ extern "C" int ag_conv1d_wgrad(const float* sh, int64_t sh_bs, int64_t sh_cs, co
     int gz = ag_cdiv(512, gx * gy);     // ~2 workgroups per CU: each ends in AG*K partial sums
     if (gz > B) gz = B;
     if (gz < 1) gz = 1;
-    float* part = nullptr;
-    if (ws.p && ws.numel >= (int64_t)gx * A * K) {
-      if ((int64_t)gz * gx * A * K > ws.numel) gz = (int)(ws.numel / ((int64_t)gx * A * K));
-      part = ws.p;
-    }
+    AG_REQUIRE(ws.p && ws.numel >= (int64_t)gx * A * K, "%s: this reduction spans several workgroups and needs a workspace of >= %lld floats bound with ag_bind_workspace (sums are two-stage, in a fixed order; there is no float-atomic accumulation)", "ag_conv1d_wgrad", (long long)gx * A * K);
+    if ((int64_t)gz * gx * A * K > ws.numel) gz = (int)(ws.numel / ((int64_t)gx * A * K));
+    float* part = ws.p;
     const int bper = ag_cdiv(B, gz);
     gz = ag_cdiv(B, bper);
     hipLaunchKernelGGL((conv_c1_wgrad_kernel<8, 8>), dim3(gx, gy, gz), dim3(256), 0, st, sh, sh_bs, sh_cs, lg, lg_bs,
                        dw, B, A, Lsh, Llg, K, stride, pad, bper, part, p.rb);
     AG_CHECK_LAUNCH("ag_conv1d_wgrad");
-    if (part) return ag_slab_reduce(part, gx * gz, (int64_t)A * K, dw, 1, st);
-    return AG_OK;
+    return ag_slab_reduce(part, gx * gz, (int64_t)A * K, dw, 1, st);
   }
   if (A <= 32) return launch_wgrad<1, 1, 1, 4>(p, st, ws);             // 32 x 128
   if (A <= 64 || p.CK <= 64) return launch_wgrad<1, 1, 2, 2>(p, st, ws);  // 64 x 64
@@ -713,11 +701,11 @@ extern "C" int64_t ag_conv1d_wgrad_ws_numel(int B, int A, int Lsh, int C, int K)
 }
 
 // ------------------------------------------------------------------------------------------
-// db[c] += sum_{b,t} dy[b,c,t]
+// db[c] (+)= sum_{b,t} dy[b,c,t]
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restrict__ dy, int64_t bs,
                                                           int64_t cs, float* __restrict__ db, int B,
-                                                          int C, int L, int nsplit, float* __restrict__ part) {
+                                                          int C, int L, int nsplit, float* __restrict__ part, int accumulate) {
   __shared__ float red[17];
   const int c = blockIdx.x;
   const int64_t total = (int64_t)B * L;
@@ -730,11 +718,11 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restric
   s = ag_block_sum(s, red);
   if (threadIdx.x == 0) {
     if (part) part[(int64_t)blockIdx.y * C + c] = s;
-    else atomicAdd(db + c, s);
+    else db[c] = accumulate ? db[c] + s : s;          // nsplit == 1: this workgroup is the only writer of db[c]
   }
 }
 
-extern "C" int ag_channel_sum(const float* dy, int64_t bs, int64_t cs, float* db, int B, int C, int L,
+extern "C" int ag_channel_sum(const float* dy, int64_t bs, int64_t cs, float* db, int B, int C, int L, int accumulate,
                               void* stream) {
   const AgWs ws = ag_ws_take();     // FIRST: an argument error below must not leave a stale binding behind
   AG_REQUIRE(dy && db && B > 0 && C > 0 && L > 0, "ag_channel_sum: bad args");
@@ -743,14 +731,15 @@ extern "C" int ag_channel_sum(const float* dy, int64_t bs, int64_t cs, float* db
   if (nsplit > cap) nsplit = cap;
   if (nsplit < 1) nsplit = 1;
   float* part = nullptr;
-  if (ws.p && ws.numel >= C) {
+  if (nsplit > 1) {
+    AG_REQUIRE(ws.p && ws.numel >= 2 * (int64_t)C, "%s: this reduction spans several workgroups and needs a workspace of >= %lld floats bound with ag_bind_workspace (sums are two-stage, in a fixed order; there is no float-atomic accumulation)", "ag_channel_sum", (long long)2 * C);
     if ((int64_t)nsplit * C > ws.numel) nsplit = (int)(ws.numel / C);
     part = ws.p;
   }
   hipLaunchKernelGGL(channel_sum_kernel, dim3(C, nsplit), dim3(256), 0, (hipStream_t)stream, dy, bs,
-                     cs, db, B, C, L, nsplit, part);
+                     cs, db, B, C, L, nsplit, part, accumulate);
   AG_CHECK_LAUNCH("ag_channel_sum");
-  if (part) return ag_slab_reduce(part, nsplit, C, db, 1, (hipStream_t)stream);
+  if (part) return ag_slab_reduce(part, nsplit, C, db, accumulate ? 1 : 0, (hipStream_t)stream);
   return AG_OK;
 }
 
@@ -792,8 +781,7 @@ __global__ __launch_bounds__(256) void leaky_bwd_kernel(const float* __restrict_
     __syncthreads();
     if (threadIdx.x == 0) {
       const float v = red[0] + red[1] + red[2] + red[3];
-      if (part) part[(int64_t)(blockIdx.z * gridDim.x + blockIdx.x) * C + c] = v;
-      else atomicAdd(bias_grad + c, v);
+      part[(int64_t)(blockIdx.z * gridDim.x + blockIdx.x) * C + c] = v;
     }
   }
 }
@@ -813,11 +801,10 @@ extern "C" int ag_leaky_bwd(const float* dy, int64_t dy_bs, int64_t dy_cs, const
     bper = (int)(((int64_t)gx * C * B) / 2048);
     if (bper < 8) bper = 8;
     if (bper > B) bper = B;
-    if (ws.p && ws.numel >= (int64_t)gx * C) {      // partial sums per (x, z) block, fixed-order second stage
-      const int64_t zmax = ws.numel / ((int64_t)gx * C);
-      if (ag_cdiv(B, bper) > zmax) bper = ag_cdiv(B, (int)zmax);
-      part = ws.p;
-    }
+    AG_REQUIRE(ws.p && ws.numel >= (int64_t)gx * C, "%s: this reduction spans several workgroups and needs a workspace of >= %lld floats bound with ag_bind_workspace (sums are two-stage, in a fixed order; there is no float-atomic accumulation)", "ag_leaky_bwd", (long long)gx * C);
+    const int64_t zmax = ws.numel / ((int64_t)gx * C);      // partial sums per (x, z) block, fixed-order second stage
+    if (ag_cdiv(B, bper) > zmax) bper = ag_cdiv(B, (int)zmax);
+    part = ws.p;
   }
   const int gz = ag_cdiv(B, bper);
   hipLaunchKernelGGL(leaky_bwd_kernel, dim3(gx, C, gz), dim3(256), 0, (hipStream_t)stream, dy, dy_bs,
@@ -1012,8 +999,7 @@ __global__ __launch_bounds__(256) void conv_o1_wgrad_kernel(const float* __restr
     if (k < K) {      // uniform
       const float s = ag_block_sum(acc[k], red);
       if (threadIdx.x == 0) {
-        if (part) part[((int64_t)(blockIdx.z * gridDim.x + blockIdx.x) * C + c) * K + k] = s;
-        else atomicAdd(dw + c * K + k, s);
+        part[((int64_t)(blockIdx.z * gridDim.x + blockIdx.x) * C + c) * K + k] = s;
       }
     }
   }
@@ -1142,8 +1128,7 @@ __global__ __launch_bounds__(256) void conv_o1_wgrad_vec3_kernel(const float* __
   for (int k = 0; k < 3; ++k) {
     const float s = ag_block_sum(acc[k], red);
     if (threadIdx.x == 0) {
-      if (part) part[((int64_t)(blockIdx.z * gridDim.x + blockIdx.x) * C + c) * 3 + k] = s;
-      else atomicAdd(dw + c * 3 + k, s);
+      part[((int64_t)(blockIdx.z * gridDim.x + blockIdx.x) * C + c) * 3 + k] = s;
     }
   }
 }
@@ -1158,11 +1143,9 @@ extern "C" int ag_conv1d_o1_wgrad(const float* dy, int64_t dy_bs, const float* x
   int gz = ag_cdiv(2048, gx * C);
   if (gz > B) gz = B;
   if (gz < 1) gz = 1;
-  float* part = nullptr;
-  if (ws.p && ws.numel >= (int64_t)gx * C * K) {
-    if ((int64_t)gz * gx * C * K > ws.numel) gz = (int)(ws.numel / ((int64_t)gx * C * K));
-    part = ws.p;
-  }
+  AG_REQUIRE(ws.p && ws.numel >= (int64_t)gx * C * K, "%s: this reduction spans several workgroups and needs a workspace of >= %lld floats bound with ag_bind_workspace (sums are two-stage, in a fixed order; there is no float-atomic accumulation)", "ag_conv1d_o1_wgrad", (long long)gx * C * K);
+  if ((int64_t)gz * gx * C * K > ws.numel) gz = (int)(ws.numel / ((int64_t)gx * C * K));
+  float* part = ws.p;
   const int bper = ag_cdiv(B, gz);
   gz = ag_cdiv(B, bper);
   if (K == 3 && pad == 1 && L % 4 == 0 && L >= 4 && x_bs % 4 == 0 && x_cs % 4 == 0 && dy_bs % 4 == 0 &&
@@ -1170,12 +1153,10 @@ extern "C" int ag_conv1d_o1_wgrad(const float* dy, int64_t dy_bs, const float* x
     hipLaunchKernelGGL(conv_o1_wgrad_vec3_kernel, dim3(gx, C, gz), dim3(256), 0, (hipStream_t)stream, dy, dy_bs, x, x_bs,
                        x_cs, dw, B, C, L, bper, part, (int)(ag_precision() == AG_PREC_BF16));
     AG_CHECK_LAUNCH("ag_conv1d_o1_wgrad");
-    if (part) return ag_slab_reduce(part, gx * gz, (int64_t)C * K, dw, 1, (hipStream_t)stream);
-    return AG_OK;
+    return ag_slab_reduce(part, gx * gz, (int64_t)C * K, dw, 1, (hipStream_t)stream);
   }
   hipLaunchKernelGGL(conv_o1_wgrad_kernel, dim3(gx, C, gz), dim3(256), 0, (hipStream_t)stream, dy, dy_bs, x, x_bs,
                      x_cs, dw, B, C, L, K, pad, bper, part, (int)(ag_precision() == AG_PREC_BF16));
   AG_CHECK_LAUNCH("ag_conv1d_o1_wgrad");
-  if (part) return ag_slab_reduce(part, gx * gz, (int64_t)C * K, dw, 1, (hipStream_t)stream);
-  return AG_OK;
+  return ag_slab_reduce(part, gx * gz, (int64_t)C * K, dw, 1, (hipStream_t)stream);
 }

@@ -305,16 +305,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
         if (col >= p.N) continue;
         float v = p.alpha * acc[i][j][e];
         float* dst = p.C + (int64_t)row * p.ldc + col;
-        if (p.ksplit > 1) {
-          if (p.part) {
-            p.part[((int64_t)bz * p.M + row) * p.N + col] = v;
-            continue;
-          }
-          if (bz == 0) {
-            if (p.bias) v += p.bias[col];
-            if (p.res) v += p.res[(int64_t)row * p.ldres + col];
-          }
-          atomicAdd(dst, v);
+        if (p.ksplit > 1) {      // K slice: a partial tile into its slab (the host never splits K without one)
+          p.part[((int64_t)bz * p.M + row) * p.N + col] = v;
           continue;
         }
         if (p.beta != 0.f) v += p.beta * *dst;
@@ -474,16 +466,8 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmP p) {
         if (col >= p.N) continue;
         float v = p.alpha * acc[i][j][e];
         float* dst = p.C + (int64_t)row * p.ldc + col;
-        if (p.ksplit > 1) {
-          if (p.part) {
-            p.part[((int64_t)bz * p.M + row) * p.N + col] = v;
-            continue;
-          }
-          if (bz == 0) {
-            if (p.bias) v += p.bias[col];
-            if (p.res) v += p.res[(int64_t)row * p.ldres + col];
-          }
-          atomicAdd(dst, v);
+        if (p.ksplit > 1) {      // K slice: a partial tile into its slab (the host never splits K without one)
+          p.part[((int64_t)bz * p.M + row) * p.N + col] = v;
           continue;
         }
         if (p.beta != 0.f) v += p.beta * *dst;
@@ -705,16 +689,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmP p) {
         if (col >= p.N) continue;
         float v = p.alpha * acc[i][j][e];
         float* dst = p.C + (int64_t)row * p.ldc + col;
-        if (p.ksplit > 1) {
-          if (p.part) {
-            p.part[((int64_t)bz * p.M + row) * p.N + col] = v;
-            continue;
-          }
-          if (bz == 0) {
-            if (p.bias) v += p.bias[col];
-            if (p.res) v += p.res[(int64_t)row * p.ldres + col];
-          }
-          atomicAdd(dst, v);
+        if (p.ksplit > 1) {      // K slice: a partial tile into its slab (the host never splits K without one)
+          p.part[((int64_t)bz * p.M + row) * p.N + col] = v;
           continue;
         }
         if (p.beta != 0.f) v += p.beta * *dst;
@@ -843,33 +819,22 @@ extern "C" int ag_gemm(const float* A, int lda, int ta, const float* B, int ldb,
   const int64_t big = (int64_t)ag_cdiv(M, 128) * ag_cdiv(N, 128);
   const bool use128 = M > 64 && N > 64 && (big >= 192 || K >= 2048);
   const int64_t tiles = use128 ? big : (int64_t)ag_cdiv(M, 64) * ag_cdiv(N, 64);
-  // few output tiles but a long reduction (weight gradients over all frames): slice K over grid.z.  With a bound
-  // workspace the slices' partial tiles are summed in a fixed order by a second kernel (deterministic); without one
-  // they are combined with atomics.  Needs a linear epilogue.
+  // few output tiles but a long reduction (weight gradients over all frames): slice K over grid.z; the slices' partial
+  // tiles go to the bound workspace and are summed in a fixed order by a second kernel (deterministic).  Needs a linear
+  // epilogue.
   p.part = nullptr;
   if (tiles < 192 && K >= 1024 && act == AG_ACT_NONE) {
     const int64_t mn = (int64_t)M * N;
     int ks = gemm_pick_ksplit(tiles, mn, K);
+    // (no bound workspace, or one too small for two slices: the product runs unsplit - slower, same result class; the
+    // float-atomic combination of round 1 is gone)
     const bool slabs = ws.p && ws.numel >= 2 * mn;
     if (slabs && (int64_t)ks * mn > ws.numel) ks = (int)(ws.numel / mn);
-    if (ks >= 2 && (slabs || beta == 0.f || beta == 1.f)) {
+    if (ks >= 2 && slabs) {
       p.ksplit = ks;
       p.kchunk = ag_roundup(ag_cdiv(K, ks), 64);
       p.ksplit = ag_cdiv(K, p.kchunk);
-      if (slabs) {
-        p.part = ws.p;
-      } else if (beta == 0.f) {
-        if (ldc == N) {
-          if (hipMemsetAsync(C, 0, sizeof(float) * (size_t)M * N, st) != hipSuccess) {
-            ag_set_error("ag_gemm: memset failed");
-            return AG_ERR_LAUNCH;
-          }
-        } else if (hipMemset2DAsync(C, sizeof(float) * (size_t)ldc, 0, sizeof(float) * (size_t)N, M, st) !=
-                   hipSuccess) {
-          ag_set_error("ag_gemm: memset2D failed");
-          return AG_ERR_LAUNCH;
-        }
-      }
+      p.part = p.ksplit > 1 ? ws.p : nullptr;
     }
   }
   int rc;
@@ -891,6 +856,10 @@ extern "C" int ag_gemm(const float* A, int lda, int ta, const float* B, int ldb,
     rc = launch_gemm<1, 1, 2, 2>(p, ta, tb, st);              // 64x64
   }
   if (rc != AG_OK || !p.part) return rc;
+  // a weight gradient's second stage inside a deferral scope joins the scope's ONE launch: slab z of a contiguous C is
+  // exactly ag_slab_reduce's layout and both kernels sum z = zq, zq + 8, ... then zq = 0..7 (bitwise the same result)
+  if (ag_reduces_deferred() && !bias && !res && (beta == 0.f || beta == 1.f))
+    return ag_slab_defer_2d(p.part, p.ksplit, M, N, C, ldc, beta == 1.f ? 1 : 0, st);
   return ag_splitk_reduce(p.part, p.ksplit, (int64_t)M * N, M, N, C, ldc, beta, bias, res, ldres, st);
 }
 
@@ -904,10 +873,10 @@ extern "C" int64_t ag_gemm_ws_numel(int M, int N, int K, int act) {
   return ks >= 2 ? (int64_t)ks * M * N : 0;
 }
 
-// out[n] += sum_m X[m, n]
+// out[n] (+)= sum_m X[m, n]
 __global__ __launch_bounds__(256) void col_sum_kernel(const float* __restrict__ X, int ldx,
                                                       float* __restrict__ out, int M, int N,
-                                                      int rows_per, float* __restrict__ part) {
+                                                      int rows_per, float* __restrict__ part, int accumulate) {
   const int n = blockIdx.x * 64 + (threadIdx.x & 63);
   const int sub = threadIdx.x >> 6;  // 4 row-phases per block
   const int mbeg = blockIdx.y * rows_per;
@@ -922,11 +891,11 @@ __global__ __launch_bounds__(256) void col_sum_kernel(const float* __restrict__ 
   if (sub == 0 && n < N) {
     s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
     if (part) part[(int64_t)blockIdx.y * N + n] = s;
-    else atomicAdd(out + n, s);
+    else out[n] = accumulate ? out[n] + s : s;        // one row block: this thread is the only writer of out[n]
   }
 }
 
-extern "C" int ag_col_sum(const float* X, int ldx, float* out, int M, int N, void* stream) {
+extern "C" int ag_col_sum(const float* X, int ldx, float* out, int M, int N, int accumulate, void* stream) {
   const AgWs ws = ag_ws_take();     // FIRST: an argument error below must not leave a stale binding behind
   AG_REQUIRE(X && out && M > 0 && N > 0 && ldx >= N, "ag_col_sum: bad args");
   const int gx = ag_cdiv(N, 64);
@@ -934,15 +903,18 @@ extern "C" int ag_col_sum(const float* X, int ldx, float* out, int M, int N, voi
   if (gy > ag_cdiv(M, 16)) gy = ag_cdiv(M, 16);
   if (gy < 1) gy = 1;
   float* part = nullptr;
-  if (gy > 1 && ws.p && ws.numel >= 2 * (int64_t)N) {   // (one row block: a single writer per column, nothing to order)
+  if (gy > 1 && ws.p && ws.numel >= 2 * (int64_t)N) {
     if ((int64_t)gy * N > ws.numel) gy = (int)(ws.numel / N);
     part = ws.p;
+  } else {
+    gy = 1;       // one row block: a single writer per column, nothing to order (and no workspace needed)
   }
   const int rows_per = ag_cdiv(M, gy);
   gy = ag_cdiv(M, rows_per);
+  if (gy == 1) part = nullptr;
   hipLaunchKernelGGL(col_sum_kernel, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, X, ldx, out, M,
-                     N, rows_per, part);
+                     N, rows_per, part, accumulate);
   AG_CHECK_LAUNCH("ag_col_sum");
-  if (part) return ag_slab_reduce(part, gy, N, out, 1, (hipStream_t)stream);
+  if (part) return ag_slab_reduce(part, gy, N, out, accumulate ? 1 : 0, (hipStream_t)stream);
   return AG_OK;
 }

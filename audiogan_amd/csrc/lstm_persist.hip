@@ -403,6 +403,7 @@ struct PersistBwdDir {
   const float* whh;     // [4H,H]
   const float* c_all;   // [T+1,B,H]
   float* dgates;        // [T,B,4H] out (and exchange)
+  float* dgsum;         // optional [B,4H] out: sum over time of dgates (what the biases and a time-invariant input see)
 };
 
 struct PersistBwdP {
@@ -470,6 +471,7 @@ __global__ __launch_bounds__(512) void lstm_persist_bwd_kernel(const PersistBwdP
   const bool epi = em < B;
   const int64_t vlen = (epi && p.valid) ? p.valid[em] : ((int64_t)1 << 60);
   float dcn = 0.f, dpass = 0.f;
+  float sum0 = 0.f, sum1 = 0.f, sum2 = 0.f, sum3 = 0.f;      // time sums of this thread's four dgates (fixed order: k = T-1 .. 0)
   // A operand row of this lane (clamped: rows past the batch only feed their own, unwritten outputs)
   const int arow = min(m0 + li, B - 1);
   const unsigned aoff = (unsigned)(((int64_t)arow * 4 * H + (wid * NU) * 16 + 4 * g) * 4);
@@ -556,6 +558,7 @@ __global__ __launch_bounds__(512) void lstm_persist_bwd_kernel(const PersistBwdP
         dpass = 0.f;
       }
       if (s_dead) { d0 = d1 = d2 = d3 = dcn = __builtin_nanf(""); }   // a wait timed out: poison instead of garbage
+      sum0 += d0; sum1 += d1; sum2 += d2; sum3 += d3;
       __amdgpu_buffer_rsrc_t orr = __builtin_amdgcn_make_buffer_rsrc(D.dgates + (int64_t)t * BG, 0, (int)(BG * 4), 0x00020000);
       const unsigned o = (unsigned)(((int64_t)em * 4 * H + eu) * 4);
       __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(d0), orr, o, 0, 16);
@@ -569,6 +572,10 @@ __global__ __launch_bounds__(512) void lstm_persist_bwd_kernel(const PersistBwdP
       if (tid == 0 && (int)blockIdx.x != p.ctl.mute)
         __hip_atomic_store(flags + ut, (unsigned)(T - k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+  }
+  if (epi && D.dgsum) {
+    float* q = D.dgsum + (int64_t)em * 4 * H + eu;
+    q[0] = sum0; q[H] = sum1; q[2 * H] = sum2; q[3 * H] = sum3;
   }
 }
 
@@ -586,8 +593,8 @@ extern "C" int ag_lstm_persist_bwd_ok(int B, int H, int ndir, int n_cu) {
 // Whole layer backward through time in ONE launch; tensors as for ag_lstm_seq_bwd (no scratch state: dc and the
 // pass-through term stay in registers).  `ws`: >= 8 KiB (status + flags), zeroed by a memset node in front.
 extern "C" int ag_lstm_seq_bwd_persist(const float* const* gates, const float* const* whh, const float* const* c_all,
-                                       const float* dy, float* const* dgates, const int64_t* valid_i64, void* ws,
-                                       int64_t ws_bytes, int T, int B, int H, int ndir, int n_cu, void* stream) {
+                                       const float* dy, float* const* dgates, float* const* dgsum, const int64_t* valid_i64,
+                                       void* ws, int64_t ws_bytes, int T, int B, int H, int ndir, int n_cu, void* stream) {
   AG_REQUIRE(gates && whh && c_all && dy && dgates && ws, "ag_lstm_seq_bwd_persist: null tensor");
   AG_REQUIRE(ndir == 1 || ndir == 2, "ag_lstm_seq_bwd_persist: ndir must be 1 or 2");
   AG_REQUIRE(T > 0, "ag_lstm_seq_bwd_persist: T must be positive");
@@ -606,6 +613,7 @@ extern "C" int ag_lstm_seq_bwd_persist(const float* const* gates, const float* c
   for (int d = 0; d < 2; ++d) {
     const int s = d < ndir ? d : 0;
     p.d[d].ga = gates[s]; p.d[d].whh = whh[s]; p.d[d].c_all = c_all[s]; p.d[d].dgates = dgates[s];
+    p.d[d].dgsum = dgsum ? dgsum[s] : nullptr;
   }
   p.dy = dy; p.valid = valid_i64; p.ctl = ps_ctl(ws);
   p.T = T; p.B = B; p.H = H; p.ndir = ndir; p.nbt = ag_cdiv(B, 16); p.ntile = H / 32;
@@ -648,7 +656,9 @@ struct FrontFwdP {
   const float* bp;     // [fs]
   float* hs;           // [T,B,S]
   float* cs;           // [T+1,B,S]  (cs[0] is written 0 by the launch)
-  float* x;            // [B, T*fs]
+  float* x;            // [B, T*fs], row pitch ldx (the caller may hand over channel 0 of the conv trunk's slab)
+  float* xt;           // optional [T,B,fs]: the same frames time-major (what the weight-gradient products read)
+  int64_t ldx;
   float* gh;           // GRU cell only: [T,B,3S], the n slot receives W_hn h + b_hn (what the backward needs)
   const float* bhn;    // GRU cell only: b_hh[2S:3S]
   float* hx;           // exchange: h   [2][nrt][S/8][32][8]
@@ -950,7 +960,10 @@ __global__ __launch_bounds__(512) void gfront_persist_fwd_kernel(const FrontFwdP
         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(bm < B ? v : 0.f), xr,
             (unsigned)(((int64_t)((t & 1) * p.nrt + rt) * xgs + ((int64_t)(col >> 3) * 32 + 16 * bsub + brow) * 8 + (col & 7)) * 4), 0, 16);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (bm < B) p.x[(int64_t)bm * T * FS + (int64_t)t * FS + col] = v;
+        if (bm < B) {
+          p.x[(int64_t)bm * p.ldx + (int64_t)t * FS + col] = v;
+          if (p.xt) p.xt[((int64_t)t * B + bm) * FS + col] = v;
+        }
       }
       __syncthreads();
       if (tid == 0) __hip_atomic_store(flag_x + ut, (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -975,10 +988,11 @@ extern "C" int64_t ag_gfront_persist_ws_bytes(int B, int S, int fs) {
 // part of the pre-activations + both biases, out = activated gates; w_x = W_ih[:, :fs] (row pitch ldwx), w_hh [4S,S],
 // w_p [fs,S], b_p [fs]; outputs hs [T,B,S], cs [T+1,B,S] (cs[0] is written 0 by the launch), x [B,T*fs].  Shapes: ag_gfront_persist_ok.
 extern "C" int ag_gfront_fwd_persist(float* gates, const float* w_x, int ldwx, const float* w_hh, const float* w_p,
-                                     const float* b_p, float* hs, float* cs, float* x, void* ws, int64_t ws_bytes,
-                                     int T, int B, int S, int fs, int n_cu, void* stream) {
+                                     const float* b_p, float* hs, float* cs, float* x, int64_t ldx, float* xt, void* ws,
+                                     int64_t ws_bytes, int T, int B, int S, int fs, int n_cu, void* stream) {
   AG_REQUIRE(gates && w_x && w_hh && w_p && b_p && hs && cs && x && ws, "ag_gfront_fwd_persist: null tensor");
   AG_REQUIRE(T > 0, "ag_gfront_fwd_persist: T must be positive");
+  AG_REQUIRE(ldx >= (int64_t)T * fs, "ag_gfront_fwd_persist: x row pitch smaller than a row");
   if (!front_shape_ok(B, S, fs, n_cu)) {
     ag_set_error("ag_gfront_fwd_persist: shape B=%d S=%d fs=%d is not supported on %d CUs", B, S, fs, n_cu);
     return AG_ERR_UNSUPPORTED;
@@ -994,6 +1008,7 @@ extern "C" int ag_gfront_fwd_persist(float* gates, const float* w_x, int ldwx, c
   }
   FrontFwdP p;
   p.gates = gates; p.gh = nullptr; p.bhn = nullptr; p.wx = w_x; p.whh = w_hh; p.wp = w_p; p.bp = b_p; p.hs = hs; p.cs = cs; p.x = x;
+  p.ldx = ldx; p.xt = xt;
   p.ctl = ps_ctl(ws);
   p.nrt = ag_cdiv(B, 32);
   p.hx = (float*)((char*)ws + PS_STICKY_BYTES + PS_HDR_BYTES);
@@ -1017,10 +1032,12 @@ extern "C" int ag_gfront_fwd_persist(float* gates, const float* w_x, int ldwx, c
 //   w_x = W_ih[:, :fs] (row pitch ldwx), w_hh [3S,S], b_hn [S] = b_hh[2S:], w_p [fs,S], b_p [fs]
 //   hs [T,B,S] (h_t), x [B,T*fs].  Shapes as ag_gfront_persist_ok; workspace as ag_gfront_fwd_persist.
 extern "C" int ag_grufront_fwd_persist(float* gates, float* gh, const float* w_x, int ldwx, const float* w_hh,
-                                       const float* b_hn, const float* w_p, const float* b_p, float* hs, float* x, void* ws,
-                                       int64_t ws_bytes, int T, int B, int S, int fs, int n_cu, void* stream) {
+                                       const float* b_hn, const float* w_p, const float* b_p, float* hs, float* x, int64_t ldx,
+                                       float* xt, void* ws, int64_t ws_bytes, int T, int B, int S, int fs, int n_cu,
+                                       void* stream) {
   AG_REQUIRE(gates && gh && w_x && w_hh && b_hn && w_p && b_p && hs && x && ws, "ag_grufront_fwd_persist: null tensor");
   AG_REQUIRE(T > 0, "ag_grufront_fwd_persist: T must be positive");
+  AG_REQUIRE(ldx >= (int64_t)T * fs, "ag_grufront_fwd_persist: x row pitch smaller than a row");
   if (!front_shape_ok(B, S, fs, n_cu)) {
     ag_set_error("ag_grufront_fwd_persist: shape B=%d S=%d fs=%d is not supported on %d CUs", B, S, fs, n_cu);
     return AG_ERR_UNSUPPORTED;
@@ -1036,6 +1053,7 @@ extern "C" int ag_grufront_fwd_persist(float* gates, float* gh, const float* w_x
   }
   FrontFwdP p;
   p.gates = gates; p.gh = gh; p.bhn = b_hn; p.wx = w_x; p.whh = w_hh; p.wp = w_p; p.bp = b_p; p.hs = hs; p.cs = nullptr; p.x = x;
+  p.ldx = ldx; p.xt = xt;
   p.ctl = ps_ctl(ws);
   p.nrt = ag_cdiv(B, 32);
   p.hx = (float*)((char*)ws + PS_STICKY_BYTES + PS_HDR_BYTES);
@@ -1069,8 +1087,10 @@ extern "C" int ag_grufront_fwd_persist(float* gates, float* gh, const float* w_x
 struct FrontBwdP {
   const float* ga;     // [T,B,4S] activated gates (i, f, g, o)
   const float* c_all;  // [T+1,B,S]
-  const float* x;      // [B,T*fs] the front's output (after tanh)
-  const float* dacc;   // [T,B,S+fs] external gradient [dL/dh_t | dL/dx_t]
+  const float* x;      // [B,T*fs] the front's output (after tanh), row pitch ldx
+  const float* dh_ext; // [T,B,S] external gradient dL/dh_t (the stop head's), or NULL = none
+  const float* dx_ext; // [B,T*fs] external gradient dL/dx_t (the conv trunk's), row pitch lddx, or NULL = none
+  int64_t ldx, lddx;
   const float* w_hh;   // [4S,S]
   const float* w_x;    // [4S,ldwx]: W_ih[:, :fs]
   const float* w_p;    // [fs,S]
@@ -1113,7 +1133,7 @@ __global__ __launch_bounds__(512) void gfront_persist_bwd_kernel(const FrontBwdP
   const bool isx = ct >= NHT;
   const int m0 = bt * 32;
   const int n0 = (isx ? ct - NHT : ct) * 16;                // first column inside W_hh / W_x
-  const int64_t BG = (int64_t)B * K4, BH = (int64_t)B * S, BX = (int64_t)B * FS, BA = (int64_t)B * (S + FS);
+  const int64_t BG = (int64_t)B * K4, BH = (int64_t)B * S, BX = (int64_t)B * FS;
 
   // resident panel: wreg[u][e] = W[(wid*NU + u)*16 + 4g + e][n0 + li]
   float wreg[NU][4];
@@ -1151,8 +1171,8 @@ __global__ __launch_bounds__(512) void gfront_persist_bwd_kernel(const FrontBwdP
     const unsigned seq = (unsigned)(T - t);
     if (isx) {
       if (epi) {
-        const float dx = p.dacc[(int64_t)t * BA + (int64_t)em * (S + FS) + S + n0 + ecol] + carry;
-        const float xv = p.x[(int64_t)em * T * FS + (int64_t)t * FS + n0 + ecol];
+        const float dx = (p.dx_ext ? p.dx_ext[(int64_t)em * p.lddx + (int64_t)t * FS + n0 + ecol] : 0.f) + carry;
+        const float xv = p.x[(int64_t)em * p.ldx + (int64_t)t * FS + n0 + ecol];
         float gx = dx * (1.f - xv * xv);
         if (s_dead) gx = __builtin_nanf("");
         __amdgpu_buffer_rsrc_t orr = __builtin_amdgcn_make_buffer_rsrc(p.dxt + (int64_t)t * BX, 0, (int)(BX * 4), 0x00020000);
@@ -1170,7 +1190,7 @@ __global__ __launch_bounds__(512) void gfront_persist_bwd_kernel(const FrontBwdP
           og = gr[3 * S];
           cn = p.c_all[(int64_t)(t + 1) * BH + (int64_t)em * S + n0 + ecol];
         }
-        ext = p.dacc[(int64_t)t * BA + (int64_t)em * (S + FS) + n0 + ecol];
+        ext = p.dh_ext ? p.dh_ext[(int64_t)t * BH + (int64_t)em * S + n0 + ecol] : 0.f;
       }
       if (wid == 0 && alive) {
         alive = ps_wait_flags(p.ctl, flags_x, NXT, seq, lane);
@@ -1297,38 +1317,42 @@ static bool front_bwd_shape_ok(int B, int S, int fs, int n_cu) {
 extern "C" int ag_gfront_bwd_persist_ok(int B, int S, int fs, int n_cu) { return front_bwd_shape_ok(B, S, fs, n_cu) ? 1 : 0; }
 
 // The frame loop of the Generator front's backward in ONE launch.  ga [T,B,4S] activated gates and c_all [T+1,B,S] as
-// saved by the forward, x [B,T*fs] the front's output, dacc [T,B,S+fs] the external gradient [dL/dh_t | dL/dx_t] (read
-// only), w_hh [4S,S], w_x = W_ih[:, :fs] (row pitch ldwx), w_p [fs,S]; outputs dgs [T,B,4S] (d gate pre-activations) and
+// saved by the forward, x [B,T*fs] the front's output (row pitch ldx), the external gradients dh_ext [T,B,S] = dL/dh_t
+// (the stop head's) and dx_ext [B,T*fs] = dL/dx_t (the conv trunk's, row pitch lddx: it may be channel 0 of the trunk's
+// gradient slab) - each read only, each may be NULL = zero -, w_hh [4S,S], w_x = W_ih[:, :fs] (row pitch ldwx), w_p [fs,S]; outputs dgs [T,B,4S] (d gate pre-activations) and
 // dxt [T,B,fs] (d pre-tanh of the projection).  `ws`: >= PS_STICKY_BYTES + 8 KiB (status + flags).
-static int front_bwd_launch(int cell, const float* ga, const float* c_all, const float* gh, const float* x, const float* dacc,
-                            const float* w_hh, const float* w_x, int ldwx, const float* w_p, float* dgs, float* dgh,
-                            float* dxt, void* ws, int64_t ws_bytes, int T, int B, int S, int fs, int n_cu, void* stream);
+static int front_bwd_launch(int cell, const float* ga, const float* c_all, const float* gh, const float* x, int64_t ldx,
+                            const float* dh_ext, const float* dx_ext, int64_t lddx, const float* w_hh, const float* w_x,
+                            int ldwx, const float* w_p, float* dgs, float* dgh, float* dxt, void* ws, int64_t ws_bytes, int T,
+                            int B, int S, int fs, int n_cu, void* stream);
 
-extern "C" int ag_gfront_bwd_persist(const float* ga, const float* c_all, const float* x, const float* dacc,
-                                     const float* w_hh, const float* w_x, int ldwx, const float* w_p, float* dgs,
-                                     float* dxt, void* ws, int64_t ws_bytes, int T, int B, int S, int fs, int n_cu,
-                                     void* stream) {
-  return front_bwd_launch(0, ga, c_all, nullptr, x, dacc, w_hh, w_x, ldwx, w_p, dgs, dgs, dxt, ws, ws_bytes, T, B, S, fs,
-                          n_cu, stream);
+extern "C" int ag_gfront_bwd_persist(const float* ga, const float* c_all, const float* x, int64_t ldx, const float* dh_ext,
+                                     const float* dx_ext, int64_t lddx, const float* w_hh, const float* w_x, int ldwx,
+                                     const float* w_p, float* dgs, float* dxt, void* ws, int64_t ws_bytes, int T, int B,
+                                     int S, int fs, int n_cu, void* stream) {
+  return front_bwd_launch(0, ga, c_all, nullptr, x, ldx, dh_ext, dx_ext, lddx, w_hh, w_x, ldwx, w_p, dgs, dgs, dxt, ws,
+                          ws_bytes, T, B, S, fs, n_cu, stream);
 }
 
 // The same for the GRU front (BASELINE configs[3]; torch.nn.GRUCell, gate order r z n): ga [T,B,3S] activated gates, hs
 // [T+1,B,S] (hs[t] = h_{t-1}, hs[0] = 0) and gh [T,B,3S] (n slot) as saved by ag_grufront_fwd_persist; outputs dgi
 // [T,B,3S] (d of the input-side pre-activations), dgh [T,B,3S] (hidden side: the n slot times r) and dxt [T,B,fs].
-extern "C" int ag_grufront_bwd_persist(const float* ga, const float* hs, const float* gh, const float* x,
-                                       const float* dacc, const float* w_hh, const float* w_x, int ldwx,
-                                       const float* w_p, float* dgi, float* dgh, float* dxt, void* ws, int64_t ws_bytes,
-                                       int T, int B, int S, int fs, int n_cu, void* stream) {
+extern "C" int ag_grufront_bwd_persist(const float* ga, const float* hs, const float* gh, const float* x, int64_t ldx,
+                                       const float* dh_ext, const float* dx_ext, int64_t lddx, const float* w_hh,
+                                       const float* w_x, int ldwx, const float* w_p, float* dgi, float* dgh, float* dxt,
+                                       void* ws, int64_t ws_bytes, int T, int B, int S, int fs, int n_cu, void* stream) {
   AG_REQUIRE(gh && dgh, "ag_grufront_bwd_persist: null tensor");
-  return front_bwd_launch(1, ga, hs, gh, x, dacc, w_hh, w_x, ldwx, w_p, dgi, dgh, dxt, ws, ws_bytes, T, B, S, fs, n_cu,
-                          stream);
+  return front_bwd_launch(1, ga, hs, gh, x, ldx, dh_ext, dx_ext, lddx, w_hh, w_x, ldwx, w_p, dgi, dgh, dxt, ws, ws_bytes, T,
+                          B, S, fs, n_cu, stream);
 }
 
-static int front_bwd_launch(int cell, const float* ga, const float* c_all, const float* gh, const float* x, const float* dacc,
-                            const float* w_hh, const float* w_x, int ldwx, const float* w_p, float* dgs, float* dgh,
-                            float* dxt, void* ws, int64_t ws_bytes, int T, int B, int S, int fs, int n_cu, void* stream) {
-  AG_REQUIRE(ga && c_all && x && dacc && w_hh && w_x && w_p && dgs && dxt && ws, "ag_gfront_bwd_persist: null tensor");
+static int front_bwd_launch(int cell, const float* ga, const float* c_all, const float* gh, const float* x, int64_t ldx,
+                            const float* dh_ext, const float* dx_ext, int64_t lddx, const float* w_hh, const float* w_x,
+                            int ldwx, const float* w_p, float* dgs, float* dgh, float* dxt, void* ws, int64_t ws_bytes, int T,
+                            int B, int S, int fs, int n_cu, void* stream) {
+  AG_REQUIRE(ga && c_all && x && w_hh && w_x && w_p && dgs && dxt && ws, "ag_gfront_bwd_persist: null tensor");
   AG_REQUIRE(T > 0, "ag_gfront_bwd_persist: T must be positive");
+  AG_REQUIRE(ldx >= (int64_t)T * fs && (!dx_ext || lddx >= (int64_t)T * fs), "ag_gfront_bwd_persist: row pitch smaller than a row");
   if (!front_bwd_shape_ok(B, S, fs, n_cu)) {
     ag_set_error("ag_gfront_bwd_persist: shape B=%d S=%d fs=%d is not supported on %d CUs", B, S, fs, n_cu);
     return AG_ERR_UNSUPPORTED;
@@ -1343,7 +1367,7 @@ static int front_bwd_launch(int cell, const float* ga, const float* c_all, const
     return AG_ERR_LAUNCH;
   }
   FrontBwdP p;
-  p.ga = ga; p.c_all = c_all; p.x = x; p.dacc = dacc; p.w_hh = w_hh; p.w_x = w_x; p.w_p = w_p; p.dgs = dgs; p.dxt = dxt;
+  p.ga = ga; p.c_all = c_all; p.x = x; p.ldx = ldx; p.dh_ext = dh_ext; p.dx_ext = dx_ext; p.lddx = lddx; p.w_hh = w_hh; p.w_x = w_x; p.w_p = w_p; p.dgs = dgs; p.dxt = dxt;
   p.gh = gh; p.dgh = dgh;
   p.ctl = ps_ctl(ws);
   p.T = T; p.B = B; p.ldwx = ldwx;

@@ -204,12 +204,9 @@ __global__ __launch_bounds__(1024) void skinny_gemm_kernel(const SkinnyP p) {
       if (p.beta != 0.f) v += p.beta * *dst;
       if (Q.bias) v += Q.bias[n];
       *dst = ag_apply_act(v, p.act, p.slope);
-    } else if (p.part) {
+    } else {      // K split over workgroups: partial products into the slabs (the host binds them; fixed-order second stage)
       const int prob = blockIdx.z / p.mtiles, nprob = gridDim.z / p.mtiles;
       p.part[(((int64_t)blockIdx.y * nprob + prob) * p.M + m) * p.N + n] = v;
-    } else {
-      if (Q.bias && blockIdx.y == 0) v += Q.bias[n];
-      atomicAdd(dst, v);
     }
   }
 }
@@ -282,10 +279,9 @@ static int launch_skinny(SkinnyP& p, int nprob, int accumulate_atomic, hipStream
     if (gy * nw > KU) gy = ag_cdiv(KU, nw);
     if (gy < 2) gy = 2;  // keep the split epilogue (C holds the addend)
     const int64_t slab = (int64_t)nprob * p.M * p.N;
-    if (ws.p && ws.numel >= 2 * slab) {     // two-stage: partial products, then a fixed-order sum into C
-      if ((int64_t)gy * slab > ws.numel) gy = (int)(ws.numel / slab);
-      p.part = ws.p;
-    }
+    AG_REQUIRE(ws.p && ws.numel >= 2 * slab, "%s: this reduction spans several workgroups and needs a workspace of >= %lld floats bound with ag_bind_workspace (sums are two-stage, in a fixed order; there is no float-atomic accumulation)", "ag_skinny_gemm (accumulate mode)", (long long)2 * slab);
+    if ((int64_t)gy * slab > ws.numel) gy = (int)(ws.numel / slab);     // two-stage: partial products, then a fixed-order sum into C
+    p.part = ws.p;
   } else {
     gy = 1;
     nw = ag_cdiv(2048, gx * gz);

@@ -404,11 +404,21 @@ extern "C" int ag_axpby(const float* x, float* y, int64_t n, float a, float b, v
 // ------------------------------------------------------------------------------------------
 #define OPT_CHUNKS 256
 
-__global__ __launch_bounds__(256) void grad_norms_kernel(const ag_opt_desc* __restrict__ descs,
-                                                         float* __restrict__ sq, int32_t* __restrict__ flags,
-                                                         float gscale, float* __restrict__ part) {
+__global__ __launch_bounds__(256) void grad_norms_kernel(const ag_opt_desc* __restrict__ descs, float gscale,
+                                                         float* __restrict__ part, int32_t* __restrict__ step_dev) {
+  if (step_dev && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) step_dev[0] += 1;   // (read by ag_opt_step only)
+  // part: [n][OPT_CHUNKS] partial sums of squares, then [n][OPT_CHUNKS] flag words (as floats' bit patterns) - every slot
+  // is written by its workgroup, so nothing needs zeroing in front of the launch
   __shared__ float red[17];
+  __shared__ int fsh;
   const ag_opt_desc d = descs[blockIdx.y];
+  float* fpart = part + (int64_t)gridDim.y * OPT_CHUNKS;
+  const int64_t slot = (int64_t)blockIdx.y * OPT_CHUNKS + blockIdx.x;
+  if ((int64_t)blockIdx.x * 256 >= d.n) {  // uniform per block
+    if (threadIdx.x == 0) { part[slot] = 0.f; fpart[slot] = __int_as_float(0); }
+    return;
+  }
+  if (threadIdx.x == 0) fsh = 0;
   float s = 0.f;
   int f = 0;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < d.n; i += (int64_t)gridDim.x * 256) {
@@ -417,54 +427,63 @@ __global__ __launch_bounds__(256) void grad_norms_kernel(const ag_opt_desc* __re
     if (g != g) f |= AG_FLAG_NAN;
     if (fabsf(g) > 1e5f) f |= AG_FLAG_BIG;
   }
-  if ((int64_t)blockIdx.x * 256 >= d.n) {  // uniform per block
-    if (part && threadIdx.x == 0) part[(int64_t)blockIdx.y * OPT_CHUNKS + blockIdx.x] = 0.f;
-    return;
-  }
-  s = ag_block_sum(s, red);
-  if (threadIdx.x == 0) {
-    if (part) part[(int64_t)blockIdx.y * OPT_CHUNKS + blockIdx.x] = s;
-    else atomicAdd(sq + blockIdx.y, s);
-  }
-  if (f && flags) atomicOr(flags, f);
+  s = ag_block_sum(s, red);             // (its first barrier also orders the fsh = 0 above)
+  if (f) atomicOr(&fsh, f);             // LDS, integer: order-independent
+  __syncthreads();
+  if (threadIdx.x == 0) { part[slot] = s; fpart[slot] = __int_as_float(fsh); }
 }
 
-__global__ void grad_norms_finish_kernel(float* __restrict__ sq_to_norm, float* __restrict__ norm_sum,
-                                         int n, int32_t* __restrict__ step_dev, const float* __restrict__ part) {
-  if (threadIdx.x == 0 && step_dev) step_dev[0] += 1;
-  // single block: norms[i] = sqrt(sq[i]); norm_sum = sum_i norms[i] (deterministic order)
+// norms of all tensors from the per-chunk partials; one workgroup.  Shared by the stand-alone finishing launch of
+// ag_grad_norms and by workgroup (0, 0) of ag_opt_step's fused form.
+__device__ __forceinline__ void grad_norms_finish(float* __restrict__ sq_to_norm, float* __restrict__ norm_sum,
+                                                  int32_t* __restrict__ flags, int n, const float* __restrict__ part);
+
+__global__ void grad_norms_finish_kernel(float* __restrict__ sq_to_norm, float* __restrict__ norm_sum, int32_t* __restrict__ flags,
+                                         int n, const float* __restrict__ part) {
+  grad_norms_finish(sq_to_norm, norm_sum, flags, n, part);
+}
+
+__device__ __forceinline__ void grad_norms_finish(float* __restrict__ sq_to_norm, float* __restrict__ norm_sum,
+                                                  int32_t* __restrict__ flags, int n, const float* __restrict__ part) {
+  // single block: norms[i] = sqrt(sum of tensor i's per-chunk partials in chunk order); norm_sum = sum_i norms[i]
+  // (deterministic order); flags = OR of every chunk's flag word (WRITTEN, not accumulated)
   __shared__ float red[17];
+  __shared__ int fsh;
+  if (threadIdx.x == 0) fsh = 0;
+  __syncthreads();
+  const float* fpart = part + (int64_t)n * OPT_CHUNKS;
   float s = 0.f;
+  int f = 0;
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    if (part) {          // sum of squares of tensor i = its per-chunk partials in chunk order
-      float q = 0.f;
-      for (int c = 0; c < OPT_CHUNKS; ++c) q += part[(int64_t)i * OPT_CHUNKS + c];
-      sq_to_norm[i] = q;
+    float q = 0.f;
+    for (int c = 0; c < OPT_CHUNKS; ++c) {
+      q += part[(int64_t)i * OPT_CHUNKS + c];
+      f |= __float_as_int(fpart[(int64_t)i * OPT_CHUNKS + c]);
     }
-    const float nr = sqrtf(sq_to_norm[i]);
+    const float nr = sqrtf(q);
     sq_to_norm[i] = nr;
     s += nr;
   }
+  if (f) atomicOr(&fsh, f);
   s = ag_block_sum(s, red);
   if (threadIdx.x == 0 && norm_sum) norm_sum[0] = s;
+  if (threadIdx.x == 0 && flags) flags[0] = fsh;
 }
 
 extern "C" int ag_grad_norms(const ag_opt_desc* descs_dev, int n, float* norms, float* norm_sum,
-                             int32_t* flags, float grad_scale, int32_t* step_dev, void* stream) {
+                             int32_t* flags, float grad_scale, int32_t* step_dev, int finish, void* stream) {
   const AgWs ws = ag_ws_take();     // FIRST: an argument error below must not leave a stale binding behind
   AG_REQUIRE(descs_dev && norms && n > 0 && n <= 65535, "ag_grad_norms: bad args");
+  AG_REQUIRE(ws.p && ws.numel >= (int64_t)2 * n * OPT_CHUNKS,
+             "ag_grad_norms: bind a workspace of >= %lld floats (ag_bind_workspace): per-chunk sums of squares and flag words, "
+             "summed in a fixed order (there is no float-atomic accumulation)", (long long)2 * n * OPT_CHUNKS);
   hipStream_t st = (hipStream_t)stream;
-  float* part = (ws.p && ws.numel >= (int64_t)n * OPT_CHUNKS) ? ws.p : nullptr;    // two-stage sum of squares
-  if (!part && hipMemsetAsync(norms, 0, sizeof(float) * n, st) != hipSuccess) {
-    ag_set_error("ag_grad_norms: memset failed");
-    return AG_ERR_LAUNCH;
-  }
-  if (flags) (void)hipMemsetAsync(flags, 0, sizeof(int32_t), st);
-  hipLaunchKernelGGL(grad_norms_kernel, dim3(OPT_CHUNKS, n), dim3(256), 0, st, descs_dev, norms, flags,
-                     grad_scale, part);
+  hipLaunchKernelGGL(grad_norms_kernel, dim3(OPT_CHUNKS, n), dim3(256), 0, st, descs_dev, grad_scale, ws.p, step_dev);
   AG_CHECK_LAUNCH("ag_grad_norms");
-  hipLaunchKernelGGL(grad_norms_finish_kernel, dim3(1), dim3(256), 0, st, norms, norm_sum, n, step_dev, part);
-  AG_CHECK_LAUNCH("ag_grad_norms(finish)");
+  if (finish) {
+    hipLaunchKernelGGL(grad_norms_finish_kernel, dim3(1), dim3(256), 0, st, norms, norm_sum, flags, n, ws.p);
+    AG_CHECK_LAUNCH("ag_grad_norms(finish)");
+  }
   return AG_OK;
 }
 
@@ -472,14 +491,32 @@ __global__ __launch_bounds__(256) void opt_step_kernel(const ag_opt_desc* __rest
                                                        const float* __restrict__ norms, int kind, float lr,
                                                        float clip, float gscale, float a1, float b2,
                                                        float eps, float bc1, float bc2sqrt,
-                                                       const int32_t* __restrict__ step_dev) {
+                                                       const int32_t* __restrict__ step_dev, const float* __restrict__ part,
+                                                       float* __restrict__ norms_out, float* __restrict__ norm_sum,
+                                                       int32_t* __restrict__ flags) {
   const ag_opt_desc d = descs[blockIdx.y];
+  float nr;
+  if (part) {
+    // fused form: ag_grad_norms(finish = 0) left the per-chunk partials; every workgroup sums its tensor's 256 partials
+    // itself (chunk order: the same value in every workgroup, and the same as the stand-alone finish computes), and
+    // workgroup (0, 0) also writes the outputs the finishing launch would have written
+    __shared__ float nsh;
+    if (blockIdx.x == 0 && blockIdx.y == 0) grad_norms_finish(norms_out, norm_sum, flags, gridDim.y, part);
+    if (threadIdx.x == 0) {
+      float q = 0.f;
+      for (int c = 0; c < OPT_CHUNKS; ++c) q += part[(int64_t)blockIdx.y * OPT_CHUNKS + c];
+      nsh = sqrtf(q);
+    }
+    __syncthreads();
+    nr = nsh;
+  } else {
+    nr = norms[blockIdx.y];
+  }
   if (step_dev && kind == AG_OPT_ADAM) {
     const float st = (float)step_dev[0];
     bc1 = 1.f - powf(a1, st);
     bc2sqrt = sqrtf(1.f - powf(b2, st));
   }
-  const float nr = norms[blockIdx.y];
   if ((int64_t)blockIdx.x * 256 >= d.n) return;
   const bool do_clip = clip > 0.f && nr > clip;
   const float div = do_clip ? nr / clip : 1.f;  // reference: grad /= (norm / clip), audiogan.py:252
@@ -503,8 +540,10 @@ __global__ __launch_bounds__(256) void opt_step_kernel(const ag_opt_desc* __rest
 
 extern "C" int ag_opt_step(const ag_opt_desc* descs_dev, int n, const float* norms, int kind, float lr,
                            float clip, float grad_scale, float alpha_or_beta1, float beta2, float eps,
-                           int step, const int32_t* step_dev, void* stream) {
-  AG_REQUIRE(descs_dev && norms && n > 0 && n <= 65535, "ag_opt_step: bad args");
+                           int step, const int32_t* step_dev, const float* part, float* norms_out, float* norm_sum,
+                           int32_t* flags, void* stream) {
+  AG_REQUIRE(descs_dev && (norms || part) && n > 0 && n <= 65535, "ag_opt_step: bad args");
+  AG_REQUIRE(!part || norms_out, "ag_opt_step: the fused form (part != NULL) writes the norms: norms_out must be given");
   AG_REQUIRE(kind == AG_OPT_RMSPROP || kind == AG_OPT_ADAM, "ag_opt_step: bad optimiser kind");
   float bc1 = 1.f, bc2s = 1.f;
   if (kind == AG_OPT_ADAM && !step_dev) {
@@ -513,7 +552,8 @@ extern "C" int ag_opt_step(const ag_opt_desc* descs_dev, int n, const float* nor
     bc2s = (float)sqrt(1.0 - pow((double)beta2, (double)step));
   }
   hipLaunchKernelGGL(opt_step_kernel, dim3(OPT_CHUNKS, n), dim3(256), 0, (hipStream_t)stream, descs_dev,
-                     norms, kind, lr, clip, grad_scale, alpha_or_beta1, beta2, eps, bc1, bc2s, step_dev);
+                     norms, kind, lr, clip, grad_scale, alpha_or_beta1, beta2, eps, bc1, bc2s, step_dev, part, norms_out,
+                     norm_sum, flags);
   AG_CHECK_LAUNCH("ag_opt_step");
   return AG_OK;
 }
@@ -739,5 +779,190 @@ extern "C" int ag_transpose_batched(const float* in, int64_t ibs, int64_t irs, f
   hipLaunchKernelGGL(transpose_batched_kernel, dim3(ag_cdiv(Cc, 32), ag_cdiv(R, 32), B), dim3(256), 0, (hipStream_t)stream,
                      in, ibs, irs, out, obs, ors, R, Cc);
   AG_CHECK_LAUNCH("ag_transpose_batched");
+  return AG_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Input assembly of the two networks - what the reference does with T.cat / expand / transpose / + on the host side
+// of every iteration (audiogan.py:433-436, :724-728, :749-751, :844) as ONE launch each instead of 3-8 torch launches.
+// ------------------------------------------------------------------------------------------
+// zc[t, b, :] = [ z[b, t, :ns] | c[b, :es] ]      (audiogan.py:439: the frame's LSTM input besides the fed-back frame)
+__global__ __launch_bounds__(256) void build_zc_kernel(const float* __restrict__ z, const float* __restrict__ c,
+                                                       float* __restrict__ zc, int B, int T, int ns, int es) {
+  const int F = ns + es;
+  const int64_t n = (int64_t)T * B * F;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int j = (int)(i % F);
+    const int64_t tb = i / F;
+    const int b = (int)(tb % B), t = (int)(tb / B);
+    zc[i] = j < ns ? z[((int64_t)b * T + t) * ns + j] : c[(int64_t)b * es + (j - ns)];
+  }
+}
+
+extern "C" int ag_build_zc(const float* z, const float* c, float* zc, int B, int T, int ns, int es, void* stream) {
+  AG_REQUIRE(z && c && zc && B > 0 && T > 0 && ns >= 0 && es >= 0 && ns + es > 0, "ag_build_zc: bad args");
+  const int64_t n = (int64_t)T * B * (ns + es);
+  int gx = (int)ag_cdiv64(n, 256 * 4);
+  if (gx > 4096) gx = 4096;
+  hipLaunchKernelGGL(build_zc_kernel, dim3(gx), dim3(256), 0, (hipStream_t)stream, z, c, zc, B, T, ns, es);
+  AG_CHECK_LAUNCH("ag_build_zc");
+  return AG_OK;
+}
+
+// The critic's minibatch: rows [0, nA) = xa + na, rows [nA, nA + nB) = xb + nb (instance noise optional), the rows'
+// lengths after every conv layer (ceil(len / (s_1 ... s_i)), audiogan.py:533) and the conditioning rows [cA ; cB].
+struct CriticBatchP {
+  const float *xa, *na, *xb, *nb;
+  int64_t xa_ld, na_ld, xb_ld, nb_ld;
+  float* x;                    // [nA + nB, L] contiguous
+  const int64_t *lenA, *lenB;  // [nA], [nB] (NULL: L)
+  int64_t* lens;               // [nl, nA + nB] (or NULL)
+  const float *cA, *cB;        // [nA, E], [nB, E] (or NULL)
+  float* c;                    // [nA + nB, E] (or NULL)
+  int nA, nB, L, nl, E;
+  int prods[8];
+};
+
+__global__ __launch_bounds__(256) void critic_batch_kernel(const CriticBatchP p) {
+  const int n = p.nA + p.nB;
+  const int row = blockIdx.y;
+  const bool a = row < p.nA;
+  const int r = a ? row : row - p.nA;
+  const float* x = a ? p.xa + (int64_t)r * p.xa_ld : p.xb + (int64_t)r * p.xb_ld;
+  const float* nz = a ? (p.na ? p.na + (int64_t)r * p.na_ld : nullptr) : (p.nb ? p.nb + (int64_t)r * p.nb_ld : nullptr);
+  float* y = p.x + (int64_t)row * p.L;
+  const bool vec = ((((uintptr_t)x | (uintptr_t)nz | (uintptr_t)y) & 15) == 0) && (p.L & 3) == 0;
+  if (vec) {
+    const int L4 = p.L >> 2;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < L4; i += gridDim.x * 256) {
+      f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+      if (nz) v += reinterpret_cast<const f32x4*>(nz)[i];
+      reinterpret_cast<f32x4*>(y)[i] = v;
+    }
+  } else {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < p.L; i += gridDim.x * 256) y[i] = x[i] + (nz ? nz[i] : 0.f);
+  }
+  if (blockIdx.x == 0) {
+    if (p.lens && threadIdx.x < p.nl) {
+      const int64_t* lp = a ? p.lenA : p.lenB;
+      const int64_t len = lp ? lp[r] : (int64_t)p.L;
+      const int64_t d = p.prods[threadIdx.x];
+      p.lens[(int64_t)threadIdx.x * n + row] = (len + d - 1) / d;
+    }
+    if (p.c) {
+      const float* cs = a ? p.cA + (int64_t)r * p.E : p.cB + (int64_t)r * p.E;
+      for (int j = threadIdx.x; j < p.E; j += 256) p.c[(int64_t)row * p.E + j] = cs[j];
+    }
+  }
+}
+
+extern "C" int ag_critic_batch(const float* xa, int64_t xa_ld, const float* na, int64_t na_ld, int nA, const float* xb,
+                               int64_t xb_ld, const float* nb, int64_t nb_ld, int nB, int L, float* x_out,
+                               const int64_t* lenA_i64, const int64_t* lenB_i64, const int32_t* prods_host, int nl,
+                               int64_t* lens_out_i64, const float* cA, const float* cB, int E, float* c_out, void* stream) {
+  AG_REQUIRE(x_out && L > 0 && nA >= 0 && nB >= 0 && nA + nB > 0 && nA + nB <= 65535, "ag_critic_batch: bad shape");
+  AG_REQUIRE((nA == 0 || xa) && (nB == 0 || xb), "ag_critic_batch: null clips");
+  AG_REQUIRE(nl >= 0 && nl <= 8 && (nl == 0 || (prods_host && lens_out_i64)), "ag_critic_batch: at most 8 conv layers");
+  AG_REQUIRE(!c_out || (E > 0 && (nA == 0 || cA) && (nB == 0 || cB)), "ag_critic_batch: null conditioning rows");
+  CriticBatchP p;
+  p.xa = xa; p.na = na; p.xb = xb; p.nb = nb; p.xa_ld = xa_ld; p.na_ld = na_ld; p.xb_ld = xb_ld; p.nb_ld = nb_ld;
+  p.x = x_out; p.lenA = lenA_i64; p.lenB = lenB_i64; p.lens = nl > 0 ? lens_out_i64 : nullptr;
+  p.cA = cA; p.cB = cB; p.c = c_out; p.nA = nA; p.nB = nB; p.L = L; p.nl = nl; p.E = E;
+  for (int i = 0; i < 8; ++i) {
+    p.prods[i] = i < nl ? prods_host[i] : 1;
+    AG_REQUIRE(p.prods[i] > 0, "ag_critic_batch: stride products must be positive");
+  }
+  int gx = ag_cdiv(L, 256 * 4 * 2);
+  if (gx < 1) gx = 1;
+  hipLaunchKernelGGL(critic_batch_kernel, dim3(gx, nA + nB), dim3(256), 0, (hipStream_t)stream, p);
+  AG_CHECK_LAUNCH("ag_critic_batch");
+  return AG_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------
+// A Linear layer with ONE output (the critic's last layer 512 -> 1, audiogan.py:511, :549; the Generator's stop head
+// 1024 -> 1, :410, :445): on the MFMA GEMM a product with one column is a 64-wide tile that is 98 % padding plus a split-K
+// second stage, its backward an outer product and a "matrix" with one row - three launches of 22 - 29 us for 33 MB.
+//   rowdot_fwd:  y[m] = x[m,:] . w + b                                    one wave per row, 16-byte loads
+//   rowdot_bwd:  dx[m,k] = dy[m] * w[k] (* LeakyReLU'(x[m,k]) when gate)   the layer's input gradient, gated by the saved
+//                dw[k] (+)= sum_m dy[m] * x[m,k];  db (+)= sum_m dy[m]     activation below, and both parameter gradients
+//                from ONE pass over x (partials per workgroup, fixed-order second stage through the bound workspace)
+// AG_PREC_BF16: x and w (forward) / dy, w and x (backward products) rounded to bf16, fp32 accumulation, like ag_gemm.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rowdot_fwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, float* __restrict__ y, int64_t ldy,
+                                                         int M, int K, int rb) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= M) return;
+  const float* xr = x + (int64_t)row * ldx;
+  float s = 0.f;
+  if ((K & 3) == 0 && (ldx & 3) == 0 && ((((uintptr_t)x | (uintptr_t)w) & 15) == 0)) {
+    for (int k = lane * 4; k < K; k += 256) {
+      const f32x4 a = ag_rbf4_if(*reinterpret_cast<const f32x4*>(xr + k), rb), b = ag_rbf4_if(*reinterpret_cast<const f32x4*>(w + k), rb);
+      s += a[0] * b[0]; s += a[1] * b[1]; s += a[2] * b[2]; s += a[3] * b[3];
+    }
+  } else {
+    for (int k = lane; k < K; k += 64) s += ag_rbf_if(xr[k], rb) * ag_rbf_if(w[k], rb);
+  }
+  s = ag_wave_sum(s);
+  if (lane == 0) y[(int64_t)row * ldy] = s + (bias ? bias[0] : 0.f);
+}
+
+#define RD_ROWS 64      // rows per workgroup of the backward kernel
+__global__ __launch_bounds__(256) void rowdot_bwd_kernel(const float* __restrict__ dy, int64_t lddy, const float* __restrict__ x,
+                                                         int ldx, const float* __restrict__ w, float* __restrict__ dx, int lddx,
+                                                         float* __restrict__ part, int M, int K, int gate, float slope, int rb) {
+  // thread <-> column k (grid.y tiles K by 256), loop over the workgroup's RD_ROWS rows: coalesced rows of x / dx
+  const int k = blockIdx.y * 256 + threadIdx.x;
+  const int m0 = blockIdx.x * RD_ROWS, m1 = min(M, m0 + RD_ROWS);
+  const bool ok = k < K;
+  const float wk = ok ? ag_rbf_if(w[k], rb) : 0.f;
+  float sw = 0.f, sb = 0.f;
+  for (int m = m0; m < m1; ++m) {
+    const float g = ag_rbf_if(dy[(int64_t)m * lddy], rb);
+    if (ok) {
+      const float xv = x[(int64_t)m * ldx + k];
+      if (dx) dx[(int64_t)m * lddx + k] = (gate && !(xv > 0.f)) ? g * wk * slope : g * wk;
+      sw += g * ag_rbf_if(xv, rb);
+    }
+    sb += dy[(int64_t)m * lddy];
+  }
+  if (part) {
+    float* pr = part + (int64_t)blockIdx.x * (K + 1);
+    if (ok) pr[k] = sw;
+    if (k == 0) pr[K] = sb;
+  }
+}
+
+extern "C" int ag_rowdot_fwd(const float* x, int ldx, const float* w, const float* bias, float* y, int64_t ldy, int M, int K,
+                             void* stream) {
+  AG_REQUIRE(x && w && y && M > 0 && K > 0 && ldx >= K && ldy >= 1, "ag_rowdot_fwd: bad args");
+  hipLaunchKernelGGL(rowdot_fwd_kernel, dim3(ag_cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, x, ldx, w, bias, y, ldy, M, K,
+                     (int)(ag_precision() == AG_PREC_BF16));
+  AG_CHECK_LAUNCH("ag_rowdot_fwd");
+  return AG_OK;
+}
+
+extern "C" int64_t ag_rowdot_bwd_ws_numel(int M, int K) { return (int64_t)ag_cdiv(M, RD_ROWS) * (K + 1); }
+
+extern "C" int ag_rowdot_bwd(const float* dy, int64_t lddy, const float* x, int ldx, const float* w, float* dx, int lddx,
+                             float* dw, float* db, int accumulate, int M, int K, int gate, float slope, void* stream) {
+  const AgWs ws = ag_ws_take();     // FIRST: an argument error below must not leave a stale binding behind
+  AG_REQUIRE(dy && x && w && M > 0 && K > 0 && ldx >= K && (!dx || lddx >= K), "ag_rowdot_bwd: bad args");
+  AG_REQUIRE((dw != nullptr) == (db != nullptr), "ag_rowdot_bwd: dw and db come together");
+  float* part = nullptr;
+  const int gx = ag_cdiv(M, RD_ROWS);
+  if (dw) {
+    AG_REQUIRE(ws.p && ws.numel >= (int64_t)gx * (K + 1),
+               "ag_rowdot_bwd: bind a workspace of >= %lld floats (ag_bind_workspace; ag_rowdot_bwd_ws_numel)", (long long)gx * (K + 1));
+    AG_REQUIRE(db == dw + K, "ag_rowdot_bwd: db must follow dw in memory (one [K+1] gradient row: the second stage sums both)");
+    part = ws.p;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(rowdot_bwd_kernel, dim3(gx, ag_cdiv(K, 256)), dim3(256), 0, st, dy, lddy, x, ldx, w, dx, lddx, part, M, K,
+                     gate, slope, (int)(ag_precision() == AG_PREC_BF16));
+  AG_CHECK_LAUNCH("ag_rowdot_bwd");
+  if (part) return ag_slab_reduce(part, gx, K + 1, dw, accumulate ? 1 : 0, st);
   return AG_OK;
 }

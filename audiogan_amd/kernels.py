@@ -52,51 +52,107 @@ def _mat(t, name):
 # ------------------------------------------------------------------------------------
 import os as _os0
 
-DETERMINISTIC = [_os0.environ.get('AG_DETERMINISTIC', '1') != '0']
+if _os0.environ.get('AG_DETERMINISTIC', '1') == '0':
+    raise ImportError('audiogan_amd: AG_DETERMINISTIC=0 asked for the float-atomic reductions of round 1; they were removed '
+                      '(round 4) - every cross-workgroup sum is two-stage and bitwise reproducible.  Unset the variable.')
 _SMALL_WS = 1 << 17        # floats; enough for the bias / channel / column sums at every BASELINE size
 
 
-import threading as _threading
+# process-wide, like the C side (api.hip): a scope is opened by the thread that calls loss.backward() and the recording
+# calls come from torch's autograd thread (never concurrently: the opener blocks inside backward())
+#   keep   workspaces kept alive until the flush (None: no scope)
+#   outer  the scope was opened by a network-level caller (common.network_backward): it RECORDS only inside the inner
+#          ``deferred_reduces()`` blocks of the autograd Functions (each block vouches that nothing inside it reads the
+#          sums it defers) and flushes once, when the whole backward is over
+#   depth  inner blocks currently open
+_DEFER = dict(keep=None, outer=False, depth=0)
 
-_DEFER = _threading.local()      # .keep: list of workspaces a deferred-reduction scope keeps alive (absent / None: not deferring)
+
+def reduces_recording():
+    return _DEFER['keep'] is not None and (_DEFER['depth'] > 0 or not _DEFER['outer'])
+
+
+def reduces_outer():
+    """is a network-level scope open?  (its sums are final only when IT closes: see common.WNGroup.backward)"""
+    return _DEFER['keep'] is not None and _DEFER['outer']
 
 
 class deferred_reduces(object):
     """``with K.deferred_reduces(): ...`` - the second stages of every two-stage reduction issued inside (conv weight
-    gradients, bias / channel sums) run as ONE launch at the end of the block instead of one each (ag_defer_reduces /
-    ag_flush_reduces; same results bit for bit).  Nothing inside the block may read those outputs.  The partial-sum
-    workspaces are kept alive until the flush.  Per thread, like the C side."""
+    gradients, bias / channel / column sums, split-K weight-gradient GEMMs called with ``defer=True``) run as ONE launch at
+    the end instead of one each (ag_defer_reduces / ag_flush_reduces; same results bit for bit).  Nothing inside the block
+    may read those outputs.  The partial-sum workspaces are kept alive until the flush.
+    ``outer=True`` (common.network_backward): open a scope around a whole backward pass; it records only inside the
+    Functions' own ``deferred_reduces()`` blocks, and those blocks then do NOT flush when they end - everything recorded
+    by the whole backward is summed by one launch when the outer scope closes."""
+
+    def __init__(self, outer=False):
+        self.outer = bool(outer)
+        self.role = None
 
     def __enter__(self):
-        self.nested = getattr(_DEFER, 'keep', None) is not None
-        if not self.nested:
+        st = _DEFER
+        if st['keep'] is None:
             check(lib.ag_defer_reduces(1), 'ag_defer_reduces')
-            _DEFER.keep = []
+            st['keep'], st['outer'], st['depth'] = [], self.outer, 0
+            self.role = 'owner'
+            if self.outer:
+                lib.ag_defer_reduces(2)                # paused until an inner block opens
+        elif self.outer:
+            self.role = 'nested'                       # a network scope inside another scope: the outermost one rules
+        else:
+            if st['outer'] and st['depth'] == 0:
+                check(lib.ag_defer_reduces(3), 'ag_defer_reduces')
+            st['depth'] += 1
+            self.role = 'inner'
         return self
 
     def __exit__(self, et, ev, tb):
-        if self.nested:
-            return False
-        try:
-            if et is None:
-                check(lib.ag_flush_reduces(_stream()), 'ag_flush_reduces')
-        finally:
-            _DEFER.keep = None
-            lib.ag_defer_reduces(1)        # drops whatever is still recorded (error path) ...
-            lib.ag_defer_reduces(0)        # ... and turns deferral off
+        st = _DEFER
+        if self.role == 'inner':
+            st['depth'] -= 1
+            if st['outer'] and st['depth'] == 0:
+                lib.ag_defer_reduces(2)
+        elif self.role == 'owner':
+            try:
+                if et is None:
+                    check(lib.ag_flush_reduces(_stream()), 'ag_flush_reduces')
+            finally:
+                st['keep'], st['outer'], st['depth'] = None, False, 0
+                lib.ag_defer_reduces(1)        # drops whatever is still recorded (error path) ...
+                lib.ag_defer_reduces(0)        # ... and turns deferral off
         return False
+
+
+def flush_reduces():
+    """sum everything recorded so far NOW (a reader inside a scope needs final values); the scope stays open"""
+    if _DEFER['keep'] is not None:
+        check(lib.ag_flush_reduces(_stream()), 'ag_flush_reduces')
+
+
+class _immediate(object):
+    """the reducing call inside runs its second stage at once even inside a recording scope"""
+
+    def __enter__(self):
+        self.on = reduces_recording()
+        if self.on:
+            lib.ag_defer_reduces(2)
+
+    def __exit__(self, *exc):
+        if self.on:
+            lib.ag_defer_reduces(3)
 
 
 def _bind_ws(numel, dev):
     """bind `numel` floats of scratch for the NEXT reducing call (ag_bind_workspace); the tensor comes from torch's
     stream-ordered caching allocator, so it is safe to drop it as soon as the call has been enqueued"""
-    if not DETERMINISTIC[0] or numel <= 0:
+    if numel <= 0:
         lib.ag_bind_workspace(None, 0)       # no workspace for this call: drop whatever an earlier, failed call left bound
         return None
     ws = torch.empty(int(numel), dtype=torch.float32, device=dev)
     check(lib.ag_bind_workspace(_p(ws), int(numel)), 'ag_bind_workspace')
-    if getattr(_DEFER, 'keep', None) is not None:
-        _DEFER.keep.append(ws)
+    if _DEFER['keep'] is not None:
+        _DEFER['keep'].append(ws)
     return ws
 
 
@@ -335,14 +391,14 @@ def conv_wgrad(sh, lg, dw, K, stride, pad):
                               K, stride, pad, _stream()), 'ag_conv1d_wgrad')
 
 
-def channel_sum(dy, db):
-    """db[c] += sum_{b,t} dy[b,c,t]"""
+def channel_sum(dy, db, accumulate=True):
+    """db[c] (+)= sum_{b,t} dy[b,c,t]"""
     bs, cs = _bcl(dy, 'dy')
     _chk(db, 'db')
     B, Cc, L = dy.shape
     assert db.numel() == Cc and db.is_contiguous()
     _ws = _bind_ws(_SMALL_WS, db.device)  # noqa: F841
-    check(lib.ag_channel_sum(_p(dy), bs, cs, _p(db), B, Cc, L, _stream()), 'ag_channel_sum')
+    check(lib.ag_channel_sum(_p(dy), bs, cs, _p(db), B, Cc, L, int(bool(accumulate)), _stream()), 'ag_channel_sum')
 
 
 def leaky_bwd(dy, y, dpre, lens=None, slope=LEAKY_SLOPE, add_into=None, bias_grad=None):
@@ -367,9 +423,12 @@ def leaky_bwd(dy, y, dpre, lens=None, slope=LEAKY_SLOPE, add_into=None, bias_gra
 # GEMM
 # ------------------------------------------------------------------------------------
 def gemm(A, B, Cm, ta=False, tb=False, alpha=1.0, beta=0.0, bias=None, res=None, act=ACT_NONE,
-         slope=LEAKY_SLOPE):
+         slope=LEAKY_SLOPE, defer=False):
     """Cm[M,N] = act(alpha * op(A) @ op(B) + beta*Cm + bias + res).
-    ta: A is stored [K,M];  tb: B is stored [N,K] (a Linear weight)."""
+    ta: A is stored [K,M];  tb: B is stored [N,K] (a Linear weight).
+    ``defer``: Cm is a parameter gradient that nothing reads before the enclosing ``deferred_reduces`` scope closes - a
+    split-K product may then leave its second stage to the scope's one launch.  Default: the product is complete when the
+    call returns (in stream order), also inside a scope."""
     lda, ldb, ldc = _mat(A, 'A'), _mat(B, 'B'), _mat(Cm, 'C')
     M, N = Cm.shape
     K = A.size(0) if ta else A.size(1)
@@ -382,19 +441,35 @@ def gemm(A, B, Cm, ta=False, tb=False, alpha=1.0, beta=0.0, bias=None, res=None,
     if bias is not None:
         _chk(bias, 'bias')
         assert bias.numel() == N and bias.is_contiguous()
-    _ws = _bind_ws(lib.ag_gemm_ws_numel(M, N, K, act), Cm.device)  # noqa: F841
-    check(lib.ag_gemm(_p(A), lda, int(ta), _p(B), ldb, int(tb), _p(Cm), ldc, M, N, K, alpha, beta,
-                      _p(bias), _p(res), ldres, act, slope, _stream()), 'ag_gemm')
+    nws = lib.ag_gemm_ws_numel(M, N, K, act)
+    hold = (not defer) and nws > 0 and reduces_recording()
+    if hold:
+        lib.ag_defer_reduces(2)
+    try:
+        _ws = _bind_ws(nws, Cm.device)  # noqa: F841
+        check(lib.ag_gemm(_p(A), lda, int(ta), _p(B), ldb, int(tb), _p(Cm), ldc, M, N, K, alpha, beta,
+                          _p(bias), _p(res), ldres, act, slope, _stream()), 'ag_gemm')
+    finally:
+        if hold:
+            lib.ag_defer_reduces(3)
 
 
-def col_sum(X, out):
-    """out[n] += sum_m X[m,n]"""
+def col_sum(X, out, accumulate=True, defer=True):
+    """out[n] (+)= sum_m X[m,n].  ``defer=False``: complete when the call returns (in stream order) also inside a recording
+    ``deferred_reduces`` scope - for sums that are read before that scope closes."""
     ldx = _mat(X, 'X')
     _chk(out, 'out')
     M, N = X.shape
     assert out.numel() == N and out.is_contiguous()
-    _ws = _bind_ws(min(_SMALL_WS, 64 * N) if M > 16 else 0, out.device)  # noqa: F841
-    check(lib.ag_col_sum(_p(X), ldx, _p(out), M, N, _stream()), 'ag_col_sum')
+    hold = (not defer) and reduces_recording()
+    if hold:
+        lib.ag_defer_reduces(2)
+    try:
+        _ws = _bind_ws(min(_SMALL_WS, 64 * N) if M > 16 else 0, out.device)  # noqa: F841
+        check(lib.ag_col_sum(_p(X), ldx, _p(out), M, N, int(bool(accumulate)), _stream()), 'ag_col_sum')
+    finally:
+        if hold:
+            lib.ag_defer_reduces(3)
 
 
 # ------------------------------------------------------------------------------------
@@ -510,6 +585,82 @@ def tbc_to_bct(x, out=None):
     return out
 
 
+def rowdot_ok(x, w):
+    """can the one-output Linear kernels (ag_rowdot_*) take x [M,K] (unit stride along K) and w [1,K] / [K]?"""
+    return x.dim() == 2 and x.stride(1) == 1 and w.numel() == x.size(1) and w.is_contiguous()
+
+
+def rowdot_fwd(x, w, bias, y):
+    """y[m] = x[m,:] . w + bias[0]; y: [M] or [M,1] of any stride"""
+    ldx = _mat(x, 'x')
+    _chk(w, 'w'); _chk(bias, 'bias'); _chk(y, 'y')
+    M, Kd = x.shape
+    assert rowdot_ok(x, w) and y.numel() == M
+    ldy = y.stride(0) if M > 1 else 1
+    check(lib.ag_rowdot_fwd(_p(x), ldx, _p(w), _p(bias), _p(y), ldy, M, Kd, _stream()), 'ag_rowdot_fwd')
+
+
+def rowdot_bwd(dy, x, w, dx=None, dw=None, db=None, gate=False, slope=LEAKY_SLOPE, accumulate=True):
+    """backward of a one-output Linear in ONE pass over x: dx = dy (x) w (times LeakyReLU'(x) when ``gate``: x is the saved
+    output of the LeakyReLU below), dw (+)= dy^T x, db (+)= sum dy.  dw [1,K] / [K] and db [1] must be adjacent in memory
+    (db right behind dw: one gradient row), as the views of WNGroup.zero_dws are; dy: [M] or [M,1] of any stride."""
+    ldx = _mat(x, 'x')
+    _chk(dy, 'dy'); _chk(w, 'w'); _chk(dx, 'dx'); _chk(dw, 'dw'); _chk(db, 'db')
+    M, Kd = x.shape
+    assert rowdot_ok(x, w) and dy.numel() == M
+    lddx = _mat(dx, 'dx') if dx is not None else 0
+    assert dx is None or tuple(dx.shape) == (M, Kd)
+    if dw is not None:
+        assert dw.is_contiguous() and dw.numel() == Kd and db is not None and db.numel() == 1
+        assert db.data_ptr() == dw.data_ptr() + 4 * Kd, 'db must sit right behind dw'
+        _ws = _bind_ws(lib.ag_rowdot_bwd_ws_numel(M, Kd), dw.device)  # noqa: F841
+    check(lib.ag_rowdot_bwd(_p(dy), dy.stride(0) if M > 1 else 1, _p(x), ldx, _p(w), _p(dx), lddx, _p(dw), _p(db),
+                            int(bool(accumulate)), M, Kd, int(bool(gate)), slope, _stream()), 'ag_rowdot_bwd')
+
+
+def build_zc(z, c, out=None):
+    """zc[t,b,:] = [z[b,t,:] | c[b,:]]: z [B,T,ns], c [B,es] -> contiguous [T,B,ns+es] (ag_build_zc; audiogan.py:433-439)"""
+    _chk(z, 'z'); _chk(c, 'c')
+    B, T, ns = z.shape
+    es = c.size(1)
+    assert z.is_contiguous() and c.is_contiguous() and c.size(0) == B
+    if out is None:
+        out = torch.empty(T, B, ns + es, device=z.device)
+    check(lib.ag_build_zc(_p(z), _p(c), _p(out), B, T, ns, es, _stream()), 'ag_build_zc')
+    return out
+
+
+def critic_batch(xa, na=None, xb=None, nb=None, len_a=None, len_b=None, prods=(), ca=None, cb=None):
+    """the critic's minibatch in ONE launch (ag_critic_batch): rows [xa + na ; xb + nb] -> x [nA+nB, L]; the rows' lengths
+    after every conv layer, lens [len(prods), nA+nB] int64 with lens[i] = ceil(len / prods[i]) (len_a / len_b None: L); the
+    conditioning rows [ca ; cb] (None: skipped).  Returns (x, lens or None, c or None)."""
+    nA, L = xa.shape
+    nB = xb.size(0) if xb is not None else 0
+    dev = xa.device
+    lda = _rows(xa, 'xa', nA, L)
+    ldna = _rows(na, 'na', nA, L) if na is not None else 0
+    ldb = _rows(xb, 'xb', nB, L) if xb is not None else 0
+    ldnb = _rows(nb, 'nb', nB, L) if nb is not None else 0
+    for t_, n_, k_ in ((len_a, 'len_a', nA), (len_b, 'len_b', nB)):
+        _chk(t_, n_, torch.int64)
+        assert t_ is None or (t_.is_contiguous() and t_.numel() == k_)
+    x = torch.empty(nA + nB, L, device=dev)
+    nl = len(prods)
+    lens = torch.empty(nl, nA + nB, dtype=torch.int64, device=dev) if nl else None
+    E, c = 0, None
+    if ca is not None:
+        E = ca.size(1)
+        for t_, n_, k_ in ((ca, 'ca', nA), (cb, 'cb', nB)):
+            _chk(t_, n_)
+            assert t_ is None or (t_.is_contiguous() and tuple(t_.shape) == (k_, E))
+        assert cb is not None or nB == 0
+        c = torch.empty(nA + nB, E, device=dev)
+    arr = (C.c_int32 * max(nl, 1))(*[int(v) for v in prods])
+    check(lib.ag_critic_batch(_p(xa), lda, _p(na), ldna, nA, _p(xb), ldb, _p(nb), ldnb, nB, L, _p(x), _p(len_a), _p(len_b),
+                              arr, nl, _p(lens), _p(ca), _p(cb), E, _p(c), _stream()), 'ag_critic_batch')
+    return x, lens, c
+
+
 def axpby(x, y, a, b):
     """y = a*x + b*y (contiguous)"""
     _chk(x, 'x'); _chk(y, 'y')
@@ -530,22 +681,30 @@ def _opt_table(params, grads, s1, s2):
     return _table('opt', descs, params[0].device)
 
 
-def grad_norms(params, grads, s1, s2, norms, norm_sum, flags, grad_scale=1.0, step_dev=None):
-    """norms[i] = ||grads[i]*grad_scale||; norm_sum[0] = sum_i norms[i]; flags |= NaN/BIG bits"""
+def grad_norms(params, grads, s1, s2, norms, norm_sum, flags, grad_scale=1.0, step_dev=None, finish=True):
+    """norms[i] = ||grads[i]*grad_scale||; norm_sum[0] = sum_i norms[i]; flags = NaN/BIG bits (written).  ``finish=False``:
+    only the per-chunk partial sums are computed; returns the workspace holding them, to be handed to ``opt_step(part=...)``
+    right behind on the same stream (norms / norm_sum / flags are then written by that launch)."""
     tab = _opt_table(params, grads, s1, s2)
     _chk(norms, 'norms'); _chk(norm_sum, 'norm_sum'); _chk(flags, 'flags', torch.int32)
     assert norms.numel() >= len(params)
     _chk(step_dev, 'step_dev', torch.int32)
-    _ws = _bind_ws(256 * len(params), norms.device)  # noqa: F841
+    ws = torch.empty(512 * len(params), dtype=torch.float32, device=norms.device)
+    check(lib.ag_bind_workspace(_p(ws), ws.numel()), 'ag_bind_workspace')
     check(lib.ag_grad_norms(_p(tab), len(params), _p(norms), _p(norm_sum), _p(flags), grad_scale,
-                            _p(step_dev), _stream()), 'ag_grad_norms')
+                            _p(step_dev), int(bool(finish)), _stream()), 'ag_grad_norms')
+    return ws
 
 
-def opt_step(params, grads, s1, s2, norms, kind, lr, clip, grad_scale, a1, b2, eps, step, step_dev=None):
+def opt_step(params, grads, s1, s2, norms, kind, lr, clip, grad_scale, a1, b2, eps, step, step_dev=None, part=None,
+             norm_sum=None, flags=None):
+    """``part``: the workspace ``grad_norms(finish=False)`` returned - this launch then also finishes the norms"""
     tab = _opt_table(params, grads, s1, s2)
-    _chk(step_dev, 'step_dev', torch.int32)
+    _chk(step_dev, 'step_dev', torch.int32); _chk(part, 'part'); _chk(norm_sum, 'norm_sum'); _chk(flags, 'flags', torch.int32)
+    assert part is None or part.numel() >= 512 * len(params)
     check(lib.ag_opt_step(_p(tab), len(params), _p(norms), kind, lr, clip, grad_scale, a1, b2, eps,
-                          step, _p(step_dev), _stream()), 'ag_opt_step')
+                          step, _p(step_dev), _p(part), _p(norms) if part is not None else None, _p(norm_sum), _p(flags),
+                          _stream()), 'ag_opt_step')
 
 
 # ------------------------------------------------------------------------------------
@@ -904,21 +1063,30 @@ def gfront_persist_ok(B, S, fs, dev):
     return bool(PERSIST[0] and torch.device(dev).type == 'cuda' and lib.ag_gfront_persist_ok(B, S, fs, _n_cu(dev)))
 
 
-def gfront_fwd_persist(gates, wx, whh, wp, bp, hs, cs, x):
-    """the Generator front's frame loop in ONE persistent launch (ag_gfront_fwd_persist)"""
+def _rows(t, name, B, n):
+    """row pitch of a [B, n] view with unit stride along dim 1 (a slab channel, a column block)"""
+    _chk(t, name)
+    assert t.dim() == 2 and tuple(t.shape) == (B, n) and (n == 1 or t.stride(1) == 1), (name, tuple(t.shape), t.stride())
+    return t.stride(0) if B > 1 else max(t.stride(0), n)
+
+
+def gfront_fwd_persist(gates, wx, whh, wp, bp, hs, cs, x, xt=None):
+    """the Generator front's frame loop in ONE persistent launch (ag_gfront_fwd_persist).  x: [B, T*fs] rows of any pitch
+    (channel 0 of the conv trunk's slab); xt: optional [T,B,fs], receives the same frames time-major"""
     T, B, S4 = gates.shape
     S = S4 // 4
     fs = wp.size(0)
     for t_, n, shp in ((gates, 'gates', (T, B, 4 * S)), (whh, 'whh', (4 * S, S)), (wp, 'wp', (fs, S)), (bp, 'bp', (fs,)),
-                       (hs, 'hs', (T, B, S)), (cs, 'cs', (T + 1, B, S)), (x, 'x', (B, T * fs))):
+                       (hs, 'hs', (T, B, S)), (cs, 'cs', (T + 1, B, S))) + (((xt, 'xt', (T, B, fs)),) if xt is not None else ()):
         _chk(t_, n)
         assert t_.is_contiguous() and tuple(t_.shape) == shp, (n, tuple(t_.shape), shp)
+    ldx = _rows(x, 'x', B, T * fs)
     _chk(wx, 'wx')
     assert tuple(wx.shape) == (4 * S, fs) and wx.stride(1) == 1
     nb = int(lib.ag_gfront_persist_ws_bytes(B, S, fs))
     ws = _persist_workspace(x.device, nb)
-    check(lib.ag_gfront_fwd_persist(_p(gates), _p(wx), wx.stride(0), _p(whh), _p(wp), _p(bp), _p(hs), _p(cs), _p(x),
-                                    _p(ws), ws.numel(), T, B, S, fs, _n_cu(x.device), _stream()),
+    check(lib.ag_gfront_fwd_persist(_p(gates), _p(wx), wx.stride(0), _p(whh), _p(wp), _p(bp), _p(hs), _p(cs), _p(x), ldx,
+                                    _p(xt), _p(ws), ws.numel(), T, B, S, fs, _n_cu(x.device), _stream()),
           'ag_gfront_fwd_persist')
 
 
@@ -947,66 +1115,77 @@ def gfront_bwd_persist_ok(B, S, fs, dev):
                 and lib.ag_gfront_bwd_persist_ok(B, S, fs, _n_cu(dev)))
 
 
-def gfront_bwd_persist(gates, cs, x, dacc, whh, wx, wp, dgs, dxt):
+def _ext_grads(dh_ext, dx_ext, T, B, S, fs):
+    if dh_ext is not None:
+        _chk(dh_ext, 'dh_ext')
+        assert dh_ext.is_contiguous() and tuple(dh_ext.shape) == (T, B, S), tuple(dh_ext.shape)
+    return _rows(dx_ext, 'dx_ext', B, T * fs) if dx_ext is not None else 0
+
+
+def gfront_bwd_persist(gates, cs, x, dh_ext, dx_ext, whh, wx, wp, dgs, dxt):
     """the backward through time of the Generator front's frame loop in ONE persistent launch (ag_gfront_bwd_persist);
-    dacc [T,B,S+fs] = the external gradient [dL/dh_t | dL/dx_t], read only"""
+    the external gradients, read only, each may be None: dh_ext [T,B,S] = dL/dh_t (the stop head's), dx_ext [B,T*fs] rows of
+    any pitch = dL/dx_t (the conv trunk's: channel 0 of its gradient slab); x likewise [B,T*fs] rows of any pitch"""
     T, B, S4 = gates.shape
     S = S4 // 4
     fs = wp.size(0)
-    for t_, n, shp in ((gates, 'gates', (T, B, 4 * S)), (cs, 'cs', (T + 1, B, S)), (x, 'x', (B, T * fs)),
-                       (dacc, 'dacc', (T, B, S + fs)), (whh, 'whh', (4 * S, S)), (wp, 'wp', (fs, S)),
-                       (dgs, 'dgs', (T, B, 4 * S)), (dxt, 'dxt', (T, B, fs))):
+    for t_, n, shp in ((gates, 'gates', (T, B, 4 * S)), (cs, 'cs', (T + 1, B, S)), (whh, 'whh', (4 * S, S)),
+                       (wp, 'wp', (fs, S)), (dgs, 'dgs', (T, B, 4 * S)), (dxt, 'dxt', (T, B, fs))):
         _chk(t_, n)
         assert t_.is_contiguous() and tuple(t_.shape) == shp, (n, tuple(t_.shape), shp)
+    ldx, lddx = _rows(x, 'x', B, T * fs), _ext_grads(dh_ext, dx_ext, T, B, S, fs)
     _chk(wx, 'wx')
     assert tuple(wx.shape) == (4 * S, fs) and wx.stride(1) == 1
     ws = _persist_workspace(x.device, _PERSIST_WS_MIN)
-    check(lib.ag_gfront_bwd_persist(_p(gates), _p(cs), _p(x), _p(dacc), _p(whh), _p(wx), wx.stride(0), _p(wp), _p(dgs),
-                                    _p(dxt), _p(ws), ws.numel(), T, B, S, fs, _n_cu(x.device), _stream()),
-          'ag_gfront_bwd_persist')
+    check(lib.ag_gfront_bwd_persist(_p(gates), _p(cs), _p(x), ldx, _p(dh_ext), _p(dx_ext), lddx, _p(whh), _p(wx),
+                                    wx.stride(0), _p(wp), _p(dgs), _p(dxt), _p(ws), ws.numel(), T, B, S, fs,
+                                    _n_cu(x.device), _stream()), 'ag_gfront_bwd_persist')
 
 
-def grufront_bwd_persist(gates, hs, gh, x, dacc, whh, wx, wp, dgi, dgh, dxt):
+def grufront_bwd_persist(gates, hs, gh, x, dh_ext, dx_ext, whh, wx, wp, dgi, dgh, dxt):
     """the GRU front's backward through time in ONE persistent launch (ag_grufront_bwd_persist); hs [T+1,B,S] with
-    hs[t] = h_{t-1}; dacc [T,B,S+fs] = the external gradient [dL/dh_t | dL/dx_t], read only"""
+    hs[t] = h_{t-1}; dh_ext / dx_ext: the external gradients as for gfront_bwd_persist"""
     T, B, S3 = gates.shape
     S = S3 // 3
     fs = wp.size(0)
     for t_, n, shp in ((gates, 'gates', (T, B, 3 * S)), (hs, 'hs', (T + 1, B, S)), (gh, 'gh', (T, B, 3 * S)),
-                       (x, 'x', (B, T * fs)), (dacc, 'dacc', (T, B, S + fs)), (whh, 'whh', (3 * S, S)), (wp, 'wp', (fs, S)),
+                       (whh, 'whh', (3 * S, S)), (wp, 'wp', (fs, S)),
                        (dgi, 'dgi', (T, B, 3 * S)), (dgh, 'dgh', (T, B, 3 * S)), (dxt, 'dxt', (T, B, fs))):
         _chk(t_, n)
         assert t_.is_contiguous() and tuple(t_.shape) == shp, (n, tuple(t_.shape), shp)
+    ldx, lddx = _rows(x, 'x', B, T * fs), _ext_grads(dh_ext, dx_ext, T, B, S, fs)
     _chk(wx, 'wx')
     assert tuple(wx.shape) == (3 * S, fs) and wx.stride(1) == 1
     ws = _persist_workspace(x.device, _PERSIST_WS_MIN)
-    check(lib.ag_grufront_bwd_persist(_p(gates), _p(hs), _p(gh), _p(x), _p(dacc), _p(whh), _p(wx), wx.stride(0), _p(wp),
-                                      _p(dgi), _p(dgh), _p(dxt), _p(ws), ws.numel(), T, B, S, fs, _n_cu(x.device),
-                                      _stream()), 'ag_grufront_bwd_persist')
+    check(lib.ag_grufront_bwd_persist(_p(gates), _p(hs), _p(gh), _p(x), ldx, _p(dh_ext), _p(dx_ext), lddx, _p(whh), _p(wx),
+                                      wx.stride(0), _p(wp), _p(dgi), _p(dgh), _p(dxt), _p(ws), ws.numel(), T, B, S, fs,
+                                      _n_cu(x.device), _stream()), 'ag_grufront_bwd_persist')
 
 
-def _work_grufront_bwd(gates, hs, gh, x, dacc, whh, wx, wp, *a_, **kw):
+def _work_grufront_bwd(gates, hs, gh, x, dh_ext, dx_ext, whh, wx, wp, *a_, **kw):
     T, B, S3 = gates.shape
     S, fs = S3 // 3, wp.size(0)
     return 'gfront_persist_bwd_kernel<gru>', 2.0 * B * ((T - 1) * S3 * (S + fs) + T * fs * S), \
         4.0 * (S3 * (S + fs) + fs * S + T * B * (4 * S3 + 2 * S + (S + fs) + 2 * fs)), 1
 
 
-def grufront_fwd_persist(gates, gh, wx, whh, bhn, wp, bp, hs, x):
-    """the GRU-front generator's frame loop in ONE persistent launch (ag_grufront_fwd_persist); hs: [T,B,S] (h_t)"""
+def grufront_fwd_persist(gates, gh, wx, whh, bhn, wp, bp, hs, x, xt=None):
+    """the GRU-front generator's frame loop in ONE persistent launch (ag_grufront_fwd_persist); hs: [T,B,S] (h_t); x / xt as
+    for gfront_fwd_persist"""
     T, B, S3 = gates.shape
     S = S3 // 3
     fs = wp.size(0)
     for t_, n, shp in ((gates, 'gates', (T, B, 3 * S)), (gh, 'gh', (T, B, 3 * S)), (whh, 'whh', (3 * S, S)), (bhn, 'bhn', (S,)),
-                       (wp, 'wp', (fs, S)), (bp, 'bp', (fs,)), (hs, 'hs', (T, B, S)), (x, 'x', (B, T * fs))):
+                       (wp, 'wp', (fs, S)), (bp, 'bp', (fs,)), (hs, 'hs', (T, B, S))) + (((xt, 'xt', (T, B, fs)),) if xt is not None else ()):
         _chk(t_, n)
         assert t_.is_contiguous() and tuple(t_.shape) == shp, (n, tuple(t_.shape), shp)
+    ldx = _rows(x, 'x', B, T * fs)
     _chk(wx, 'wx')
     assert tuple(wx.shape) == (3 * S, fs) and wx.stride(1) == 1
     nb = int(lib.ag_gfront_persist_ws_bytes(B, S, fs))
     ws = _persist_workspace(x.device, nb)
     check(lib.ag_grufront_fwd_persist(_p(gates), _p(gh), _p(wx), wx.stride(0), _p(whh), _p(bhn), _p(wp), _p(bp), _p(hs),
-                                      _p(x), _p(ws), ws.numel(), T, B, S, fs, _n_cu(x.device), _stream()),
+                                      _p(x), ldx, _p(xt), _p(ws), ws.numel(), T, B, S, fs, _n_cu(x.device), _stream()),
           'ag_grufront_fwd_persist')
 
 
@@ -1024,7 +1203,7 @@ def _work_gfront(gates, wx, whh, wp, *a_, **kw):
         4.0 * (S4 * (S + fs) + fs * S + T * B * (2 * S4 + 2 * S + fs)), 1
 
 
-def _work_gfront_bwd(gates, cs, x, dacc, whh, wx, wp, *a_, **kw):
+def _work_gfront_bwd(gates, cs, x, dh_ext, dx_ext, whh, wx, wp, *a_, **kw):
     T, B, S4 = gates.shape
     S, fs = S4 // 4, wp.size(0)
     return 'gfront_persist_bwd_kernel' + _bf16_tag(), 2.0 * B * ((T - 1) * S4 * (S + fs) + T * fs * S), \
@@ -1035,8 +1214,9 @@ def lstm_persist_bwd_ok(B, H, ndir, dev):
     return bool(PERSIST[0] and lib.ag_lstm_persist_bwd_ok(B, H, ndir, _n_cu(dev)))
 
 
-def _lstm_seq_bwd_persist_call(gates, whh, c_all, dy, dgates, valid):
-    """ONE persistent launch for the whole backward through time (ag_lstm_seq_bwd_persist)"""
+def _lstm_seq_bwd_persist_call(gates, whh, c_all, dy, dgates, valid, dgsum=None):
+    """ONE persistent launch for the whole backward through time (ag_lstm_seq_bwd_persist); dgsum: optional list of
+    [B,4H] outputs (one per direction) = the sum over time of dgates"""
     ndir = len(gates)
     T, B, H4 = gates[0].shape
     H = H4 // 4
@@ -1047,24 +1227,32 @@ def _lstm_seq_bwd_persist_call(gates, whh, c_all, dy, dgates, valid):
             assert t_.is_contiguous() and tuple(t_.shape) == shp, (tuple(t_.shape), shp)
     _chk(dy, 'dy'); _chk(valid, 'valid', torch.int64)
     assert dy.is_contiguous() and tuple(dy.shape) == (T, B, ndir * H)
+    if dgsum is not None:
+        assert len(dgsum) == ndir
+        for t_ in dgsum:
+            _chk(t_, 'dgsum')
+            assert t_.is_contiguous() and tuple(t_.shape) == (B, 4 * H)
     ws = _persist_workspace(dy.device, 8192 + 256)
     check(lib.ag_lstm_seq_bwd_persist(_ptr_table(gates), _ptr_table(whh), _ptr_table(c_all), _p(dy),
-                                      _ptr_table(dgates), _p(valid), _p(ws), ws.numel(), T, B, H, ndir,
-                                      _n_cu(dy.device), _stream()), 'ag_lstm_seq_bwd_persist')
+                                      _ptr_table(dgates), _ptr_table(dgsum) if dgsum is not None else None, _p(valid),
+                                      _p(ws), ws.numel(), T, B, H, ndir, _n_cu(dy.device), _stream()),
+          'ag_lstm_seq_bwd_persist')
 
 
-def _work_seq_bwd_persist(gates, whh, c_all, dy, dgates, valid):
+def _work_seq_bwd_persist(gates, whh, c_all, dy, dgates, valid, dgsum=None):
     T, B, H4 = gates[0].shape
     nd = len(gates)
     return 'lstm_persist_bwd_kernel' + _bf16_tag(), T * 2.0 * nd * B * H4 * (H4 // 4), \
         4.0 * nd * (H4 * (H4 // 4) + T * 5.5 * B * H4), 1
 
 
-def lstm_seq_bwd(gates, whh, c_all, dy, dgates, dhbuf, dcbuf, valid):
+def lstm_seq_bwd(gates, whh, c_all, dy, dgates, dhbuf, dcbuf, valid, dgsum=None):
+    """``dgsum``: optional list of [B,4H] tensors (one per direction) that receive the sum over time of dgates.  Returns True
+    when they were filled (the persistent launch sums them in registers); False: the caller sums dgates itself."""
     T = gates[0].size(0)
     if lstm_persist_bwd_ok(gates[0].size(1), gates[0].size(2) // 4, len(gates), dy.device):
-        _lstm_seq_bwd_persist_call(gates, whh, c_all, dy, dgates, valid)
-        return
+        _lstm_seq_bwd_persist_call(gates, whh, c_all, dy, dgates, valid, dgsum)
+        return dgsum is not None
     if Profiler.enabled:
         H = gates[0].size(2) // 4
         if H % 16 == 0:         # the fused step kernel: the whole chain between one pair of events
@@ -1076,6 +1264,7 @@ def lstm_seq_bwd(gates, whh, c_all, dy, dgates, dhbuf, dcbuf, valid):
                 _lstm_seq_bwd_prod(gates, whh, c_all, dy, dgates, dhbuf, dcbuf, valid, k_, k_ + 1, 2)
     else:
         _lstm_seq_bwd_range(gates, whh, c_all, dy, dgates, dhbuf, dcbuf, valid, 0, T)
+    return False
 
 
 def _lstm_seq_bwd_cell(*a):
@@ -1185,7 +1374,7 @@ def gru_cell_bwd(gates_act, gh, h_prev, dh, dgi, dgh, dh_prev):
           'ag_gru_cell_bwd')
 
 
-for _n in ('gru_cell_fwd', 'gru_cell_bwd'):
+for _n in ('gru_cell_fwd', 'gru_cell_bwd', 'rowdot_fwd', 'rowdot_bwd', 'build_zc', 'critic_batch'):
     _instrument(_n, None)
 
 

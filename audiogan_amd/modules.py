@@ -163,6 +163,8 @@ class Generator(nn.Module):
         fin = self.dense_res_gen[-1].module
         _add(self._trunk.group, fin, 'weight', stride=1, engine=True)
         _add(self._trunk.group, fin, 'bias')
+        # the front writes its frames straight into channel 0 of the trunk's activation slab (no copy between the blocks)
+        self._front.slab_channels = self._trunk.ctot
 
     def _front_apply(self, zc):
         return ops.GFrontFn.apply(zc, self._front, *self._front.group.params())
@@ -200,7 +202,10 @@ class Generator(nn.Module):
             z = torch.randn(batch_size, nframes, ns, device=dev)
         else:
             batch_size, nframes, _ = z.size()
-        zc = torch.cat([z, c.unsqueeze(1).expand(batch_size, nframes, es)], 2).transpose(0, 1).contiguous()
+        if z.is_cuda and z.dtype == torch.float32 and c.dtype == torch.float32:
+            zc = ops.BuildZCFn.apply(z, c)          # [T,B,noise+embed] in one launch
+        else:
+            zc = torch.cat([z, c.unsqueeze(1).expand(batch_size, nframes, es)], 2).transpose(0, 1).contiguous()
         x, s = self._front_apply(zc)
 
         if isinstance(stop, str):
@@ -295,13 +300,20 @@ class Discriminator(nn.Module):
                 out.append(getattr(self.rnn, '%s_l%d%s' % (n, layer, suffix)))
         return out
 
-    def features(self, x, length):
-        """the conv stack of forward() (audiogan.py:529-536): (activations, their lengths)"""
-        length = length.to(x.device).long()
-        # nframes after layer i = ceil(... ceil(length / s_1) ... / s_i) = ceil(length / (s_1 ... s_i)):
-        # all layers in one broadcast op instead of one tiny kernel pair per layer (:533)
-        prods, prods_m1 = self._stride_prods(x.device)
-        lens_all = torch.div(length.view(1, -1) + prods_m1, prods, rounding_mode='floor')
+    def stride_products(self):
+        """s_1, s_1 s_2, ...: the length after conv layer i is ceil(length / (s_1 ... s_i)) (audiogan.py:533)"""
+        return list(_cumprod([s for _, s, _ in self.cnn_struct]))
+
+    def features(self, x, length, lens_all=None):
+        """the conv stack of forward() (audiogan.py:529-536): (activations, their lengths).  ``lens_all``: the
+        [n_layers, B] int64 table of the clips' lengths after every layer when the caller already has it (the one-launch
+        input assembly of train.d_step / g_step, ops.CriticInputFn); ``length`` is then not read."""
+        if lens_all is None:
+            length = length.to(x.device).long()
+            # nframes after layer i = ceil(... ceil(length / s_1) ... / s_i) = ceil(length / (s_1 ... s_i)):
+            # all layers in one broadcast op instead of one tiny kernel pair per layer (:533)
+            prods, prods_m1 = self._stride_prods(x.device)
+            lens_all = torch.div(length.view(1, -1) + prods_m1, prods, rounding_mode='floor')
         lens_list = [lens_all[i] for i in range(lens_all.size(0))]
         acts = ops.DConvStackFn.apply(x, self._stack, lens_list, *self._stack.group.params())
         return acts, lens_list
@@ -329,9 +341,9 @@ class Discriminator(nn.Module):
         date); features() / classify() called on their own prepare their block at its first use"""
         prepare_groups([self._stack.group, self._head.group])
 
-    def forward(self, x, length, c, percent_used=0.1):
+    def forward(self, x, length, c, percent_used=0.1, lens_all=None):
         self.prepare_weights()
-        acts, lens_list = self.features(x, length)
+        acts, lens_list = self.features(x, length, lens_all)
         n = lens_list[-1]
         return self.classify(acts[-1], n, c), list(acts), lens_list, n
 
@@ -381,6 +393,7 @@ class GRUGenerator(Generator):
         for lin in (self.proj.module, self.stopper.module):
             _add(self._front.group, lin, 'weight')
             _add(self._front.group, lin, 'bias')
+        self._front.slab_channels = self._trunk.ctot
 
     def _front_apply(self, zc):
         return ops.GRUFrontFn.apply(zc, self._front, *self._front.group.params())

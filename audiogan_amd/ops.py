@@ -94,8 +94,15 @@ class GTrunkFn(torch.autograd.Function):
     def forward(ctx, x0, trunk, *params):
         B, L = x0.shape
         prep = trunk.group.prepare()
-        slab = torch.empty(B, trunk.ctot, L, device=x0.device)
-        slab[:, 0, :].copy_(x0)
+        ctot = trunk.ctot
+        if (x0.stride() == (ctot * L, 1) and x0.storage_offset() == 0 and x0.dtype == torch.float32
+                and x0.untyped_storage().nbytes() == 4 * B * ctot * L):
+            # the recurrent front wrote its frames straight into channel 0 of a fresh [B, ctot, L] slab
+            # (recurrent._frames_buffer): the trunk's input is in place
+            slab = x0.as_strided((B, ctot, L), (ctot * L, L, 1), 0)
+        else:
+            slab = torch.empty(B, ctot, L, device=x0.device)
+            slab[:, 0, :].copy_(x0)
         hids = []
         cin = 1
         for i, (cs, ds) in enumerate(trunk.bottlenecks):
@@ -130,7 +137,7 @@ class GTrunkFn(torch.autograd.Function):
         with K.deferred_reduces():      # every weight-gradient / bias-sum second stage of this backward in ONE launch
             GTrunkFn._backward_layers(trunk, prep, slab, hids, dy, dslab, dws, wg, ctot)
         grads = trunk.group.backward(dws) if wg else [None] * (2 * len(trunk.group.items))
-        dx0 = dslab[:, 0, :].contiguous() if ctx.needs_input_grad[0] else None
+        dx0 = dslab[:, 0, :] if ctx.needs_input_grad[0] else None      # (a view: the front's backward reads it in place)
         return (dx0, None) + tuple(grads)
 
     @staticmethod
@@ -290,7 +297,10 @@ class DHeadFn(torch.autograd.Function):
         hmid = torch.empty(M, w0.size(0), device=a.device)
         K.gemm(a, w0, hmid, tb=True, bias=b0, act=ACT_LEAKY)
         out = torch.empty(M, w1.size(0), device=a.device)
-        K.gemm(hmid, w1, out, tb=True, bias=b1)
+        if w1.size(0) == 1 and K.rowdot_ok(hmid, w1):
+            K.rowdot_fwd(hmid, w1, b1, out)          # a Linear with one output: one wave per row, no padded MFMA tile
+        else:
+            K.gemm(hmid, w1, out, tb=True, bias=b1)
         saved.append(hmid)
         ctx.head, ctx.key = head, head.group._key[1:]
         ctx.save_for_backward(*saved)
@@ -310,17 +320,24 @@ class DHeadFn(torch.autograd.Function):
         dout = dout.contiguous()
         with K.deferred_reduces():      # the bias sums' second stages in ONE launch (nothing below reads them)
             w0, w1 = prep[2 * nr].w, prep[2 * nr + 2].w
-            # classifier[2]: out = hmid @ w1^T + b1
-            if wg:
-                K.gemm(dout, hmid, dws[2 * nr + 2], ta=True)
-                K.col_sum(dout, dws[2 * nr + 3])
-            # every LeakyReLU backward rides in the epilogue of the product that feeds it (ACT_LEAKY_GATE: res = the saved
-            # activation), so dh / da below are d(pre-activation) as they leave the GEMM
             dh = torch.empty_like(hmid)
-            K.gemm(dout, w1, dh, res=hmid, act=ACT_LEAKY_GATE)
+            dw1, db1 = (dws[2 * nr + 2], dws[2 * nr + 3]) if wg else (None, None)
+            if w1.size(0) == 1 and K.rowdot_ok(hmid, w1) and (not wg or db1.data_ptr() == dw1.data_ptr() + 4 * dw1.numel()):
+                # classifier[2] has ONE output: its whole backward - the input gradient dout (x) w1 gated by hmid's
+                # LeakyReLU, dW1 = dout^T hmid and db1 = sum dout - is one pass over hmid (ag_rowdot_bwd) instead of an outer
+                # product and a one-row "matrix" on 64-wide MFMA tiles plus a column sum
+                K.rowdot_bwd(dout, hmid, w1, dx=dh, dw=dw1, db=db1, gate=True)
+            else:
+                # classifier[2]: out = hmid @ w1^T + b1
+                if wg:
+                    K.gemm(dout, hmid, dws[2 * nr + 2], ta=True, defer=True)
+                    K.col_sum(dout, dws[2 * nr + 3])
+                # every LeakyReLU backward rides in the epilogue of the product that feeds it (ACT_LEAKY_GATE: res = the
+                # saved activation), so dh / da below are d(pre-activation) as they leave the GEMM
+                K.gemm(dout, w1, dh, res=hmid, act=ACT_LEAKY_GATE)
             # classifier[0]
             if wg:
-                K.gemm(dh, acts[nr], dws[2 * nr], ta=True)
+                K.gemm(dh, acts[nr], dws[2 * nr], ta=True, defer=True)
                 K.col_sum(dh, dws[2 * nr + 1])
             da = torch.empty_like(acts[nr])
             if nr > 0:
@@ -330,7 +347,7 @@ class DHeadFn(torch.autograd.Function):
             fold = K.get_precision() != 'bf16'
             for i in reversed(range(nr)):
                 if wg:
-                    K.gemm(da, acts[i], dws[2 * i], ta=True)
+                    K.gemm(da, acts[i], dws[2 * i], ta=True, defer=True)
                     K.col_sum(da, dws[2 * i + 1])
                 dprev = torch.empty_like(acts[i])
                 # d(input of residual i) = W^T da + da (skip connection) = (W + I)^T da: with the identity folded into the
@@ -353,6 +370,41 @@ from .recurrent import LSTMSeqFn, GFront, GFrontFn, GRUFront, GRUFrontFn  # noqa
 
 
 # --------------------------------------------------------------------------------------
+# input assembly of the two networks (one launch each; audiogan.py:433-439, :724-728, :749-751, :844)
+# --------------------------------------------------------------------------------------
+class BuildZCFn(torch.autograd.Function):
+    """z [B,T,ns], c [B,es] -> zc [T,B,ns+es] = the non-recurrent part of every frame's LSTM input (the reference's
+    T.cat([z_t, c]) per frame, :433-439) in ONE launch instead of expand + cat + transpose + contiguous"""
+
+    @staticmethod
+    def forward(ctx, z, c):
+        ctx.ns = z.size(2)
+        return K.build_zc(z.contiguous(), c.contiguous())
+
+    @staticmethod
+    def backward(ctx, dzc):
+        ns = ctx.ns
+        dz = dzc[:, :, :ns].transpose(0, 1) if ctx.needs_input_grad[0] else None
+        dc = dzc[:, :, ns:].sum(0) if ctx.needs_input_grad[1] else None
+        return dz, dc
+
+
+class CriticInputFn(torch.autograd.Function):
+    """x + noise -> the critic's input rows and the rows' lengths after every conv layer ([n_layers, B] int64), ONE launch
+    (audiogan.py:844 ``fake + noise``, :533 the per-layer ``div_roundup``); the gradient passes through to x"""
+
+    @staticmethod
+    def forward(ctx, x, noise, length, prods):
+        xo, lens, _ = K.critic_batch(x, noise, None, None, length, None, prods)
+        ctx.mark_non_differentiable(lens)
+        return xo, lens
+
+    @staticmethod
+    def backward(ctx, dx, _dlens):
+        return dx, None, None, None
+
+
+# --------------------------------------------------------------------------------------
 # masked BCE-with-logits, / nframes, mean over batch
 # --------------------------------------------------------------------------------------
 class BCEFn(torch.autograd.Function):
@@ -363,6 +415,7 @@ class BCEFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, target, nframes, scale=None):
         B, T = x.shape
+        ctx.set_materialize_grads(False)
         rows = target if torch.is_tensor(target) else None
         tgt = 0.0 if rows is not None else float(target)
         if rows is not None:
@@ -383,6 +436,8 @@ class BCEFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dloss, _dper):
         x, nfr, rows = ctx.saved_tensors
+        if dloss is None:
+            return None, None, None, None
         dx = torch.empty_like(x)          # (keeps x's memory layout: the gradient flows back through the same view)
         g = dloss.contiguous().view(1).float()
         K.bce_logits_bwd_strided(x, ctx.target, nfr if ctx.has_n else None, g, ctx.scale, dx,

@@ -107,14 +107,17 @@ class _Fused(object):
         s1 = [l[2] for l in live]
         s2 = [l[3] for l in live] if st['s2'] else None
         self.step_count += 1
-        K.grad_norms(ps, gs, s1, s2, st['norms'], st['norm_sum'], st['flags'], grad_scale, st['step'])
+        # check=True reads the flags BEFORE the update (check_grad asserts before clip_grad / step, audiogan.py:786-788):
+        # the norms are finished by a launch of their own.  Otherwise the update launch finishes them itself (2 launches)
+        part = K.grad_norms(ps, gs, s1, s2, st['norms'], st['norm_sum'], st['flags'], grad_scale, st['step'], finish=bool(check))
         if check:
+            part = None
             f = int(st['flags'].item())
             if self.params[0].is_cuda:
                 K.check_persist_status(self.params[0].device)     # a persistent launch that gave up (its outputs are NaN)
             assert not (f & 1), 'NaN in gradients (check_grad)'
             assert not (f & 2), '|grad| > 1e5 (check_grad)'
-        self._launch(ps, gs, s1, s2, st['norms'], clip_norm, grad_scale)
+        self._launch(ps, gs, s1, s2, st['norms'], clip_norm, grad_scale, part)
         common.bump_param_epoch(self.params)
         self.last_norm_sum, self.last_flags = st['norm_sum'], st['flags']
         return st['norm_sum']
@@ -128,9 +131,10 @@ class RMSprop(_Fused):
         super().__init__(params, lr)
         self.alpha, self.eps = alpha, eps
 
-    def _launch(self, ps, gs, s1, s2, norms, clip, gscale):
+    def _launch(self, ps, gs, s1, s2, norms, clip, gscale, part=None):
         K.opt_step(ps, gs, s1, None, norms, K.OPT_RMSPROP, self.lr, float(clip), float(gscale),
-                   self.alpha, 0.0, self.eps, self.step_count, self._state['step'])
+                   self.alpha, 0.0, self.eps, self.step_count, self._state['step'], part=part,
+                   norm_sum=self._state['norm_sum'], flags=self._state['flags'])
 
 
 class Adam(_Fused):
@@ -141,9 +145,10 @@ class Adam(_Fused):
         super().__init__(params, lr)
         self.betas, self.eps = betas, eps
 
-    def _launch(self, ps, gs, s1, s2, norms, clip, gscale):
+    def _launch(self, ps, gs, s1, s2, norms, clip, gscale, part=None):
         K.opt_step(ps, gs, s1, s2, norms, K.OPT_ADAM, self.lr, float(clip), float(gscale),
-                   self.betas[0], self.betas[1], self.eps, self.step_count, self._state['step'])
+                   self.betas[0], self.betas[1], self.eps, self.step_count, self._state['step'], part=part,
+                   norm_sum=self._state['norm_sum'], flags=self._state['flags'])
 
 
 def make_optimizer(params, kind, lr):

@@ -30,6 +30,20 @@ def _small(A, B, Cm, tb=False, beta=0.0, bias=None, act=ACT_NONE, res=None):
         K.gemm(A, B, Cm, tb=tb, beta=beta, bias=bias, res=res, act=act)
 
 
+def _linear1(x, w, b, y):
+    """y [M,1] = x @ w^T + b for a Linear with ONE output (the stop head): one wave per row (ag_rowdot_fwd) instead of a
+    64-wide MFMA tile that is 98 % padding plus a split-K second stage"""
+    if K.rowdot_ok(x, w):
+        K.rowdot_fwd(x, w, b, y)
+    else:
+        K.gemm(x, w, y, tb=True, bias=b)
+
+
+def _bcast_rows(v, rows):
+    """[n] -> a [rows, n] view whose rows are all `v` (row pitch 0): a second bias for K.gemm's `res`"""
+    return v.view(1, -1).expand(rows, v.numel())
+
+
 def _small_acc(A, B, Cm, tb=False):
     """Cm += A @ op(B)"""
     if K.skinny_ok(A, B, tb):
@@ -63,15 +77,14 @@ class LSTMSeqFn(torch.autograd.Function):
         y = torch.empty(T, B, ndir * H, device=dev)
         gates_all, c_all, whh, cbs = [], [], [], []
         fused = K.lstm_step_ok(B, H)
-        # b_ih + b_hh of every direction in ONE launch
-        bsums = torch._foreach_add([w[4 * d + 2].data for d in range(ndir)], [w[4 * d + 3].data for d in range(ndir)])
         for d in range(ndir):
             w_ih, w_hh, b_ih, b_hh = w[4 * d:4 * d + 4]
             g = torch.empty(T, B, 4 * H, device=dev)
-            bsum = bsums[d]
+            # b_ih + b_hh: one rides as the GEMM's bias, the other as a `res` whose row pitch is 0 (the same row for every
+            # output row) - no launch to add the two vectors first
             if st is not None:
                 cb = torch.empty(B, 4 * H, device=dev)
-                K.gemm(st, w_ih.data[:, Fx:], cb, tb=True, bias=bsum)
+                K.gemm(st, w_ih.data[:, Fx:], cb, tb=True, bias=b_ih.data, res=_bcast_rows(b_hh.data, B))
                 if fused:
                     K.gemm(x2, w_ih.data[:, :Fx], g.view(T * B, 4 * H), tb=True)
                     cbs.append(cb)
@@ -79,7 +92,7 @@ class LSTMSeqFn(torch.autograd.Function):
                     g.copy_(cb.unsqueeze(0).expand(T, B, 4 * H))
                     K.gemm(x2, w_ih.data[:, :Fx], g.view(T * B, 4 * H), tb=True, beta=1.0)
             else:
-                K.gemm(x2, w_ih.data, g.view(T * B, 4 * H), tb=True, bias=bsum)
+                K.gemm(x2, w_ih.data, g.view(T * B, 4 * H), tb=True, bias=b_ih.data, res=_bcast_rows(b_hh.data, T * B))
             c = torch.empty(T + 1, B, H, device=dev)   # c[k+1] = cell after the k-th processed step
             if not (fused and K.lstm_persist_ok(B, H, ndir, dev)):
                 c[0].zero_()                           # (the persistent launch writes c_0 = 0 itself)
@@ -123,8 +136,15 @@ class LSTMSeqFn(torch.autograd.Function):
         dgs = [torch.empty(T, B, 4 * H, device=dev) for _ in range(ndir)]
         dhb = [torch.empty(2, B, H, device=dev) for _ in range(ndir)]
         dcb = [torch.empty(2, B, H, device=dev) for _ in range(ndir)]
+        wg = any(ctx.needs_input_grad[4:])
+        need_ds = st is not None and ctx.needs_input_grad[3]
+        # sum over time of dgates (the static input and the biases see every step's gradient): the persistent launch sums it
+        # in the registers of the threads that produce dgates; other paths leave it to a pass over dgates below
+        want_sum = st is not None and (wg or need_ds)
+        dgsums = [torch.empty(B, 4 * H, device=dev) for _ in range(ndir)] if want_sum else None
+        have_sum = False
         if B <= 256 and H % 2 == 0:
-            K.lstm_seq_bwd(gates_all, whh, c_all, dy, dgs, dhb, dcb, lengths)
+            have_sum = K.lstm_seq_bwd(gates_all, whh, c_all, dy, dgs, dhb, dcb, lengths, dgsum=dgsums)
         else:
             for d in range(ndir):
                 g, c, dg = gates_all[d], c_all[d], dgs[d]
@@ -138,52 +158,61 @@ class LSTMSeqFn(torch.autograd.Function):
                         K.gemm(dg[t], whh[d], dpass, beta=1.0)
         dx2 = torch.empty(T * B, Fx, device=dev)
         outs = []
-        wg = any(ctx.needs_input_grad[4:])
-        need_ds = st is not None and ctx.needs_input_grad[3]
         dstatic = torch.zeros_like(st) if need_ds else None
+        if dgsums is None:
+            dgsums = [None] * ndir
         for d in range(ndir):
-            w_ih, w_hh = w[4 * d], w[4 * d + 1]
+            w_ih = w[4 * d]
             wx = w_ih[:, :Fx] if st is not None else w_ih
             dg2 = dgs[d].view(T * B, 4 * H)
             K.gemm(dg2, wx, dx2, beta=0.0 if d == 0 else 1.0)
-            dgsum = None
-            if st is not None and (wg or need_ds):
-                # sum over time of dgates: the static input and the biases see every step's gradient
-                dgsum = torch.zeros(B, 4 * H, device=dev)
-                K.col_sum(dgs[d].view(T, B * 4 * H), dgsum.view(-1))
+            dgsum = dgsums[d]
+            if want_sum:
+                if not have_sum:
+                    # (read right below and by the weight-gradient products: complete at once, also inside a deferral scope)
+                    K.col_sum(dgs[d].view(T, B * 4 * H), dgsum.view(-1), accumulate=False, defer=False)
                 if need_ds:
                     K.gemm(dgsum, w_ih[:, Fx:], dstatic, beta=1.0)
-            if not wg:
-                outs += [None, None, None, None]
-                continue
-            tg = [grad_target(p_) for p_ in ctx.params[4 * d:4 * d + 4]]
-            direct = all(t_ is not None for t_ in tg)
-            # h_prev of processing step k is the layer output of step k-1 (zero at padded steps,
-            # where dgates is zero as well)
-            if direct:      # accumulate straight into .grad
-                dw_ih, dw_hh = tg[0], tg[1]
-            else:
-                dw_ih = torch.zeros_like(w_ih)
-                dw_hh = torch.zeros_like(w_hh)
-            K.gemm(dg2, x2, dw_ih[:, :Fx] if st is not None else dw_ih, ta=True, beta=1.0)
-            if st is not None:
-                K.gemm(dgsum, st, dw_ih[:, Fx:], ta=True, beta=1.0)
-            if T > 1:
-                if d == 0:
-                    K.gemm(dgs[d][1:].view((T - 1) * B, 4 * H), y[:-1].view((T - 1) * B, ndir * H)[:, :H],
-                           dw_hh, ta=True, beta=1.0)
+        if not wg:
+            outs = [None] * (4 * ndir)
+        tgs = [[grad_target(p_) for p_ in ctx.params[4 * d:4 * d + 4]] for d in range(ndir)] if wg else []
+        # every parameter gradient goes straight into ``.grad``: nothing reads it before the optimiser, so the second
+        # stages of the split-K products and column sums below may wait for the enclosing scope's ONE launch
+        direct_all = wg and all(t_ is not None for tg in tgs for t_ in tg)
+        import contextlib
+        with (K.deferred_reduces() if direct_all else contextlib.nullcontext()):
+            for d in range(ndir if wg else 0):
+                w_ih, w_hh = w[4 * d], w[4 * d + 1]
+                dg2 = dgs[d].view(T * B, 4 * H)
+                dgsum = dgsums[d]
+                tg = tgs[d]
+                direct = all(t_ is not None for t_ in tg)
+                # h_prev of processing step k is the layer output of step k-1 (zero at padded steps,
+                # where dgates is zero as well)
+                if direct:      # accumulate straight into .grad
+                    dw_ih, dw_hh = tg[0], tg[1]
                 else:
-                    K.gemm(dgs[d][:-1].view((T - 1) * B, 4 * H),
-                           y[1:].view((T - 1) * B, ndir * H)[:, H:2 * H], dw_hh, ta=True, beta=1.0)
-            src, rows = (dgsum, B) if dgsum is not None else (dg2, T * B)
-            if direct:
-                K.col_sum(src.view(rows, 4 * H), tg[2])
-                K.col_sum(src.view(rows, 4 * H), tg[3])
-                outs += [None, None, None, None]
-                continue
-            db = torch.zeros(4 * H, device=dev)
-            K.col_sum(src.view(rows, 4 * H), db)
-            outs += [dw_ih, dw_hh, db, db.clone()]
+                    dw_ih = torch.zeros_like(w_ih)
+                    dw_hh = torch.zeros_like(w_hh)
+                K.gemm(dg2, x2, dw_ih[:, :Fx] if st is not None else dw_ih, ta=True, beta=1.0, defer=direct_all)
+                if st is not None:
+                    K.gemm(dgsum, st, dw_ih[:, Fx:], ta=True, beta=1.0, defer=direct_all)
+                if T > 1:
+                    if d == 0:
+                        K.gemm(dgs[d][1:].view((T - 1) * B, 4 * H), y[:-1].view((T - 1) * B, ndir * H)[:, :H],
+                               dw_hh, ta=True, beta=1.0, defer=direct_all)
+                    else:
+                        K.gemm(dgs[d][:-1].view((T - 1) * B, 4 * H),
+                               y[1:].view((T - 1) * B, ndir * H)[:, H:2 * H], dw_hh, ta=True, beta=1.0, defer=direct_all)
+                src, rows = (dgsum, B) if dgsum is not None else (dg2, T * B)
+                if direct:
+                    K.col_sum(src.view(rows, 4 * H), tg[2])
+                    K.col_sum(src.view(rows, 4 * H), tg[3])
+                    outs += [None, None, None, None]
+                    continue
+                db = torch.zeros(4 * H, device=dev)
+                K.col_sum(src.view(rows, 4 * H), db)
+                outs += [dw_ih, dw_hh, db, db.clone()]
         dx = dx2.view(T, B, Fx) if ctx.needs_input_grad[0] else None
         return (dx, None, None, dstatic) + tuple(outs)
 
@@ -191,11 +220,24 @@ class LSTMSeqFn(torch.autograd.Function):
 # --------------------------------------------------------------------------------------
 # Generator recurrent front: T x [LSTMCell stack -> tanh(proj) fed back, stopper logit]
 # --------------------------------------------------------------------------------------
+def _frames_buffer(front, B, n, dev):
+    """where the front writes its frames x [B, n].  When the block feeds a conv trunk that keeps its activations in one
+    [B, ctot, n] slab (``front.slab_channels = ctot``, set by the Generator), x IS channel 0 of a fresh slab - the trunk
+    finds its input in place (ops.GTrunkFn) instead of copying 2 MB per forward."""
+    ctot = getattr(front, 'slab_channels', 0)
+    # (device tensors only: the kernels write through raw pointers; under the CPU kernel model of the tests torch's version
+    # counter of the shared storage would see the trunk's writes as in-place edits of the saved frames)
+    if ctot and ctot > 1 and torch.device(dev).type == 'cuda':
+        return torch.empty(B, ctot, n, device=dev)[:, 0, :]
+    return torch.empty(B, n, device=dev)
+
+
 class GFront(object):
     """WN items: per layer [w_ih, w_hh, b_ih, b_hh] * num_layers, then [proj.w, proj.b, stop.w, stop.b]"""
 
     def __init__(self, frame_size, num_layers, state_size):
         self.fs, self.nl, self.ss = frame_size, num_layers, state_size
+        self.slab_channels = 0
         self.group = WNGroup()
 
 
@@ -213,24 +255,29 @@ class GFrontFn(torch.autograd.Function):
         prep = front.group.prepare()
         lw = [[p.w for p in prep[4 * l:4 * l + 4]] for l in range(nl)]
         pw, pb, sw, sb = [p.w for p in prep[4 * nl:4 * nl + 4]]
-        x = torch.empty(B, T * fs, device=dev)
+        x = _frames_buffer(front, B, T * fs, dev)
         gates = [torch.empty(T, B, 4 * S, device=dev) for _ in range(nl)]
         hs = [torch.empty(T, B, S, device=dev) for _ in range(nl)]
         cs = [torch.empty(T + 1, B, S, device=dev) for _ in range(nl)]
-        bsum = [lw[l][2] + lw[l][3] for l in range(nl)]
         w_ih0 = lw[0][0]
         wx, wz = w_ih0[:, :fs], w_ih0[:, fs:]
-        # all frames at once: zc_t @ W_ih[:, fs:]^T + b_ih + b_hh
-        K.gemm(zc.contiguous().view(T * B, Fz), wz, gates[0].view(T * B, 4 * S), tb=True, bias=bsum[0])
+        # all frames at once: zc_t @ W_ih[:, fs:]^T + b_ih + b_hh (the second bias as a `res` of row pitch 0: no launch to
+        # add the two vectors first)
+        K.gemm(zc.contiguous().view(T * B, Fz), wz, gates[0].view(T * B, 4 * S), tb=True, bias=lw[0][2],
+               res=_bcast_rows(lw[0][3], T * B))
         fused0 = K.lstm_step_ok(B, S, x[:, :fs], wx)
         persist = nl == 1 and T > 0 and wx.stride(1) == 1 and K.gfront_persist_ok(B, S, fs, dev)
+        xt = None
         if not persist:
             for l in range(nl):
                 cs[l][0].zero_()                       # (the persistent launch writes c_0 = 0 itself)
         h0 = None if persist else torch.zeros(B, S, device=dev)      # (only the per-frame path reads it)
+        bsum = None if persist else [lw[l][2] + lw[l][3] for l in range(nl)]
         if persist:
-            # the whole frame loop (LSTMCell step + projection, fed back) in ONE launch, weights resident in registers
-            K.gfront_fwd_persist(gates[0], wx, lw[0][1], pw, pb, hs[0], cs[0], x)
+            # the whole frame loop (LSTMCell step + projection, fed back) in ONE launch, weights resident in registers; the
+            # frames are also written time-major (xt): what the weight gradient of W_ih[:, :fs] reads in backward
+            xt = torch.empty(T, B, fs, device=dev)
+            K.gfront_fwd_persist(gates[0], wx, lw[0][1], pw, pb, hs[0], cs[0], x, xt)
         for t in range(0 if persist else T):
             xprev = x[:, (t - 1) * fs:t * fs] if t > 0 else x[:, :fs]
             if fused0:
@@ -252,10 +299,11 @@ class GFrontFn(torch.autograd.Function):
                     K.lstm_cell_fwd(gates[l][t], cs[l][t], cs[l][t + 1], h_out=hs[l][t])
             _small(hs[-1][t], pw, x[:, t * fs:(t + 1) * fs], tb=True, bias=pb, act=ACT_TANH)
         s = torch.empty(T * B, 1, device=dev)
-        K.gemm(hs[-1].view(T * B, S), sw, s, tb=True, bias=sb)
+        _linear1(hs[-1].view(T * B, S), sw, sb, s)
         ctx.front, ctx.key = front, front.group._key[1:]
         ctx.dims = (T, B, Fz)
-        ctx.save_for_backward(zc, x, *(gates + hs + cs))
+        ctx.has_xt = xt is not None
+        ctx.save_for_backward(zc, x, *(gates + hs + cs + ([xt] if xt is not None else [])))
         return x, s.view(T, B).t()
 
     @staticmethod
@@ -298,21 +346,31 @@ class GFrontFn(torch.autograd.Function):
         W_ih[:, :fs]]  is ONE product, and the tanh backward of the projection, its product and the cell backward are one
         fused step (ag_lstm_front_bwd_step)."""
         dev = x.device
-        dacc = torch.zeros(T, B, S + fs, device=dev)
-        if dx is not None:
-            dacc[:, :, S:].copy_(dx.contiguous().view(B, T, fs).transpose(0, 1))
+        persist = T > 0 and wx.stride(1) == 1 and K.gfront_bwd_persist_ok(B, S, fs, dev)
+        ds_tb = None
         if ds is not None:
             ds_tb = ds.t().contiguous().view(T * B, 1)
             if dws is not None:
                 K.gemm(ds_tb, hs.view(T * B, S), dws[4 * nl + 2], ta=True)
-                K.col_sum(ds_tb, dws[4 * nl + 3])
-            K.gemm(ds_tb, sw, dacc.view(T * B, S + fs)[:, :S])
+                K.col_sum(ds_tb, dws[4 * nl + 3], defer=False)
         dgs = torch.empty(T, B, 4 * S, device=dev)
         dxt = torch.empty(T, B, fs, device=dev)
-        if T > 0 and wx.stride(1) == 1 and K.gfront_bwd_persist_ok(B, S, fs, dev):
-            # the whole loop in ONE launch, [W_hh | W_x] and W_p resident in registers (ag_gfront_bwd_persist)
-            K.gfront_bwd_persist(gates, cs, x, dacc, w_hh, wx, pw, dgs, dxt)
+        if persist:
+            # the whole loop in ONE launch, [W_hh | W_x] and W_p resident in registers (ag_gfront_bwd_persist).  The external
+            # gradients are read where they are: dL/dx_t from the trunk's gradient (any row pitch: channel 0 of its slab),
+            # dL/dh_t (the stop head's, if any) from a [T,B,S] product - no [T,B,S+fs] staging tensor to fill and copy into
+            dh_ext = None
+            if ds_tb is not None:
+                dh_ext = torch.empty(T, B, S, device=dev)
+                K.gemm(ds_tb, sw, dh_ext.view(T * B, S))
+            dx_ext = dx if (dx is None or dx.stride(1) == 1) else dx.contiguous()
+            K.gfront_bwd_persist(gates, cs, x, dh_ext, dx_ext, w_hh, wx, pw, dgs, dxt)
             return [dgs], dxt
+        dacc = torch.zeros(T, B, S + fs, device=dev)
+        if dx is not None:
+            dacc[:, :, S:].copy_(dx.view(B, T, fs).transpose(0, 1))
+        if ds_tb is not None:
+            K.gemm(ds_tb, sw, dacc.view(T * B, S + fs)[:, :S])
         wcat = torch.cat([w_hh, wx], 1)                # [4S, S+fs]
         dcs = [torch.empty(B, S, device=dev), torch.empty(B, S, device=dev)]
         for t in reversed(range(T)):
@@ -332,6 +390,7 @@ class GFrontFn(torch.autograd.Function):
         sv = ctx.saved_tensors
         zc, x = sv[0], sv[1]
         gates, hs, cs = sv[2:2 + nl], sv[2 + nl:2 + 2 * nl], sv[2 + 2 * nl:2 + 3 * nl]
+        xt = sv[2 + 3 * nl] if ctx.has_xt else None
         dev = zc.device
         lw = [[p.w for p in prep[4 * l:4 * l + 4]] for l in range(nl)]
         pw, sw = prep[4 * nl].w, prep[4 * nl + 2].w
@@ -362,24 +421,26 @@ class GFrontFn(torch.autograd.Function):
         dxt2 = dxt.view(T * B, fs)
         with K.deferred_reduces():      # the bias sums' second stages in ONE launch (read only after the block)
             if wg:
-                K.gemm(dxt2, hs[-1].view(T * B, S), dws[4 * nl], ta=True)
+                K.gemm(dxt2, hs[-1].view(T * B, S), dws[4 * nl], ta=True, defer=True)
                 K.col_sum(dxt2, dws[4 * nl + 1])
             for l in range(nl if wg else 0):
                 dg2 = dgs[l].view(T * B, 4 * S)
                 dwih = dws[4 * l]
                 if l == 0:
-                    K.gemm(dg2, zc.contiguous().view(T * B, Fz), dwih[:, fs:], ta=True)
+                    K.gemm(dg2, zc.contiguous().view(T * B, Fz), dwih[:, fs:], ta=True, defer=True)
                     if T > 1:
-                        xprev = x.view(B, T, fs)[:, :T - 1].transpose(0, 1).contiguous().view((T - 1) * B, fs)
-                        K.gemm(dgs[0][1:].view((T - 1) * B, 4 * S), xprev, dwih[:, :fs], ta=True)
+                        # x_{t-1} rows in (t, b) order: the persistent forward left them time-major (xt)
+                        xprev = xt[:T - 1].view((T - 1) * B, fs) if xt is not None else \
+                            x.view(B, T, fs)[:, :T - 1].transpose(0, 1).contiguous().view((T - 1) * B, fs)
+                        K.gemm(dgs[0][1:].view((T - 1) * B, 4 * S), xprev, dwih[:, :fs], ta=True, defer=True)
                 else:
-                    K.gemm(dg2, hs[l - 1].view(T * B, S), dwih, ta=True)
+                    K.gemm(dg2, hs[l - 1].view(T * B, S), dwih, ta=True, defer=True)
                 if T > 1:
                     K.gemm(dgs[l][1:].view((T - 1) * B, 4 * S), hs[l][:T - 1].view((T - 1) * B, S),
-                           dws[4 * l + 1], ta=True)
+                           dws[4 * l + 1], ta=True, defer=True)
                 K.col_sum(dg2, dws[4 * l + 2])
         for l in range(nl if wg else 0):
-            dws[4 * l + 3].copy_(dws[4 * l + 2])              # b_hh sees the same gradient as b_ih
+            dws[4 * l + 3] = dws[4 * l + 2]       # b_hh sees the same gradient as b_ih: the weight-norm backward reads one buffer twice
         dzc = None
         if ctx.needs_input_grad[0]:
             dzc = torch.empty(T * B, Fz, device=dev)
@@ -398,6 +459,7 @@ class GRUFront(object):
 
     def __init__(self, frame_size, state_size):
         self.fs, self.ss = frame_size, state_size
+        self.slab_channels = 0
         self.group = WNGroup()
 
 
@@ -413,7 +475,8 @@ class GRUFrontFn(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         w_ih, w_hh, b_ih, b_hh, pw, pb, sw, sb = [p.w for p in front.group.prepare()]
         wx, wz = w_ih[:, :fs], w_ih[:, fs:]
-        x = torch.empty(B, T * fs, device=dev)
+        x = _frames_buffer(front, B, T * fs, dev)
+        xt = None
         gi = torch.empty(T, B, 3 * S, device=dev)      # -> activated (r, z, n)
         gh = torch.empty(T, B, 3 * S, device=dev)      # h-part incl. b_hh (n slot needed for backward)
         hs = torch.empty(T + 1, B, S, device=dev)      # hs[t+1] = h_t, hs[0] = 0
@@ -425,7 +488,8 @@ class GRUFrontFn(torch.autograd.Function):
             bias = b_ih.clone()
             bias[:2 * S] += b_hh[:2 * S]
             K.gemm(zc.contiguous().view(T * B, Fz), wz, gi.view(T * B, 3 * S), tb=True, bias=bias)
-            K.grufront_fwd_persist(gi, gh, wx, w_hh, b_hh[2 * S:].contiguous(), pw, pb, hs[1:], x)
+            xt = torch.empty(T, B, fs, device=dev)
+            K.grufront_fwd_persist(gi, gh, wx, w_hh, b_hh[2 * S:].contiguous(), pw, pb, hs[1:], x, xt)
         else:
             K.gemm(zc.contiguous().view(T * B, Fz), wz, gi.view(T * B, 3 * S), tb=True, bias=b_ih)
         for t in range(0 if persist else T):
@@ -435,9 +499,10 @@ class GRUFrontFn(torch.autograd.Function):
             K.gru_cell_fwd(gi[t], gh[t], hs[t], hs[t + 1])
             _small(hs[t + 1], pw, x[:, t * fs:(t + 1) * fs], tb=True, bias=pb, act=ACT_TANH)
         s = torch.empty(T * B, 1, device=dev)
-        K.gemm(hs[1:].view(T * B, S), sw, s, tb=True, bias=sb)
+        _linear1(hs[1:].view(T * B, S), sw, sb, s)
         ctx.front, ctx.key, ctx.dims = front, front.group._key[1:], (T, B, Fz)
-        ctx.save_for_backward(zc, x, gi, gh, hs)
+        ctx.has_xt = xt is not None
+        ctx.save_for_backward(zc, x, gi, gh, hs, *([xt] if xt is not None else []))
         return x, s.view(T, B).t()
 
     @staticmethod
@@ -449,7 +514,8 @@ class GRUFrontFn(torch.autograd.Function):
         assert front.group._key[1:] == ctx.key, 'parameters changed between forward and backward'
         w_ih, w_hh, _, _, pw, _, sw, _ = [p.w for p in prep]
         wx = w_ih[:, :fs]
-        zc, x, gi, gh, hs = ctx.saved_tensors
+        zc, x, gi, gh, hs = ctx.saved_tensors[:5]
+        xt = ctx.saved_tensors[5] if ctx.has_xt else None
         dev = zc.device
         wg = any(ctx.needs_input_grad[2:])
         dws = front.group.zero_dws() if wg else None
@@ -457,22 +523,22 @@ class GRUFrontFn(torch.autograd.Function):
         dgi = torch.empty(T, B, 3 * S, device=dev)
         dgh = torch.empty(T, B, 3 * S, device=dev)
         dxt = torch.empty(T, B, fs, device=dev)
-        if persist:
-            # the whole loop in ONE launch (ag_grufront_bwd_persist): dacc[t] = the external gradient [dL/dh_t | dL/dx_t]
-            dacc = torch.zeros(T, B, S + fs, device=dev)
-            if dx is not None:
-                dacc[:, :, S:].copy_(dx.contiguous().view(B, T, fs).transpose(0, 1))
-        else:
+        dh_ext = None
+        if not persist:
             dxa = dx.contiguous().clone() if dx is not None else torch.zeros(B, T * fs, device=dev)
             dha = torch.zeros(T + 1, B, S, device=dev)     # dha[t+1] accumulates dL/dh_t
         if ds is not None:
             ds_tb = ds.t().contiguous().view(T * B, 1)
             if wg:
                 K.gemm(ds_tb, hs[1:].view(T * B, S), dws[6], ta=True)
-                K.col_sum(ds_tb, dws[7])
-            K.gemm(ds_tb, sw, dacc.view(T * B, S + fs)[:, :S] if persist else dha[1:].view(T * B, S))
+                K.col_sum(ds_tb, dws[7], defer=False)
+            if persist:
+                dh_ext = torch.empty(T, B, S, device=dev)
+            K.gemm(ds_tb, sw, dh_ext.view(T * B, S) if persist else dha[1:].view(T * B, S))
         if persist:
-            K.grufront_bwd_persist(gi, hs, gh, x, dacc, w_hh, wx, pw, dgi, dgh, dxt)
+            # the whole loop in ONE launch (ag_grufront_bwd_persist); the external gradients dL/dh_t, dL/dx_t are read in place
+            dx_ext = dx if (dx is None or dx.stride(1) == 1) else dx.contiguous()
+            K.grufront_bwd_persist(gi, hs, gh, x, dh_ext, dx_ext, w_hh, wx, pw, dgi, dgh, dxt)
         dh_dir = None if persist else torch.empty(B, S, device=dev)
         for t in reversed(range(0 if persist else T)):
             gx = dxt[t]
@@ -489,7 +555,8 @@ class GRUFrontFn(torch.autograd.Function):
             K.col_sum(dxt2, dws[5])
             K.gemm(dgi2, zc.contiguous().view(T * B, Fz), dws[0][:, fs:], ta=True)
             if T > 1:
-                xprev = x.view(B, T, fs)[:, :T - 1].transpose(0, 1).contiguous().view((T - 1) * B, fs)
+                xprev = xt[:T - 1].view((T - 1) * B, fs) if xt is not None else \
+                    x.view(B, T, fs)[:, :T - 1].transpose(0, 1).contiguous().view((T - 1) * B, fs)
                 K.gemm(dgi[1:].view((T - 1) * B, 3 * S), xprev, dws[0][:, :fs], ta=True)
             K.gemm(dgh2, hs[:T].view(T * B, S), dws[1], ta=True)
             K.col_sum(dgi2, dws[2])

@@ -4,11 +4,45 @@ numbers can be fed to the CPU oracle."""
 import torch
 
 from . import kernels as K
-from .common import frozen
+from .common import frozen, network_backward
+from .ops import CriticInputFn
 from .extras import adversarial_movement_d, adversarially_sample_z, calc_dists, feature_penalty
 from .losses import length_mask, masked_bce_mean, only_stopper_trains, real_fake_targets, stopper_surrogate_loss
 
 _SIDE = {}
+_ONE = {}
+
+
+def _backward(t, grad=None, **kw):
+    """``t.backward(grad)`` inside a network-level scope (common.network_backward): the second stages of every deferred
+    reduction of the whole backward run as ONE launch and the weight-norm backward of every block as ONE launch.  The root
+    gradient of a scalar loss is a cached ones tensor (autograd would fill a fresh one: a launch per backward)."""
+    if grad is None:
+        key = (t.device, t.dtype)
+        grad = _ONE.get(key)
+        if grad is None:
+            grad = _ONE[key] = torch.ones((), device=t.device, dtype=t.dtype)
+        assert t.dim() == 0, 'a root gradient is needed for a non-scalar tensor'
+    with network_backward():
+        t.backward(grad, **kw)
+
+
+def _critic_inputs(d, real, noise_real, fake, noise_fake, real_len, fake_len, c):
+    """the critic iteration's minibatch [real + noise ; fake + noise], the rows' lengths after every conv layer and the
+    conditioning rows [c ; c] - ONE launch (kernels.critic_batch) instead of two adds, three cats and the length
+    arithmetic; plain torch when the tensors are not on the GPU (host-logic tests)"""
+    if real.is_cuda and hasattr(d, 'stride_products') and real.dtype == torch.float32:
+        return K.critic_batch(real, noise_real, fake, noise_fake, real_len.to(real.device).long().contiguous(),
+                              fake_len.contiguous(), d.stride_products(), c.contiguous(), c.contiguous())
+    x = torch.cat([real + noise_real, fake + noise_fake if noise_fake is not None else fake], 0)
+    return x, None, torch.cat([c, c], 0)
+
+
+def _noisy(d, fake, noise, fake_len):
+    """generator iteration: (fake + noise, lengths table or None), the gradient passing through to ``fake``"""
+    if fake.is_cuda and hasattr(d, 'stride_products') and fake.dtype == torch.float32:
+        return CriticInputFn.apply(fake, noise, fake_len.contiguous(), d.stride_products())
+    return fake + noise, None
 
 
 def gd_step(g, d, opt_g, opt_d, real, real_len, c, z, noise_real, noise_fake, dgradclip=1.0, ggradclip=0.1,
@@ -54,25 +88,25 @@ def d_step(g, d, opt_d, real, real_len, c, z, noise_real, noise_fake, dgradclip=
     (audiogan.py:723-728, 739-740, 748-751, 761-766, 780-788)."""
     with torch.no_grad():
         fake, _, _, fake_len = g(z=z, c=c, stop=stop)
-        fake = fake + noise_fake
     B = real.size(0)
     if batch_real_fake and fake.size(1) == real.size(1):
         # D has no cross-sample op, so D(cat(real, fake)) == cat(D(real), D(fake)): one pass over
         # 2B clips halves the number of strictly sequential biLSTM steps of the critic iteration
-        cls, _, _, nf = d(torch.cat([real + noise_real, fake], 0), torch.cat([real_len.to(fake_len.device), fake_len], 0),
-                          torch.cat([c, c], 0))
+        x2, tab, c2 = _critic_inputs(d, real, noise_real, fake, noise_fake, real_len, fake_len, c)
+        cls, _, _, nf = d(x2, torch.cat([real_len.to(fake_len.device), fake_len], 0) if tab is None else None, c2,
+                          lens_all=tab)
         cls_d, cls_g = cls[:B], cls[B:]
         # mean over the real clips + mean over the fake clips = (1 / B) * the sum over all 2B rows, targets 0.9 / 0 per row:
         # ONE loss launch forward and backward (no slices for autograd to reassemble)
         loss, _ = masked_bce_mean(cls, real_fake_targets(B, cls.device), nf, scale=1.0 / B)
     else:
         cls_d, _, _, nf_d = d(real + noise_real, real_len, c)
-        cls_g, _, _, nf_g = d(fake, fake_len, c)
+        cls_g, _, _, nf_g = d(fake + noise_fake, fake_len, c)
         loss_d, _ = masked_bce_mean(cls_d, 0.9, nf_d.contiguous())
         loss_g, _ = masked_bce_mean(cls_g, 0.0, nf_g.contiguous())
         loss = loss_d + loss_g
     opt_d.zero_grad()
-    loss.backward()
+    _backward(loss)
     scale = grad_hook() if grad_hook is not None else 1.0
     opt_d.step(clip_norm=dgradclip, grad_scale=scale, check=check)
     return loss.detach(), cls_d.detach(), cls_g.detach()
@@ -86,12 +120,13 @@ def g_step(g, d, opt_g, c, z, noise_fake, ggradclip=0.1, g_optim='boundary_seeki
     iteration - bench.py does that)."""
     with frozen(d):
         fake, _, _, fake_len = pre if pre is not None else g(z=z, c=c, stop=stop)
-        cls_g, _, _, nf_g = d(fake + noise_fake, fake_len, c)
+        noisy, tab = _noisy(d, fake, noise_fake, fake_len)
+        cls_g, _, _, nf_g = d(noisy, fake_len, c, lens_all=tab)
         tgt = 0.5 if g_optim == 'boundary_seeking' else 0.0
         loss, _ = masked_bce_mean(cls_g, tgt, nf_g)
         opt_g.zero_grad()
         with K.front_bwd_persist(_single_gpu(opt_g)):
-            loss.backward()
+            _backward(loss)
     scale = grad_hook() if grad_hook is not None else 1.0
     opt_g.step(clip_norm=ggradclip, grad_scale=scale, check=check)
     return loss.detach(), fake.detach(), cls_g.detach()
@@ -107,20 +142,20 @@ def d_backward(g, d, opt_d, real, real_len, c, z, noise_real, noise_fake, stop='
     """forward + backward of the critic iteration; gradients are left in ``.grad``"""
     with torch.no_grad():
         fake, _, _, fake_len = g(z=z, c=c, stop=stop)
-        fake = fake + noise_fake
     B = real.size(0)
     if batch_real_fake and fake.size(1) == real.size(1):
-        cls, _, _, nf = d(torch.cat([real + noise_real, fake], 0),
-                          torch.cat([real_len.to(fake_len.device), fake_len], 0), torch.cat([c, c], 0))
+        x2, tab, c2 = _critic_inputs(d, real, noise_real, fake, noise_fake, real_len, fake_len, c)
+        cls, _, _, nf = d(x2, torch.cat([real_len.to(fake_len.device), fake_len], 0) if tab is None else None, c2,
+                          lens_all=tab)
         loss, _ = masked_bce_mean(cls, real_fake_targets(B, cls.device), nf, scale=1.0 / B)     # (see d_step)
     else:
         cls_d, _, _, nf_d = d(real + noise_real, real_len, c)
-        cls_g, _, _, nf_g = d(fake, fake_len, c)
+        cls_g, _, _, nf_g = d(fake + noise_fake, fake_len, c)
         loss_d, _ = masked_bce_mean(cls_d, 0.9, nf_d.contiguous())
         loss_g, _ = masked_bce_mean(cls_g, 0.0, nf_g.contiguous())
         loss = loss_d + loss_g
     opt_d.zero_grad()
-    loss.backward()
+    _backward(loss)
     return loss.detach()
 
 
@@ -129,11 +164,12 @@ def g_backward(g, d, opt_g, c, z, noise_fake, g_optim='boundary_seeking', stop='
     ``pre``: the generator's forward result when the caller already ran it (see g_step)"""
     with frozen(d):
         fake, _, _, fake_len = pre if pre is not None else g(z=z, c=c, stop=stop)
-        cls_g, _, _, nf_g = d(fake + noise_fake, fake_len, c)
+        noisy, tab = _noisy(d, fake, noise_fake, fake_len)
+        cls_g, _, _, nf_g = d(noisy, fake_len, c, lens_all=tab)
         loss, _ = masked_bce_mean(cls_g, 0.5 if g_optim == 'boundary_seeking' else 0.0, nf_g)
         opt_g.zero_grad()
         with K.front_bwd_persist(_single_gpu(opt_g)):
-            loss.backward()
+            _backward(loss)
     return loss.detach()
 
 
@@ -143,24 +179,23 @@ def d_backward_early(g, d, opt_d, real, real_len, c, z, noise_real, noise_fake, 
     ``d_backward_late`` pushes the gradient through the conv stack.  ``keep`` carries the cut tensors."""
     with torch.no_grad():
         fake, _, _, fake_len = g(z=z, c=c, stop=stop)
-        fake = fake + noise_fake
     B = real.size(0)
-    x = torch.cat([real + noise_real, fake], 0)
-    lens = torch.cat([real_len.to(fake_len.device), fake_len], 0)
-    acts, lens_list = d.features(x, lens)
+    x, tab, c2 = _critic_inputs(d, real, noise_real, fake, noise_fake, real_len, fake_len, c)
+    lens = torch.cat([real_len.to(fake_len.device), fake_len], 0) if tab is None else None
+    acts, lens_list = d.features(x, lens, tab)
     a_cut = acts[-1].detach().requires_grad_(True)
     nf = lens_list[-1]
-    cls = d.classify(a_cut, nf, torch.cat([c, c], 0))
+    cls = d.classify(a_cut, nf, c2)
     loss, _ = masked_bce_mean(cls, real_fake_targets(B, cls.device), nf, scale=1.0 / B)     # (see d_step)
     opt_d.zero_grad()
-    loss.backward()
+    _backward(loss)
     keep['acts'], keep['a_cut'] = acts, a_cut
     return loss.detach()
 
 
 def d_backward_late(keep):
     """the conv stack's backward (weight gradients of D's cnn) from the cut gradient"""
-    keep['acts'][-1].backward(keep['a_cut'].grad)
+    _backward(keep['acts'][-1], keep['a_cut'].grad)
 
 
 def g_backward_early(g, d, opt_g, c, z, noise_fake, keep, g_optim='boundary_seeking', stop='never', pre=None):
@@ -170,10 +205,11 @@ def g_backward_early(g, d, opt_g, c, z, noise_fake, keep, g_optim='boundary_seek
     caller already ran the generator's forward (with the same ``keep``)."""
     with frozen(d):
         fake, _, _, fake_len = pre if pre is not None else g(z=z, c=c, stop=stop, cut=keep)
-        cls_g, _, _, nf_g = d(fake + noise_fake, fake_len, c)
+        noisy, tab = _noisy(d, fake, noise_fake, fake_len)
+        cls_g, _, _, nf_g = d(noisy, fake_len, c, lens_all=tab)
         loss, _ = masked_bce_mean(cls_g, 0.5 if g_optim == 'boundary_seeking' else 0.0, nf_g)
         opt_g.zero_grad()
-        loss.backward()
+        _backward(loss)
     return loss.detach()
 
 
@@ -184,7 +220,7 @@ def g_backward_late(keep, persist=False):
     while a persistent launch wants all of its workgroups resident - pass True only when no collective is in flight
     (``GraphedStep`` does when it has no gradient bucket)."""
     with K.front_bwd_persist(bool(persist)):
-        keep['x'].backward(keep['x_cut'].grad)
+        _backward(keep['x'], keep['x_cut'].grad)
 
 
 # --------------------------------------------------------------------------------------
@@ -221,7 +257,7 @@ def d_step_full(g, d, e_g, e_d, opt_d, dis_iter, real, real_len, cs, cl, cs2, cl
     loss_g, _ = masked_bce_mean(cls_g, 0.0, nf_g.contiguous())
     loss = loss_d + loss_g
     opt_d.zero_grad()
-    loss.backward()
+    _backward(loss)
     opt_d.step(clip_norm=dgradclip, check=check)
     return dict(loss=loss.detach(), loss_d=loss_d.detach(), loss_g=loss_g.detach(), cls_d=cls_d.detach(),
                 cls_g=cls_g.detach(), grad_norm=opt_d.last_norm_sum,
@@ -256,9 +292,9 @@ def g_step_full(g, d, e_g, e_d, opt_g, real, real_len, cs, cl, z0, noise_real, n
         reward = (reward - baseline).unsqueeze(1) * weight_r
         loss = bce + pen * lambda_fp
         opt_g.zero_grad()
-        loss.backward(retain_graph=True)
+        _backward(loss, retain_graph=True)
         with only_stopper_trains(g, e_g):
-            stopper_surrogate_loss(s, stop_list, reward).backward()
+            _backward(stopper_surrogate_loss(s, stop_list, reward))
     opt_g.step(clip_norm=ggradclip, check=check)
     return dict(loss=loss.detach(), bce=bce.detach(), feature_penalty=pen.detach(), z=z, fake=fake.detach(),
                 fake_len=fake_len, s=s.detach(), baseline=baseline, grad_norm=opt_g.last_norm_sum)
@@ -280,13 +316,13 @@ def c4_step(g, critic, opt_g, opt_d, real, c, z, noise_real, noise_fake, dgradcl
     cls = critic(torch.cat([real + noise_real, fake], 0)).view(2 * B, 1)
     loss_d = masked_bce_mean(cls[:B], 0.9, None)[0] + masked_bce_mean(cls[B:], 0.0, None)[0]
     opt_d.zero_grad()
-    loss_d.backward()
+    _backward(loss_d)
     opt_d.step(clip_norm=dgradclip, grad_scale=hook_d() if hook_d is not None else 1.0, check=check)
     with frozen(critic):
         fake = g(z=z, c=c, stop='never')[0]
         loss_g = masked_bce_mean(critic(fake + noise_fake).view(B, 1), 0.5, None)[0]
         opt_g.zero_grad()
-        loss_g.backward()
+        _backward(loss_g)
     opt_g.step(clip_norm=ggradclip, grad_scale=hook_g() if hook_g is not None else 1.0, check=check)
     return loss_d.detach(), loss_g.detach()
 
@@ -298,12 +334,12 @@ def wgan_gp_step(g, critic, opt_g, opt_d, real, c, z, eps, lam=10.0, dgradclip=0
         fake = g(z=z, c=c, stop='never')[0]
     loss_d = wgan_gp_d_loss(critic, real, fake, eps, lam)
     opt_d.zero_grad()
-    loss_d.backward()
+    _backward(loss_d)
     opt_d.step(clip_norm=dgradclip, grad_scale=hook_d() if hook_d is not None else 1.0, check=check)
     with frozen(critic):
         loss_g = wgan_g_loss(critic, g(z=z, c=c, stop='never')[0])
         opt_g.zero_grad()
-        loss_g.backward()
+        _backward(loss_g)
     opt_g.step(clip_norm=ggradclip, grad_scale=hook_g() if hook_g is not None else 1.0, check=check)
     return loss_d.detach(), loss_g.detach()
 

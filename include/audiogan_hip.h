@@ -146,7 +146,7 @@ int ag_conv1d_wgrad(const float* sh, int64_t sh_bs, int64_t sh_cs, const float* 
  * has plain vector kernels.  w is the standard [1, C, K] weight (= [C, K]); K <= 9.
  *   fwd      y[b,t]      = act(bias + sum_{c,k} w[c,k] x[b,c,t+k-pad])
  *   bwd_data dx[b,c,t] (+)= sum_k w[c,k] dy[b,t-k+pad]
- *   wgrad    dw[c,k]    += sum_{b,t} dy[b,t] x[b,c,t+k-pad]        (atomics; dw pre-zeroed) */
+ *   wgrad    dw[c,k]    += sum_{b,t} dy[b,t] x[b,c,t+k-pad]        (two-stage, needs a bound workspace; dw pre-zeroed) */
 int ag_conv1d_o1_fwd(const float* x, int64_t x_bs, int64_t x_cs, const float* w, const float* bias, float* y,
                      int64_t y_bs, int B, int C, int L, int K, int pad, int act, float slope, void* stream);
 int ag_conv1d_o1_bwd_data(const float* dy, int64_t dy_bs, const float* w, float* dx, int64_t dx_bs,
@@ -154,8 +154,8 @@ int ag_conv1d_o1_bwd_data(const float* dy, int64_t dy_bs, const float* w, float*
 int ag_conv1d_o1_wgrad(const float* dy, int64_t dy_bs, const float* x, int64_t x_bs, int64_t x_cs, float* dw,
                        int B, int C, int L, int K, int pad, void* stream);
 
-/* db[c] (+)= sum_{b,t} dy[b,c,t]   (bias gradient; atomics, db pre-zeroed) */
-int ag_channel_sum(const float* dy, int64_t bs, int64_t cs, float* db, int B, int C, int L,
+/* db[c] = (accumulate ? db[c] : 0) + sum_{b,t} dy[b,c,t]   (bias gradient; two-stage through the bound workspace) */
+int ag_channel_sum(const float* dy, int64_t bs, int64_t cs, float* db, int B, int C, int L, int accumulate,
                    void* stream);
 
 /* dpre = dy * (y > 0 ? 1 : slope) * (t < lens[b])   elementwise on [B,C,L] views.
@@ -183,8 +183,9 @@ int ag_gemm(const float* A, int lda, int ta, const float* B, int ldb, int tb, fl
             int M, int N, int K, float alpha, float beta, const float* bias, const float* res,
             int ldres, int act, float slope, void* stream);
 
-/* column sums: out[n] (+)= sum_m X[m, n]   (Linear bias gradient) */
-int ag_col_sum(const float* X, int ldx, float* out, int M, int N, void* stream);
+/* column sums: out[n] = (accumulate ? out[n] : 0) + sum_m X[m, n]   (Linear bias gradient; two-stage through the bound
+ * workspace, or one row block per column when none is bound) */
+int ag_col_sum(const float* X, int ldx, float* out, int M, int N, int accumulate, void* stream);
 
 /* ---------------------------------------------------------------------------
  * LSTM cell pointwise step (NN.LSTMCell / NN.LSTM, audiogan.py:380,440-442,498):
@@ -236,12 +237,13 @@ int ag_get_precision(void);
 
 /* Deterministic cross-workgroup reductions.  Entry points that sum over workgroups (ag_conv1d_wgrad,
  * ag_conv1d_o1_wgrad, ag_channel_sum, ag_leaky_bwd's bias gradient, ag_gemm's split-K products, ag_col_sum,
- * ag_skinny_gemm in accumulate mode, ag_lstm_seq_bwd's unfused fallback, ag_grad_norms) do so in TWO STAGES when a
- * workspace is bound: partial results with plain stores, then a sum in a fixed order - bitwise reproducible, and no
- * float atomics (which execute at the memory side at ~1.3 TB/s).  ag_bind_workspace() binds `numel` floats (16-byte
+ * ag_skinny_gemm in accumulate mode, ag_lstm_seq_bwd's unfused fallback, ag_grad_norms) do so in TWO STAGES through a
+ * bound workspace: partial results with plain stores, then a sum in a fixed order - bitwise reproducible.  There is NO
+ * float-atomic path any more (round 4): a call whose sum spans workgroups returns AG_ERR_ARG when no (or too small a)
+ * workspace is bound; ag_gemm and ag_col_sum then run unsplit instead.  ag_bind_workspace() binds `numel` floats (16-byte
  * aligned device memory on the launch stream's device) for the NEXT such call of this host thread; the call consumes
- * the binding.  The ag_*_ws_numel() functions return the size a call wants (0: none needed); a smaller workspace
- * reduces the number of partial slabs, a missing one selects the float-atomic path (order-dependent last bits). */
+ * the binding.  The ag_*_ws_numel() functions return the size a call wants (0: none needed); a smaller workspace (down to
+ * the minimum each call states in its error text) reduces the number of partial slabs. */
 int ag_bind_workspace(float* ws, int64_t numel);
 int64_t ag_conv1d_wgrad_ws_numel(int B, int A, int Lsh, int C, int K);
 int64_t ag_gemm_ws_numel(int M, int N, int K, int act);
@@ -252,12 +254,38 @@ int64_t ag_gemm_ws_numel(int M, int N, int K, int act);
 int ag_transpose_batched(const float* in, int64_t ibs, int64_t irs, float* out, int64_t obs, int64_t ors, int B, int R,
                          int Cc, void* stream);
 
-/* Deferred second stages.  Between ag_defer_reduces(1) and ag_flush_reduces() every two-stage reduction of the calling
- * thread (conv weight gradients, bias / channel sums - not the split-K GEMM, whose second stage carries an epilogue) only
- * records its second stage; the flush sums all recorded outputs in ONE launch, each in the order its own launch would use
- * (bitwise the same results).  The caller keeps every bound workspace alive until the flush and turns deferral off again
- * with ag_defer_reduces(0) (an error if recorded stages were never flushed).  Thread-local, like ag_bind_workspace. */
-int ag_defer_reduces(int on);
+/* Input assembly, one launch each (round 4; replaces T.cat / expand / transpose / + on the iteration path).
+ * ag_build_zc: zc[t,b,:] = [z[b,t,:ns] | c[b,:es]], the non-recurrent part of the Generator front's LSTM input
+ * (audiogan.py:433-439: z [B,T,ns], c [B,es] -> zc [T,B,ns+es] contiguous).
+ * ag_critic_batch: the critic's minibatch (audiogan.py:724-728, :749-751, :844): rows [0,nA) = xa + na, rows [nA,nA+nB) =
+ * xb + nb (na / nb = instance noise, NULL = none; row pitches in elements) -> x_out [nA+nB, L] contiguous; the rows'
+ * lengths after every conv layer, lens_out[i, row] = ceil(len / prods[i]) (audiogan.py:533; lenA / lenB NULL = L; prods =
+ * the nl <= 8 cumulative stride products, a HOST array) and the conditioning rows c_out = [cA ; cB] ([.,E]; NULL = skip). */
+/* A Linear layer with ONE output (the critic's last layer 512 -> 1, audiogan.py:511,:549; the Generator's stop head
+ * 1024 -> 1, :410,:445).  ag_rowdot_fwd: y[m*ldy] = x[m,:K] . w + bias[0] (bias may be NULL).  ag_rowdot_bwd, one pass over
+ * x: dx[m,k] = dy[m*lddy] * w[k] (times LeakyReLU'(x[m,k]) when gate: x is then the SAVED OUTPUT of the LeakyReLU below;
+ * dx may be NULL), and when dw != NULL: dw[k] (+)= sum_m dy[m] x[m,k], db[0] (+)= sum_m dy[m] with db == dw + K (one
+ * [K+1] gradient row), two-stage through a bound workspace of ag_rowdot_bwd_ws_numel floats (deferrable). */
+int ag_rowdot_fwd(const float* x, int ldx, const float* w, const float* bias, float* y, int64_t ldy, int M, int K,
+                  void* stream);
+int64_t ag_rowdot_bwd_ws_numel(int M, int K);
+int ag_rowdot_bwd(const float* dy, int64_t lddy, const float* x, int ldx, const float* w, float* dx, int lddx, float* dw,
+                  float* db, int accumulate, int M, int K, int gate, float slope, void* stream);
+int ag_build_zc(const float* z, const float* c, float* zc, int B, int T, int ns, int es, void* stream);
+int ag_critic_batch(const float* xa, int64_t xa_ld, const float* na, int64_t na_ld, int nA, const float* xb,
+                    int64_t xb_ld, const float* nb, int64_t nb_ld, int nB, int L, float* x_out,
+                    const int64_t* lenA_i64, const int64_t* lenB_i64, const int32_t* prods_host, int nl,
+                    int64_t* lens_out_i64, const float* cA, const float* cB, int E, float* c_out, void* stream);
+
+/* Deferred second stages.  Between ag_defer_reduces(1) and ag_flush_reduces() every two-stage reduction (conv weight
+ * gradients, bias / channel / column sums, and a split-K ag_gemm whose second stage has a plain epilogue: contiguous C, no
+ * bias / res, beta 0 or 1) only records its second stage; the flush sums all recorded outputs in ONE launch, each in the
+ * order its own launch would use (bitwise the same results).  The caller keeps every bound workspace alive until the flush
+ * and turns deferral off again with ag_defer_reduces(0) (an error if recorded stages were never flushed).
+ * Modes: 1 = start recording, 0 = stop, 2 = pause (a call issued now finishes at once; recorded stages stay), 3 = resume.
+ * Process-wide since round 4 (a scope is opened by the thread that calls backward(), the recording calls come from
+ * torch's autograd thread; never concurrently), unlike ag_bind_workspace, which stays per thread. */
+int ag_defer_reduces(int mode);
 int ag_flush_reduces(void* stream);
 int64_t ag_skinny_ws_numel(int M, int N, int K);
 
@@ -329,9 +357,11 @@ int ag_lstm_seq_fwd_persist(float* const* pre, const float* const* whh, float* c
  * ndir * ceil(B/16) * H/32 <= n_cu (ag_lstm_persist_bwd_ok); `ws` >= 256 B + 8 KiB, laid out as above.  Tensors as for
  * ag_lstm_seq_bwd (no dhbuf/dcbuf: the state stays in registers). */
 int ag_lstm_persist_bwd_ok(int B, int H, int ndir, int n_cu);
+/* (round 4) dgsum: optional table of ndir [B,4H] outputs, the sum over time of dgates (what the biases and a time-invariant
+ * input see), accumulated in registers by the thread that produces each (clip, gate) pair - no separate pass over dgates */
 int ag_lstm_seq_bwd_persist(const float* const* gates, const float* const* whh, const float* const* c_all,
-                            const float* dy, float* const* dgates, const int64_t* valid_i64, void* ws,
-                            int64_t ws_bytes, int T, int B, int H, int ndir, int n_cu, void* stream);
+                            const float* dy, float* const* dgates, float* const* dgsum, const int64_t* valid_i64,
+                            void* ws, int64_t ws_bytes, int T, int B, int H, int ndir, int n_cu, void* stream);
 
 /* The Generator front's whole frame loop (audiogan.py:428-460, one LSTMCell layer + tanh(proj) fed back) as ONE
  * persistent launch with every weight resident in registers (csrc/lstm_persist.hip).  gates [T,B,4S]: in = the z / c
@@ -341,28 +371,34 @@ int ag_lstm_seq_bwd_persist(const float* const* gates, const float* const* whh, 
  * ag_gfront_persist_ws_bytes() bytes, used as for ag_lstm_seq_fwd_persist. */
 int ag_gfront_persist_ok(int B, int S, int fs, int n_cu);
 int64_t ag_gfront_persist_ws_bytes(int B, int S, int fs);
+/* (round 4) x [B,T*fs] has a row pitch `ldx`: the caller may hand over channel 0 of the conv trunk's activation slab, so the
+ * frames land where the trunk reads them (no copy); `xt` (optional) receives the same frames time-major [T,B,fs], the layout
+ * the weight-gradient products over all frames read. */
 int ag_gfront_fwd_persist(float* gates, const float* w_x, int ldwx, const float* w_hh, const float* w_p,
-                          const float* b_p, float* hs, float* cs, float* x, void* ws, int64_t ws_bytes, int T, int B,
-                          int S, int fs, int n_cu, void* stream);
+                          const float* b_p, float* hs, float* cs, float* x, int64_t ldx, float* xt, void* ws,
+                          int64_t ws_bytes, int T, int B, int S, int fs, int n_cu, void* stream);
 
 /* The frame loop of the Generator front's BACKWARD through time (audiogan.py:437-443 under .backward() :903) in one
- * persistent launch: per frame gx_t = (dacc_x[t] + dgates_{t+1} W_x)(1 - x_t^2), dh_t = dacc_h[t] + dgates_{t+1} W_hh +
+ * persistent launch: per frame gx_t = (dx_ext[t] + dgates_{t+1} W_x)(1 - x_t^2), dh_t = dh_ext[t] + dgates_{t+1} W_hh +
  * gx_t W_p, dgates_t = cell backward.  ga [T,B,4S] activated gates and c_all [T+1,B,S] as saved by ag_gfront_fwd_persist,
- * x [B,T*fs], dacc [T,B,S+fs] the external gradient [dL/dh_t | dL/dx_t] (read only), w_hh [4S,S], w_x = W_ih[:, :fs] (row
- * pitch ldwx), w_p [fs,S]; outputs dgs [T,B,4S] and dxt [T,B,fs] (d pre-tanh of the projection), which the weight-gradient
+ * x [B,T*fs] (row pitch ldx); the external gradients dh_ext [T,B,S] = dL/dh_t (the stop head's) and dx_ext [B,T*fs] =
+ * dL/dx_t (the conv trunk's; row pitch lddx - it may be channel 0 of the trunk's gradient slab), each read only and each
+ * NULL = zero; w_hh [4S,S], w_x = W_ih[:, :fs] (row pitch ldwx), w_p [fs,S]; outputs dgs [T,B,4S] and dxt [T,B,fs] (d pre-tanh of the projection), which the weight-gradient
  * GEMMs over all frames read.  Supported: (S, fs) as above and ceil(B/32) * (S+fs)/16 <= n_cu (ag_gfront_bwd_persist_ok);
  * `ws`: the sticky word + 8 KiB header (see ag_lstm_seq_fwd_persist). */
 int ag_gfront_bwd_persist_ok(int B, int S, int fs, int n_cu);
-int ag_gfront_bwd_persist(const float* ga, const float* c_all, const float* x, const float* dacc, const float* w_hh,
-                          const float* w_x, int ldwx, const float* w_p, float* dgs, float* dxt, void* ws,
-                          int64_t ws_bytes, int T, int B, int S, int fs, int n_cu, void* stream);
+int ag_gfront_bwd_persist(const float* ga, const float* c_all, const float* x, int64_t ldx, const float* dh_ext,
+                          const float* dx_ext, int64_t lddx, const float* w_hh, const float* w_x, int ldwx,
+                          const float* w_p, float* dgs, float* dxt, void* ws, int64_t ws_bytes, int T, int B, int S, int fs,
+                          int n_cu, void* stream);
 /* The same for the GRU-front generator (BASELINE configs[3]; torch.nn.GRUCell backward, gate order r z n): ga [T,B,3S]
  * activated gates, hs [T+1,B,S] (hs[t] = h_{t-1}, hs[0] = 0) and gh [T,B,3S] (n slot = W_hn h_{t-1} + b_hn) as saved by
  * ag_grufront_fwd_persist; outputs dgi [T,B,3S] (d of the input-side pre-activations), dgh [T,B,3S] (hidden side: the n slot
  * times r) and dxt [T,B,fs].  Shapes and workspace as ag_gfront_bwd_persist. */
-int ag_grufront_bwd_persist(const float* ga, const float* hs, const float* gh, const float* x, const float* dacc,
-                            const float* w_hh, const float* w_x, int ldwx, const float* w_p, float* dgi, float* dgh,
-                            float* dxt, void* ws, int64_t ws_bytes, int T, int B, int S, int fs, int n_cu, void* stream);
+int ag_grufront_bwd_persist(const float* ga, const float* hs, const float* gh, const float* x, int64_t ldx,
+                            const float* dh_ext, const float* dx_ext, int64_t lddx, const float* w_hh, const float* w_x,
+                            int ldwx, const float* w_p, float* dgi, float* dgh, float* dxt, void* ws, int64_t ws_bytes, int T,
+                            int B, int S, int fs, int n_cu, void* stream);
 
 /* The same frame loop with a GRU cell (BASELINE configs[3]: the audiogan.py Generator with the LSTMCell of :380-386 replaced
  * by a GRU cell, gate order r z n as torch.nn.GRUCell) as ONE persistent launch.  gates [T,B,3S]: in = W_ih[:, fs:] zc_t +
@@ -370,8 +406,8 @@ int ag_grufront_bwd_persist(const float* ga, const float* hs, const float* gh, c
  * ag_gru_cell_bwd reads); w_x = W_ih[:, :fs] (row pitch ldwx), w_hh [3S,S], b_hn [S] = b_hh[2S:], w_p [fs,S], b_p [fs];
  * outputs hs [T,B,S] and the frames x [B,T*fs].  Shapes and workspace as for ag_gfront_fwd_persist. */
 int ag_grufront_fwd_persist(float* gates, float* gh, const float* w_x, int ldwx, const float* w_hh, const float* b_hn,
-                            const float* w_p, const float* b_p, float* hs, float* x, void* ws, int64_t ws_bytes, int T,
-                            int B, int S, int fs, int n_cu, void* stream);
+                            const float* w_p, const float* b_p, float* hs, float* x, int64_t ldx, float* xt, void* ws,
+                            int64_t ws_bytes, int T, int B, int S, int fs, int n_cu, void* stream);
 
 /* One fused backward step of the Generator front (audiogan.py:428-460: LSTMCell -> tanh(Linear) fed back), frame t:
  *   gx     = dxa * (1 - x_t^2)                        d(pre-tanh) of the projection, stored to gx_out [B,Kp]
@@ -456,12 +492,19 @@ typedef struct ag_opt_desc {
 
 /* step_dev (optional): device-side optimiser step counter, incremented by ag_grad_norms and
  * read by ag_opt_step for Adam's bias correction, so a captured hipGraph of the train step
- * advances it on every replay.  When NULL the host value `step` is used. */
+ * advances it on every replay.  When NULL the host value `step` is used.
+ * ag_grad_norms needs a bound workspace of 2 * n * 256 floats (ag_bind_workspace): per-chunk sums of squares and flag
+ * words, every slot written by its workgroup (nothing is zeroed in front of the launch, `flags` is WRITTEN).  finish = 1:
+ * a second, one-workgroup launch turns the partials into norms / norm_sum / flags.  finish = 0 (round 4): that launch is
+ * left out and the caller hands the same workspace to ag_opt_step as `part`: every workgroup of the update then sums its
+ * tensor's 256 partials itself (same order, same value) and workgroup (0,0) writes norms_out / norm_sum / flags - two
+ * launches per network and step instead of three plus two memset nodes.  part = NULL: `norms` as computed before. */
 int ag_grad_norms(const ag_opt_desc* descs_dev, int n, float* norms, float* norm_sum,
-                  int32_t* flags, float grad_scale, int32_t* step_dev, void* stream);
+                  int32_t* flags, float grad_scale, int32_t* step_dev, int finish, void* stream);
 int ag_opt_step(const ag_opt_desc* descs_dev, int n, const float* norms, int kind, float lr,
                 float clip, float grad_scale, float alpha_or_beta1, float beta2, float eps, int step,
-                const int32_t* step_dev, void* stream);
+                const int32_t* step_dev, const float* part, float* norms_out, float* norm_sum, int32_t* flags,
+                void* stream);
 
 /* ---- Conv2DLSTMCell (reference cells.py:4-103: convolutional LSTM with peepholes and TF layer normalisation) ----------
  * Pointwise / normalisation pieces (csrc/convlstm.hip); the convolution runs on ag_conv1d_engine, one launch per kernel row.

@@ -144,8 +144,11 @@ def conv_wgrad(sh, lg, dw, K, stride, pad):
     dw.add_(acc.view(dw.shape))
 
 
-def channel_sum(dy, db):
-    db.add_(dy.sum((0, 2)))
+def channel_sum(dy, db, accumulate=True):
+    if accumulate:
+        db.add_(dy.sum((0, 2)))
+    else:
+        db.copy_(dy.sum((0, 2)))
 
 
 def lstm_front_bwd_ok(B, H, fs, dxa_t, x_t):
@@ -172,7 +175,7 @@ def leaky_bwd(dy, y, dpre, lens=None, slope=LEAKY_SLOPE, add_into=None, bias_gra
 
 
 def gemm(A, B, Cm, ta=False, tb=False, alpha=1.0, beta=0.0, bias=None, res=None, act=ACT_NONE,
-         slope=LEAKY_SLOPE):
+         slope=LEAKY_SLOPE, defer=False):
     a = A.t() if ta else A
     b = B.t() if tb else B
     out = alpha * (a @ b)
@@ -187,8 +190,11 @@ def gemm(A, B, Cm, ta=False, tb=False, alpha=1.0, beta=0.0, bias=None, res=None,
     Cm.copy_(_act(out, act if act != ACT_LEAKY_GATE else ACT_NONE, slope))
 
 
-def col_sum(X, out):
-    out.add_(X.sum(0))
+def col_sum(X, out, accumulate=True, defer=True):
+    if accumulate:
+        out.add_(X.sum(0))
+    else:
+        out.copy_(X.sum(0))
 
 
 def lstm_cell_fwd(gates, c_prev, c_out, h_out=None, y_out=None, h_prev=None, valid=None, t=0):
@@ -295,7 +301,8 @@ def axpby(x, y, a, b):
     y.copy_(a * x + (b * y if b != 0.0 else 0.0))
 
 
-def grad_norms(params, grads, s1, s2, norms, norm_sum, flags, grad_scale=1.0, step_dev=None):
+def grad_norms(params, grads, s1, s2, norms, norm_sum, flags, grad_scale=1.0, step_dev=None, finish=True):
+    """(the model always finishes the norms; ``opt_step(part=...)`` then finds them in place)"""
     if step_dev is not None:
         step_dev.add_(1)
     f = 0
@@ -313,9 +320,11 @@ def grad_norms(params, grads, s1, s2, norms, norm_sum, flags, grad_scale=1.0, st
         norm_sum.fill_(float(tot))
     if flags is not None:
         flags.fill_(f)
+    return None if finish else norms
 
 
-def opt_step(params, grads, s1, s2, norms, kind, lr, clip, grad_scale, a1, b2, eps, step, step_dev=None):
+def opt_step(params, grads, s1, s2, norms, kind, lr, clip, grad_scale, a1, b2, eps, step, step_dev=None, part=None,
+             norm_sum=None, flags=None):
     if step_dev is not None:
         step = int(step_dev.item())
     for i, p in enumerate(params):
@@ -378,11 +387,77 @@ def tbc_to_bct(x, out=None):
 class deferred_reduces(object):
     """(no second stages in the model)"""
 
+    def __init__(self, outer=False):
+        self.role = 'owner'
+
     def __enter__(self):
         return self
 
     def __exit__(self, *exc):
         return False
+
+
+def reduces_outer():
+    return False
+
+
+def reduces_recording():
+    return False
+
+
+def flush_reduces():
+    pass
+
+
+def rowdot_ok(x, w):
+    return x.dim() == 2 and x.stride(1) == 1 and w.numel() == x.size(1) and w.is_contiguous()
+
+
+def rowdot_fwd(x, w, bias, y):
+    r = x @ w.reshape(-1)
+    if bias is not None:
+        r = r + bias.reshape(-1)[0]
+    y.copy_(r.view(y.shape))
+
+
+def rowdot_bwd(dy, x, w, dx=None, dw=None, db=None, gate=False, slope=LEAKY_SLOPE, accumulate=True):
+    g = dy.reshape(-1, 1)
+    if dx is not None:
+        r = g * w.reshape(1, -1)
+        if gate:
+            r = r * torch.where(x > 0, torch.ones_like(x), torch.full_like(x, slope))
+        dx.copy_(r)
+    if dw is not None:
+        gw, gb = (g * x).sum(0).view(dw.shape), g.sum().view(db.shape)
+        if accumulate:
+            dw.add_(gw); db.add_(gb)
+        else:
+            dw.copy_(gw); db.copy_(gb)
+
+
+def build_zc(z, c, out=None):
+    B, T, ns = z.shape
+    r = torch.cat([z, c.unsqueeze(1).expand(B, T, c.size(1))], 2).transpose(0, 1).contiguous()
+    if out is not None:
+        out.copy_(r)
+        return out
+    return r
+
+
+def critic_batch(xa, na=None, xb=None, nb=None, len_a=None, len_b=None, prods=(), ca=None, cb=None):
+    rows = [xa + na if na is not None else xa.clone()]
+    L = xa.size(1)
+    lens = [len_a if len_a is not None else torch.full((xa.size(0),), L, dtype=torch.long)]
+    if xb is not None:
+        rows.append(xb + nb if nb is not None else xb.clone())
+        lens.append(len_b if len_b is not None else torch.full((xb.size(0),), L, dtype=torch.long))
+    x = torch.cat(rows, 0)
+    ln = torch.cat([l.long() for l in lens], 0)
+    tab = torch.stack([(ln + d - 1) // d for d in prods], 0) if len(prods) else None
+    c = None
+    if ca is not None:
+        c = torch.cat([ca, cb], 0) if xb is not None else ca.clone()
+    return x, tab, c
 
 
 def gfront_bwd_persist_ok(B, S, fs, dev):
@@ -445,7 +520,7 @@ def lstm_seq_fwd(pre, whh, c_all, hbuf, y, valid, static=None):
                           y_out=y[t, :, d * H:(d + 1) * H], h_prev=hp, valid=valid, t=t)
 
 
-def lstm_seq_bwd(gates, whh, c_all, dy, dgates, dhbuf, dcbuf, valid):
+def lstm_seq_bwd(gates, whh, c_all, dy, dgates, dhbuf, dcbuf, valid, dgsum=None):
     ndir = len(gates)
     T, B, H4 = gates[0].shape
     H = H4 // 4
@@ -459,6 +534,7 @@ def lstm_seq_bwd(gates, whh, c_all, dy, dgates, dhbuf, dcbuf, valid):
                           dgates[d][t], dcbuf[d][k & 1], dh_pass=dpass, valid=valid, t=t)
             if k > 0:
                 dpass.add_(dgates[d][t] @ whh[d])
+    return False        # (dgsum is left to the caller, like the per-step kernels do)
 
 
 def gru_cell_fwd(gi, gh, h_prev, h_out):

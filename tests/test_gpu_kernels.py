@@ -455,13 +455,23 @@ def test_fused_optimizer_vs_torch(K, kind):
             p.grad, q.grad = g.clone(), g.clone().cuda()
         tot = O.clip_grad(ps_ref, 1.0)
         oref.step()
-        ns = o.step(clip_norm=1.0, check=True)
+        # check=True: the norms are finished by a launch of their own (the flags are read before the update); check=False:
+        # the update launch finishes them itself (two launches per network) - the same numbers either way
+        ns = o.step(clip_norm=1.0, check=(it != 1))
         close(ns, float(tot), rtol=1e-5)
+        assert int(o.last_flags.item()) == 0
         for p, q in zip(ps_ref, ps):
             close(q, p, rtol=1e-5, atol=2e-6)   # lr=1e-3 steps: a 1-ulp difference in g/sqrt(v)
     ps[0].grad[0, 0, 0] = float('nan')
+    o.step(clip_norm=1.0, check=False)
+    assert int(o.last_flags.item()) & 1, 'the fused form must still report NaN gradients'
+    ps[0].grad.zero_()
+    ps[1].grad[5, 5] = 3e5
+    o2 = optim.make_optimizer([torch.nn.Parameter(p.detach().clone()) for p in ps], kind, 1e-3)
+    for q, p in zip(o2.params, ps):
+        q.grad = p.grad.clone()
     with pytest.raises(AssertionError):
-        o.step(clip_norm=1.0, check=True)
+        o2.step(clip_norm=1.0, check=True)
 
 
 def test_error_convention(K):
@@ -679,22 +689,35 @@ def test_gfront_persistent_launch(K, S, fs, B, T):
     gx, gs = torch.randn(B, T * fs, generator=gen).cuda(), torch.randn(B, T, generator=gen).cuda()
     outs = []
     old = K.PERSIST[0]
+    gx_wide = torch.zeros(B, 3, T * fs).cuda()
+    gx_wide[:, 0] = gx
     try:
-        for persist in (False, True):
+        # third pass: the frames written straight into channel 0 of a [B, 3, T*fs] slab (what the Generator does) and the
+        # output gradient handed back as a row-pitched view - the persistent launches read / write both in place
+        for persist, ctot in ((False, 0), (True, 0), (True, 3)):
             K.PERSIST[0] = persist
+            front.slab_channels = ctot
             for q in params:
                 q.grad = None
             x, s = ops.GFrontFn.apply(zc, front, *front.group.params())
-            ((x * gx).sum() + (s * gs).sum()).backward()
+            assert x.stride(0) == (ctot if ctot else 1) * T * fs
+            if ctot:
+                x.backward(gx_wide[:, 0], retain_graph=True)
+                (s * gs).sum().backward()
+            else:
+                ((x * gx).sum() + (s * gs).sum()).backward()
             torch.cuda.synchronize()
             assert K.lstm_persist_status() == 0
             outs.append((x.detach().clone(), s.detach().clone(), [q.grad.clone() for q in params]))
     finally:
         K.PERSIST[0] = old
-    close(outs[1][0], outs[0][0], rtol=1e-4, atol=1e-6)
-    close(outs[1][1], outs[0][1], rtol=1e-4, atol=1e-5)
-    for a, b in zip(outs[1][2], outs[0][2]):
-        close(a, b, rtol=1e-3, atol=1e-5 * max(1.0, float(b.abs().max())))
+        front.slab_channels = 0
+    for k in (1, 2):
+        close(outs[k][0], outs[0][0], rtol=1e-4, atol=1e-6)
+        close(outs[k][1], outs[0][1], rtol=1e-4, atol=1e-5)
+        for a, b in zip(outs[k][2], outs[0][2]):
+            close(a, b, rtol=1e-3, atol=1e-5 * max(1.0, float(b.abs().max())))
+    assert torch.equal(outs[2][0], outs[1][0])
 
 
 def test_persistent_launch_timeout_surfaces(K):
@@ -750,16 +773,17 @@ def test_front_backward_timeout_surfaces(K, cell):
         gates[:, :, 2 * S:3 * S] = torch.tanh(r(T, B, S))
     else:
         gates[:, :, 2 * S:] = torch.tanh(r(T, B, S))
-    state, gh, x, dacc = r(T + 1, B, S) * 0.5, r(T, B, ng * S) * 0.5, torch.tanh(r(B, T * fs)), r(T, B, S + fs) * 0.1
+    state, gh, x = r(T + 1, B, S) * 0.5, r(T, B, ng * S) * 0.5, torch.tanh(r(B, T * fs))
+    dh_ext, dx_ext = r(T, B, S) * 0.1, r(B, T * fs) * 0.1
     whh, wih, wp = r(ng * S, S) * 0.1, r(ng * S, fs + 8) * 0.1, r(fs, S) * 0.1
     wx = wih[:, :fs]
 
     def run():
         dgs, dgh, dxt = torch.empty(T, B, ng * S).cuda(), torch.empty(T, B, ng * S).cuda(), torch.empty(T, B, fs).cuda()
         if cell == 'lstm':
-            K.gfront_bwd_persist(gates, state, x, dacc, whh, wx, wp, dgs, dxt)
+            K.gfront_bwd_persist(gates, state, x, dh_ext, dx_ext, whh, wx, wp, dgs, dxt)
         else:
-            K.grufront_bwd_persist(gates, state, gh, x, dacc, whh, wx, wp, dgs, dgh, dxt)
+            K.grufront_bwd_persist(gates, state, gh, x, dh_ext, dx_ext, whh, wx, wp, dgs, dgh, dxt)
         torch.cuda.synchronize()
         return dgs, dxt
 
@@ -876,3 +900,68 @@ def test_single_input_channel_conv_kernels(K, k, s, p, cout, lin, B):
     close(dw, wr.grad, rtol=1e-4, atol=1e-4 * float(wr.grad.abs().max()), msg='bwd-weight')
     for a, b, n in zip(res['1'], res['0'], ('fwd', 'bwd-data', 'bwd-data acc', 'bwd-weight')):
         close(a, b, rtol=1e-4, atol=1e-4 * max(1.0, float(b.abs().max())), msg='vs engine: ' + n)
+
+
+def test_input_assembly_kernels(K):
+    """ag_build_zc / ag_critic_batch (one launch each) against the torch expressions they replace (audiogan.py:433-439,
+    :724-728, :749-751, :533, :844), incl. row-pitched inputs, missing noise / lengths and the one-network form"""
+    gen = torch.Generator().manual_seed(61)
+    B, T, ns, es, L = 5, 7, 6, 3, 1000
+    z, c = torch.randn(B, T, ns, generator=gen).cuda(), torch.randn(B, es, generator=gen).cuda()
+    ref = torch.cat([z, c.unsqueeze(1).expand(B, T, es)], 2).transpose(0, 1).contiguous()
+    assert torch.equal(K.build_zc(z, c), ref)
+    wide = torch.randn(B, 3, L, generator=gen).cuda()
+    real, nr = wide[:, 1], torch.randn(B, L, generator=gen).cuda() * 0.01          # a row-pitched view
+    fake, nf = torch.randn(4, L, generator=gen).cuda(), torch.randn(4, L, generator=gen).cuda() * 0.01
+    la, lb = torch.tensor([1000, 3, 999, 512, 1]).cuda(), torch.tensor([1000, 1000, 77, 640]).cuda()
+    cb = torch.randn(4, es, generator=gen).cuda()
+    prods = [2, 4, 8, 16, 32, 64]
+    x, lens, c2 = K.critic_batch(real, nr, fake, nf, la, lb, prods, c, cb)
+    assert torch.equal(x, torch.cat([real + nr, fake + nf], 0))
+    ln = torch.cat([la, lb])
+    assert torch.equal(lens, torch.stack([(ln + p - 1) // p for p in prods]))
+    assert torch.equal(c2, torch.cat([c, cb], 0))
+    x, lens, c2 = K.critic_batch(fake, None, None, None, None, None, prods[:3])
+    assert torch.equal(x, fake) and c2 is None
+    assert torch.equal(lens, torch.stack([torch.full((4,), (L + p - 1) // p, dtype=torch.long) for p in prods[:3]]).cuda())
+    odd = torch.randn(3, 1001, generator=gen).cuda()                                 # rows that are not 16-byte multiples
+    x, lens, _ = K.critic_batch(odd[:, 1:], odd[:, :1000])
+    assert torch.equal(x, odd[:, 1:] + odd[:, :1000]) and lens is None
+
+
+def test_deferred_split_k_weight_gradient_is_bitwise_the_same(K):
+    """a split-K weight-gradient product inside a deferral scope with defer=True hands its second stage to the scope's one
+    launch (nothing written before the flush); the result equals the stand-alone product bit for bit, also when it
+    accumulates (beta = 1); without defer=True, or with an epilogue, the product is complete at once inside the scope"""
+    gen = torch.Generator().manual_seed(62)
+    M, N, Kd = 512, 640, 8192
+    a, b = torch.randn(Kd, M, generator=gen).cuda(), torch.randn(Kd, N, generator=gen).cuda()
+    assert K.lib.ag_gemm_ws_numel(M, N, Kd, 0) > 0, 'shape must take the split-K path'
+    base = torch.randn(M, N, generator=gen).cuda()
+    ref0, ref1 = torch.empty(M, N).cuda(), base.clone()
+    K.gemm(a, b, ref0, ta=True)
+    K.gemm(a, b, ref1, ta=True, beta=1.0)
+    got0, got1, now = torch.zeros(M, N).cuda(), base.clone(), torch.zeros(M, N).cuda()
+    with K.deferred_reduces():
+        K.gemm(a, b, got0, ta=True, defer=True)
+        K.gemm(a, b, got1, ta=True, beta=1.0, defer=True)
+        K.gemm(a, b, now, ta=True)
+        torch.cuda.synchronize()
+        assert not bool(got0.any()) and torch.equal(got1, base), 'deferred second stages ran before the flush'
+        assert torch.equal(now, ref0), 'a product without defer=True must be complete inside the scope'
+    torch.cuda.synchronize()
+    assert torch.equal(got0, ref0) and torch.equal(got1, ref1)
+    close(ref0, a.t().double().cpu() @ b.double().cpu(), rtol=1e-4, atol=1e-2)
+
+
+def test_no_float_atomic_path_is_left(K):
+    """round 4: a cross-workgroup sum without a bound workspace is an error, not an order-dependent float-atomic sum"""
+    import ctypes as C
+    x = torch.randn(4, 64, 4096).cuda()
+    db = torch.zeros(64).cuda()
+    K.lib.ag_bind_workspace(None, 0)
+    rc = K.lib.ag_channel_sum(C.c_void_p(x.data_ptr()), x.stride(0), x.stride(1), C.c_void_p(db.data_ptr()), 4, 64, 4096, 1,
+                              C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == -1 and b'workspace' in K.lib.ag_last_error()
+    K.channel_sum(x, db)
+    close(db, x.double().sum((0, 2)).cpu(), rtol=1e-5, atol=1e-3)

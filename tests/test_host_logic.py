@@ -324,7 +324,7 @@ def test_g_backward_late_is_per_frame_unless_the_caller_opts_in():
             seen.append(K.PERSIST_FRONT_BWD[0])
 
     class _Cut(object):
-        grad = None
+        grad = torch.zeros(1)
 
     keep = dict(x=_X(), x_cut=_Cut())
     train.g_backward_late(keep)
