@@ -44,7 +44,7 @@ SIGNATURES = {
     'ag_abi_version': (C.c_int, []),
     'ag_bce_logits_fwd_strided': (C.c_int, [vp, i64, i64, C.c_float, vp, vp, vp, vp, C.c_float, C.c_int, C.c_int, vp]),
     'ag_bce_logits_bwd_strided': (C.c_int, [vp, i64, i64, C.c_float, vp, vp, vp, C.c_float, vp, i64, i64, C.c_int, C.c_int, vp]),
-    'ag_transpose_batched': (C.c_int, [vp, i64, i64, vp, i64, i64, C.c_int, C.c_int, C.c_int, vp]),
+    'ag_transpose_batched': (C.c_int, [vp, C.c_int, i64, i64, vp, C.c_int, i64, i64, C.c_int, C.c_int, C.c_int, vp]),
     'ag_defer_reduces': (C.c_int, [C.c_int]),
     'ag_flush_reduces': (C.c_int, [vp]),
     'ag_arch': (C.c_char_p, []),
@@ -68,7 +68,7 @@ SIGNATURES = {
                                C.c_int, C.c_int, f32, vp]),
     'ag_gemm': (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp, C.c_int, C.c_int,
                           C.c_int, C.c_int, f32, f32, vp, vp, C.c_int, C.c_int, f32, vp]),
-    'ag_col_sum': (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp]),
+    'ag_col_sum': (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp]),
     'ag_lstm_cell_fwd': (C.c_int, [vp, C.c_int, vp, C.c_int, vp, C.c_int, vp, C.c_int, vp, C.c_int,
                                    vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp]),
     'ag_lstm_cell_bwd': (C.c_int, [vp, C.c_int, vp, C.c_int, vp, C.c_int, vp, C.c_int, vp, C.c_int,
@@ -91,12 +91,17 @@ SIGNATURES = {
     'ag_persist_debug': (C.c_int, [i64, C.c_int]),
     'ag_lstm_persist_ok': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     'ag_lstm_persist_ws_bytes': (i64, [C.c_int, C.c_int, C.c_int]),
-    'ag_lstm_seq_fwd_persist': (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    'ag_lstm_seq_fwd_persist': (C.c_int, [vp, vp, vp, vp, C.c_int, vp, vp, vp, i64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     'ag_lstm_persist_bwd_ok': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
-    'ag_lstm_seq_bwd_persist': (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, i64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
-    'ag_rowdot_fwd': (C.c_int, [vp, C.c_int, vp, vp, vp, i64, C.c_int, C.c_int, vp]),
+    'ag_lstm_seq_bwd_persist': (C.c_int, [vp, vp, vp, vp, C.c_int, vp, vp, vp, C.c_int, vp, vp, i64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    'ag_rowdot_fwd': (C.c_int, [vp, C.c_int, C.c_int, vp, vp, vp, i64, C.c_int, C.c_int, vp]),
     'ag_rowdot_bwd_ws_numel': (i64, [C.c_int, C.c_int]),
-    'ag_rowdot_bwd': (C.c_int, [vp, i64, vp, C.c_int, vp, vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, f32, vp]),
+    'ag_rowdot_bwd': (C.c_int, [vp, i64, vp, C.c_int, vp, vp, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, f32, vp]),
+    'ag_gemm_h_ok': (C.c_int, [C.c_int] * 7),
+    'ag_gemm_h_ws_numel': (i64, [C.c_int] * 5),
+    'ag_gemm_h': (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, f32, f32, vp,
+                            vp, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int, f32, vp]),
+    'ag_to_bf16_2d': (C.c_int, [vp, i64, vp, i64, C.c_int, C.c_int, vp]),
     'ag_gfront_persist_ok': (C.c_int, [C.c_int] * 4),
     'ag_gfront_persist_ws_bytes': (i64, [C.c_int] * 3),
     'ag_gfront_bwd_persist_ok': (C.c_int, [C.c_int] * 4),
@@ -141,7 +146,7 @@ def _load():
     return lib
 
 
-ABI_VERSION = 9      # what this package was written against (csrc/api.hip: ag_abi_version)
+ABI_VERSION = 10      # what this package was written against (csrc/api.hip: ag_abi_version)
 
 lib = _load()
 if lib.ag_abi_version() != ABI_VERSION:

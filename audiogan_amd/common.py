@@ -118,6 +118,29 @@ class network_backward(object):
         return False
 
 
+class Bf16Images(object):
+    """bfloat16 images of fp32 tensors (weights, or column blocks of them), made by ONE small launch each and cached until
+    the source changes: what ag_gemm_h reads on the bf16-storage path.  The key follows WNGroup's: parameter pointer /
+    version / epoch, and the capture tag - inside a hipGraph capture the first use re-converts, so a replayed graph never
+    reads an image that was filled outside it."""
+
+    def __init__(self):
+        self._img = {}
+
+    def get(self, name, src, owner=None):
+        """``src``: a 2-D fp32 tensor (any row pitch) or contiguous; ``owner``: the Parameter whose version identifies its
+        content (default: src itself)"""
+        o = owner if owner is not None else src
+        key = (capture_tag(src.device), o.data_ptr(), o._version, param_epoch(o), src.data_ptr(), tuple(src.shape))
+        hit = self._img.get(name)
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        buf = hit[1] if (hit is not None and hit[1].shape == src.shape and hit[1].device == src.device) else None
+        img = K.to_bf16(src, out=buf)
+        self._img[name] = (key, img)
+        return img
+
+
 class Prepared(object):
     __slots__ = ('w', 'wpa', 'wpb', 'pad')
 
@@ -174,8 +197,28 @@ class WNGroup(object):
         key = self._current_key()
         if key != self._key:
             K.weight_norm_fwd(self._entries())
-            self._key = key
+            self._mark_fresh(key)
         return self._bufs
+
+    def _mark_fresh(self, key):
+        """the materialised weights were just rewritten: their bf16 images are stale"""
+        self._key = key
+        self._w16 = {}
+
+    def w16(self, i):
+        """bfloat16 image of the materialised weight of item i (made on first use after every materialisation; inside a
+        hipGraph capture that first use lies inside the graph, like the materialisation itself)"""
+        d = getattr(self, '_w16', None)
+        if d is None:
+            d = self._w16 = {}
+        img = d.get(i)
+        if img is None:
+            keep = getattr(self, '_w16_buf', None)
+            if keep is None:
+                keep = self._w16_buf = {}
+            img = d[i] = K.to_bf16(self._bufs[i].w, out=keep.get(i))       # (stable address: the buffer is reused)
+            keep[i] = img
+        return img
 
     def zero_dws(self):
         """zero-filled scratch for the gradients wrt the materialised weights, one tensor per item (views of ONE
@@ -248,7 +291,7 @@ def prepare_groups(groups):
             return
         K.weight_norm_fwd(ents)
         for gr, key in stale:
-            gr._key = key
+            gr._mark_fresh(key)
 
 
 def _zeros_like_list(tensors):

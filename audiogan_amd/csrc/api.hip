@@ -15,9 +15,10 @@ void ag_set_error(const char* fmt, ...) {
 
 // bumped whenever an entry point, a struct layout or the meaning of an argument changes (round 3: sticky persistent status,
 // AG_ACT_LEAKY_GATE, AG_PREC_F32X3, GRU front, Conv2DLSTMCell pieces; round 4: v9 - pitched x / split external gradients of
-// the front's persistent launches, process-wide deferral with pause / resume, ag_build_zc, ag_critic_batch): audiogan_amd/_lib.py refuses a library of another
+// the front's persistent launches, process-wide deferral with pause / resume, ag_build_zc, ag_critic_batch; v10 - bf16 storage: ag_gemm_h, bf16 in / out flags of the transposes, rowdot, col_sum and the
+// persistent LSTM launches): audiogan_amd/_lib.py refuses a library of another
 // version, so Python that relies on a new mode can never drive an older build
-extern "C" int ag_abi_version(void) { return 9; }
+extern "C" int ag_abi_version(void) { return 10; }
 extern "C" const char* ag_arch(void) { return "gfx950"; }
 extern "C" const char* ag_last_error(void) { return g_err; }
 

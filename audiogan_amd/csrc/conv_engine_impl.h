@@ -784,7 +784,7 @@ __global__ __launch_bounds__(512) void conv_engine_bf16_kernel(const ConvP p) {
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
-static int ilog2_exact(int v) {
+static inline int ilog2_exact(int v) {
   for (int s = 0; s < 31; ++s)
     if ((1 << s) == v) return s;
   return -1;

@@ -876,15 +876,21 @@ extern "C" int64_t ag_gemm_ws_numel(int M, int N, int K, int act) {
 // out[n] (+)= sum_m X[m, n]
 __global__ __launch_bounds__(256) void col_sum_kernel(const float* __restrict__ X, int ldx,
                                                       float* __restrict__ out, int M, int N,
-                                                      int rows_per, float* __restrict__ part, int accumulate) {
+                                                      int rows_per, float* __restrict__ part, int accumulate, int x16) {
   const int n = blockIdx.x * 64 + (threadIdx.x & 63);
   const int sub = threadIdx.x >> 6;  // 4 row-phases per block
   const int mbeg = blockIdx.y * rows_per;
   int mend = mbeg + rows_per;
   if (mend > M) mend = M;
   float s = 0.f;
-  if (n < N)
-    for (int m = mbeg + sub; m < mend; m += 4) s += X[(int64_t)m * ldx + n];
+  if (n < N) {
+    if (x16) {        // X stored as bfloat16 (ldx in 2-byte elements)
+      const unsigned short* X16 = reinterpret_cast<const unsigned short*>(X);
+      for (int m = mbeg + sub; m < mend; m += 4) s += __uint_as_float((unsigned)X16[(int64_t)m * ldx + n] << 16);
+    } else {
+      for (int m = mbeg + sub; m < mend; m += 4) s += X[(int64_t)m * ldx + n];
+    }
+  }
   __shared__ float red[4][64];
   red[sub][threadIdx.x & 63] = s;
   __syncthreads();
@@ -895,7 +901,7 @@ __global__ __launch_bounds__(256) void col_sum_kernel(const float* __restrict__ 
   }
 }
 
-extern "C" int ag_col_sum(const float* X, int ldx, float* out, int M, int N, int accumulate, void* stream) {
+extern "C" int ag_col_sum(const void* X, int x_bf16, int ldx, float* out, int M, int N, int accumulate, void* stream) {
   const AgWs ws = ag_ws_take();     // FIRST: an argument error below must not leave a stale binding behind
   AG_REQUIRE(X && out && M > 0 && N > 0 && ldx >= N, "ag_col_sum: bad args");
   const int gx = ag_cdiv(N, 64);
@@ -912,8 +918,8 @@ extern "C" int ag_col_sum(const float* X, int ldx, float* out, int M, int N, int
   const int rows_per = ag_cdiv(M, gy);
   gy = ag_cdiv(M, rows_per);
   if (gy == 1) part = nullptr;
-  hipLaunchKernelGGL(col_sum_kernel, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, X, ldx, out, M,
-                     N, rows_per, part, accumulate);
+  hipLaunchKernelGGL(col_sum_kernel, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (const float*)X, ldx, out, M,
+                     N, rows_per, part, accumulate, x_bf16 ? 1 : 0);
   AG_CHECK_LAUNCH("ag_col_sum");
   if (part) return ag_slab_reduce(part, gy, N, out, accumulate ? 1 : 0, (hipStream_t)stream);
   return AG_OK;

@@ -78,7 +78,8 @@ struct PersistDir {
 
 struct PersistFwdP {
   PersistDir d[2];
-  float* y;            // [T,B,ndir*H]
+  float* y;            // [T,B,ndir*H]  (y16 != 0: the same tensor as bfloat16 - the pointer then addresses 2-byte elements)
+  int y16;
   const int64_t* valid;
   float* xbuf;         // exchange buffer
   PersistCtl ctl;
@@ -303,7 +304,9 @@ __global__ __launch_bounds__(512) void lstm_persist_fwd_kernel(const PersistFwdP
       }
       if (k == 0) D.c_all[(int64_t)em * H + eu] = 0.f;         // c_0 = 0: written here, so the caller need not fill it
       D.c_all[((int64_t)(k + 1) * B + em) * H + eu] = creg;
-      p.y[((int64_t)t * B + em) * p.ndir * H + (int64_t)dir * H + eu] = sv_y;
+      const int64_t yi = ((int64_t)t * B + em) * p.ndir * H + (int64_t)dir * H + eu;
+      if (p.y16) reinterpret_cast<unsigned short*>(p.y)[yi] = (unsigned short)(ag_pack_bf16(sv_y, sv_y) & 0xFFFFu);
+      else p.y[yi] = sv_y;
     }
   }
 }
@@ -337,7 +340,7 @@ extern "C" int64_t ag_lstm_persist_ws_bytes(int B, int H, int ndir) {
 // Whole (bi)directional layer forward in ONE launch.  Same tensors as ag_lstm_seq_fwd (lstm_step.hip) minus the
 // hidden-state scratch; `ws` = ag_lstm_persist_ws_bytes() bytes of device memory, 16-byte aligned, used by no other
 // launch in flight.  `n_cu`: compute units of the device (the grid must be co-resident).
-extern "C" int ag_lstm_seq_fwd_persist(float* const* pre, const float* const* whh, float* const* c_all, float* y,
+extern "C" int ag_lstm_seq_fwd_persist(float* const* pre, const float* const* whh, float* const* c_all, void* y, int y_bf16,
                                        const int64_t* valid_i64, const float* const* static_pre, void* ws,
                                        int64_t ws_bytes, int T, int B, int H, int ndir, int n_cu, void* stream) {
   AG_REQUIRE(pre && whh && c_all && y && ws, "ag_lstm_seq_fwd_persist: null tensor");
@@ -362,7 +365,7 @@ extern "C" int ag_lstm_seq_fwd_persist(float* const* pre, const float* const* wh
     p.d[d].pre = pre[s]; p.d[d].whh = whh[s]; p.d[d].c_all = c_all[s];
     p.d[d].cb = static_pre ? static_pre[s] : nullptr;
   }
-  p.y = y; p.valid = valid_i64;
+  p.y = (float*)y; p.y16 = y_bf16 ? 1 : 0; p.valid = valid_i64;
   p.ctl = ps_ctl(ws);
   p.xbuf = (float*)((char*)ws + PS_STICKY_BYTES + PS_HDR_BYTES);
   p.T = T; p.B = B; p.H = H; p.ndir = ndir; p.nbt = nbt; p.ntile = H / 8;
@@ -404,11 +407,14 @@ struct PersistBwdDir {
   const float* c_all;   // [T+1,B,H]
   float* dgates;        // [T,B,4H] out (and exchange)
   float* dgsum;         // optional [B,4H] out: sum over time of dgates (what the biases and a time-invariant input see)
+  unsigned short* dg16; // optional [T,B,4H] out (row pitch dg16_ld): dgates as bfloat16, the operand of the gradient products
 };
 
 struct PersistBwdP {
   PersistBwdDir d[2];
-  const float* dy;      // [T,B,ndir*H]
+  const float* dy;      // [T,B,ndir*H]  (dy16 != 0: stored as bfloat16, the pointer addresses 2-byte elements)
+  int dy16;
+  int dg16_ld;          // row pitch of dg16 in elements (>= 4H: both directions may share one [T,B,ndir*4H] tensor)
   const int64_t* valid;
   PersistCtl ctl;
   int T, B, H, ndir;
@@ -485,7 +491,8 @@ __global__ __launch_bounds__(512) void lstm_persist_bwd_kernel(const PersistBwdP
       ig = gr[0]; fg = gr[H]; gg = gr[2 * H]; og = gr[3 * H];
       cp = D.c_all[(int64_t)k * BH + (int64_t)em * H + eu];
       cn = D.c_all[(int64_t)(k + 1) * BH + (int64_t)em * H + eu];
-      dyv = p.dy[((int64_t)t * B + em) * p.ndir * H + (int64_t)dir * H + eu];
+      const int64_t yi = ((int64_t)t * B + em) * p.ndir * H + (int64_t)dir * H + eu;
+      dyv = p.dy16 ? __uint_as_float((unsigned)reinterpret_cast<const unsigned short*>(p.dy)[yi] << 16) : p.dy[yi];
     }
     f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
     if (k < T - 1) {
@@ -559,6 +566,11 @@ __global__ __launch_bounds__(512) void lstm_persist_bwd_kernel(const PersistBwdP
       }
       if (s_dead) { d0 = d1 = d2 = d3 = dcn = __builtin_nanf(""); }   // a wait timed out: poison instead of garbage
       sum0 += d0; sum1 += d1; sum2 += d2; sum3 += d3;
+      if (D.dg16) {
+        unsigned short* q16 = D.dg16 + ((int64_t)t * B + em) * p.dg16_ld + eu;
+        q16[0] = (unsigned short)(ag_pack_bf16(d0, d0) & 0xFFFFu); q16[H] = (unsigned short)(ag_pack_bf16(d1, d1) & 0xFFFFu);
+        q16[2 * H] = (unsigned short)(ag_pack_bf16(d2, d2) & 0xFFFFu); q16[3 * H] = (unsigned short)(ag_pack_bf16(d3, d3) & 0xFFFFu);
+      }
       __amdgpu_buffer_rsrc_t orr = __builtin_amdgcn_make_buffer_rsrc(D.dgates + (int64_t)t * BG, 0, (int)(BG * 4), 0x00020000);
       const unsigned o = (unsigned)(((int64_t)em * 4 * H + eu) * 4);
       __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(d0), orr, o, 0, 16);
@@ -593,8 +605,9 @@ extern "C" int ag_lstm_persist_bwd_ok(int B, int H, int ndir, int n_cu) {
 // Whole layer backward through time in ONE launch; tensors as for ag_lstm_seq_bwd (no scratch state: dc and the
 // pass-through term stay in registers).  `ws`: >= 8 KiB (status + flags), zeroed by a memset node in front.
 extern "C" int ag_lstm_seq_bwd_persist(const float* const* gates, const float* const* whh, const float* const* c_all,
-                                       const float* dy, float* const* dgates, float* const* dgsum, const int64_t* valid_i64,
-                                       void* ws, int64_t ws_bytes, int T, int B, int H, int ndir, int n_cu, void* stream) {
+                                       const void* dy, int dy_bf16, float* const* dgates, float* const* dgsum,
+                                       uint16_t* const* dg16, int dg16_ld, const int64_t* valid_i64, void* ws,
+                                       int64_t ws_bytes, int T, int B, int H, int ndir, int n_cu, void* stream) {
   AG_REQUIRE(gates && whh && c_all && dy && dgates && ws, "ag_lstm_seq_bwd_persist: null tensor");
   AG_REQUIRE(ndir == 1 || ndir == 2, "ag_lstm_seq_bwd_persist: ndir must be 1 or 2");
   AG_REQUIRE(T > 0, "ag_lstm_seq_bwd_persist: T must be positive");
@@ -614,8 +627,10 @@ extern "C" int ag_lstm_seq_bwd_persist(const float* const* gates, const float* c
     const int s = d < ndir ? d : 0;
     p.d[d].ga = gates[s]; p.d[d].whh = whh[s]; p.d[d].c_all = c_all[s]; p.d[d].dgates = dgates[s];
     p.d[d].dgsum = dgsum ? dgsum[s] : nullptr;
+    p.d[d].dg16 = dg16 ? dg16[s] : nullptr;
   }
-  p.dy = dy; p.valid = valid_i64; p.ctl = ps_ctl(ws);
+  AG_REQUIRE(!dg16 || dg16_ld >= 4 * H, "ag_lstm_seq_bwd_persist: dg16 row pitch smaller than a row");
+  p.dy = (const float*)dy; p.dy16 = dy_bf16 ? 1 : 0; p.dg16_ld = dg16_ld; p.valid = valid_i64; p.ctl = ps_ctl(ws);
   p.T = T; p.B = B; p.H = H; p.ndir = ndir; p.nbt = ag_cdiv(B, 16); p.ntile = H / 32;
   p.rb = ag_precision() == AG_PREC_BF16;
   const int grid = ndir * p.nbt * p.ntile;

@@ -750,34 +750,48 @@ extern "C" int ag_time_moments_bwd(const float* h, int64_t bs, int64_t cs, const
 //   in : element (b, i, j) at in  + b*ibs + i*irs + j        (i < R, j < Cc)
 //   out: element (b, j, i) at out + b*obs + j*ors + i
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void transpose_batched_kernel(const float* __restrict__ in, int64_t ibs, int64_t irs,
-                                                                float* __restrict__ out, int64_t obs, int64_t ors,
+// (IN16 / OUT16: that side is stored as bfloat16 - strides in elements of its own type; fp32 -> bf16 rounds to nearest even)
+template <bool IN16, bool OUT16>
+__global__ __launch_bounds__(256) void transpose_batched_kernel(const void* __restrict__ in, int64_t ibs, int64_t irs,
+                                                                void* __restrict__ out, int64_t obs, int64_t ors,
                                                                 int R, int Cc) {
   __shared__ float tile[32][33];
   const int b = blockIdx.z, i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
-  const float* src = in + (int64_t)b * ibs;
-  float* dst = out + (int64_t)b * obs;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int i = i0 + ty + 8 * k, j = j0 + tx;
-    tile[ty + 8 * k][tx] = (i < R && j < Cc) ? src[(int64_t)i * irs + j] : 0.f;
+    float v = 0.f;
+    if (i < R && j < Cc) {
+      const int64_t o = (int64_t)b * ibs + (int64_t)i * irs + j;
+      v = IN16 ? __uint_as_float((unsigned)reinterpret_cast<const unsigned short*>(in)[o] << 16) : reinterpret_cast<const float*>(in)[o];
+    }
+    tile[ty + 8 * k][tx] = v;
   }
   __syncthreads();
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int j = j0 + ty + 8 * k, i = i0 + tx;
-    if (j < Cc && i < R) dst[(int64_t)j * ors + i] = tile[tx][ty + 8 * k];
+    if (j < Cc && i < R) {
+      const int64_t o = (int64_t)b * obs + (int64_t)j * ors + i;
+      const float v = tile[tx][ty + 8 * k];
+      if (OUT16) reinterpret_cast<unsigned short*>(out)[o] = (unsigned short)(ag_pack_bf16(v, v) & 0xFFFFu);
+      else reinterpret_cast<float*>(out)[o] = v;
+    }
   }
 }
 
-extern "C" int ag_transpose_batched(const float* in, int64_t ibs, int64_t irs, float* out, int64_t obs, int64_t ors,
-                                    int B, int R, int Cc, void* stream) {
+extern "C" int ag_transpose_batched(const void* in, int in_bf16, int64_t ibs, int64_t irs, void* out, int out_bf16, int64_t obs,
+                                    int64_t ors, int B, int R, int Cc, void* stream) {
   AG_REQUIRE(in && out && B > 0 && R > 0 && Cc > 0 && B <= 65535, "ag_transpose_batched: bad args");
   AG_REQUIRE(irs >= Cc && ors >= R, "ag_transpose_batched: a row pitch is smaller than its row");
   AG_REQUIRE(ag_cdiv(R, 32) <= 65535, "ag_transpose_batched: too many rows");
-  hipLaunchKernelGGL(transpose_batched_kernel, dim3(ag_cdiv(Cc, 32), ag_cdiv(R, 32), B), dim3(256), 0, (hipStream_t)stream,
-                     in, ibs, irs, out, obs, ors, R, Cc);
+  const dim3 grid(ag_cdiv(Cc, 32), ag_cdiv(R, 32), B);
+  hipStream_t st = (hipStream_t)stream;
+  if (!in_bf16 && !out_bf16) hipLaunchKernelGGL((transpose_batched_kernel<false, false>), grid, dim3(256), 0, st, in, ibs, irs, out, obs, ors, R, Cc);
+  if (!in_bf16 && out_bf16) hipLaunchKernelGGL((transpose_batched_kernel<false, true>), grid, dim3(256), 0, st, in, ibs, irs, out, obs, ors, R, Cc);
+  if (in_bf16 && !out_bf16) hipLaunchKernelGGL((transpose_batched_kernel<true, false>), grid, dim3(256), 0, st, in, ibs, irs, out, obs, ors, R, Cc);
+  if (in_bf16 && out_bf16) hipLaunchKernelGGL((transpose_batched_kernel<true, true>), grid, dim3(256), 0, st, in, ibs, irs, out, obs, ors, R, Cc);
   AG_CHECK_LAUNCH("ag_transpose_batched");
   return AG_OK;
 }
@@ -892,12 +906,15 @@ extern "C" int ag_critic_batch(const float* xa, int64_t xa_ld, const float* na, 
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void rowdot_fwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w,
                                                          const float* __restrict__ bias, float* __restrict__ y, int64_t ldy,
-                                                         int M, int K, int rb) {
+                                                         int M, int K, int rb, int x16) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= M) return;
   const float* xr = x + (int64_t)row * ldx;
   float s = 0.f;
-  if ((K & 3) == 0 && (ldx & 3) == 0 && ((((uintptr_t)x | (uintptr_t)w) & 15) == 0)) {
+  if (x16) {          // x stored as bfloat16 (ldx in 2-byte elements); w rounded like every operand of a bf16 contraction
+    const unsigned short* xh = reinterpret_cast<const unsigned short*>(x) + (int64_t)row * ldx;
+    for (int k = lane; k < K; k += 64) s += __uint_as_float((unsigned)xh[k] << 16) * ag_rbf(w[k]);
+  } else if ((K & 3) == 0 && (ldx & 3) == 0 && ((((uintptr_t)x | (uintptr_t)w) & 15) == 0)) {
     for (int k = lane * 4; k < K; k += 256) {
       const f32x4 a = ag_rbf4_if(*reinterpret_cast<const f32x4*>(xr + k), rb), b = ag_rbf4_if(*reinterpret_cast<const f32x4*>(w + k), rb);
       s += a[0] * b[0]; s += a[1] * b[1]; s += a[2] * b[2]; s += a[3] * b[3];
@@ -912,7 +929,8 @@ __global__ __launch_bounds__(256) void rowdot_fwd_kernel(const float* __restrict
 #define RD_ROWS 64      // rows per workgroup of the backward kernel
 __global__ __launch_bounds__(256) void rowdot_bwd_kernel(const float* __restrict__ dy, int64_t lddy, const float* __restrict__ x,
                                                          int ldx, const float* __restrict__ w, float* __restrict__ dx, int lddx,
-                                                         float* __restrict__ part, int M, int K, int gate, float slope, int rb) {
+                                                         float* __restrict__ part, int M, int K, int gate, float slope, int rb,
+                                                         int h16) {
   // thread <-> column k (grid.y tiles K by 256), loop over the workgroup's RD_ROWS rows: coalesced rows of x / dx
   const int k = blockIdx.y * 256 + threadIdx.x;
   const int m0 = blockIdx.x * RD_ROWS, m1 = min(M, m0 + RD_ROWS);
@@ -922,8 +940,14 @@ __global__ __launch_bounds__(256) void rowdot_bwd_kernel(const float* __restrict
   for (int m = m0; m < m1; ++m) {
     const float g = ag_rbf_if(dy[(int64_t)m * lddy], rb);
     if (ok) {
-      const float xv = x[(int64_t)m * ldx + k];
-      if (dx) dx[(int64_t)m * lddx + k] = (gate && !(xv > 0.f)) ? g * wk * slope : g * wk;
+      // h16: x and dx are stored as bfloat16 (pitches in 2-byte elements)
+      const float xv = h16 ? __uint_as_float((unsigned)reinterpret_cast<const unsigned short*>(x)[(int64_t)m * ldx + k] << 16)
+                           : x[(int64_t)m * ldx + k];
+      const float dv = (gate && !(xv > 0.f)) ? g * wk * slope : g * wk;
+      if (dx) {
+        if (h16) reinterpret_cast<unsigned short*>(dx)[(int64_t)m * lddx + k] = (unsigned short)(ag_pack_bf16(dv, dv) & 0xFFFFu);
+        else dx[(int64_t)m * lddx + k] = dv;
+      }
       sw += g * ag_rbf_if(xv, rb);
     }
     sb += dy[(int64_t)m * lddy];
@@ -935,18 +959,18 @@ __global__ __launch_bounds__(256) void rowdot_bwd_kernel(const float* __restrict
   }
 }
 
-extern "C" int ag_rowdot_fwd(const float* x, int ldx, const float* w, const float* bias, float* y, int64_t ldy, int M, int K,
-                             void* stream) {
+extern "C" int ag_rowdot_fwd(const void* x, int x_bf16, int ldx, const float* w, const float* bias, float* y, int64_t ldy, int M,
+                             int K, void* stream) {
   AG_REQUIRE(x && w && y && M > 0 && K > 0 && ldx >= K && ldy >= 1, "ag_rowdot_fwd: bad args");
-  hipLaunchKernelGGL(rowdot_fwd_kernel, dim3(ag_cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, x, ldx, w, bias, y, ldy, M, K,
-                     (int)(ag_precision() == AG_PREC_BF16));
+  hipLaunchKernelGGL(rowdot_fwd_kernel, dim3(ag_cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, (const float*)x, ldx, w, bias, y,
+                     ldy, M, K, (int)(ag_precision() == AG_PREC_BF16), x_bf16 ? 1 : 0);
   AG_CHECK_LAUNCH("ag_rowdot_fwd");
   return AG_OK;
 }
 
 extern "C" int64_t ag_rowdot_bwd_ws_numel(int M, int K) { return (int64_t)ag_cdiv(M, RD_ROWS) * (K + 1); }
 
-extern "C" int ag_rowdot_bwd(const float* dy, int64_t lddy, const float* x, int ldx, const float* w, float* dx, int lddx,
+extern "C" int ag_rowdot_bwd(const float* dy, int64_t lddy, const void* x, int ldx, const float* w, void* dx, int lddx, int h16,
                              float* dw, float* db, int accumulate, int M, int K, int gate, float slope, void* stream) {
   const AgWs ws = ag_ws_take();     // FIRST: an argument error below must not leave a stale binding behind
   AG_REQUIRE(dy && x && w && M > 0 && K > 0 && ldx >= K && (!dx || lddx >= K), "ag_rowdot_bwd: bad args");
@@ -960,8 +984,8 @@ extern "C" int ag_rowdot_bwd(const float* dy, int64_t lddy, const float* x, int 
     part = ws.p;
   }
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(rowdot_bwd_kernel, dim3(gx, ag_cdiv(K, 256)), dim3(256), 0, st, dy, lddy, x, ldx, w, dx, lddx, part, M, K,
-                     gate, slope, (int)(ag_precision() == AG_PREC_BF16));
+  hipLaunchKernelGGL(rowdot_bwd_kernel, dim3(gx, ag_cdiv(K, 256)), dim3(256), 0, st, dy, lddy, (const float*)x, ldx, w, (float*)dx,
+                     lddx, part, M, K, gate, slope, (int)(ag_precision() == AG_PREC_BF16) || h16, h16 ? 1 : 0);
   AG_CHECK_LAUNCH("ag_rowdot_bwd");
   if (part) return ag_slab_reduce(part, gx, K + 1, dw, accumulate ? 1 : 0, st);
   return AG_OK;

@@ -31,6 +31,42 @@ def _chk(t, name, dtype=torch.float32):
         raise TypeError('audiogan_amd: %s must be %s, got %s' % (name, dtype, t.dtype))
 
 
+BF16 = torch.bfloat16
+
+
+def _is16(t):
+    return t is not None and t.dtype == torch.bfloat16
+
+
+def _chk_any(t, name):
+    """fp32 or bfloat16 device tensor"""
+    if t is None:
+        return
+    if not t.is_cuda:
+        raise RuntimeError('audiogan_amd: %s must be a CUDA (HIP) tensor; there is no CPU path' % name)
+    if t.dtype not in (torch.float32, torch.bfloat16):
+        raise TypeError('audiogan_amd: %s must be float32 or bfloat16, got %s' % (name, t.dtype))
+
+
+def _mat_any(t, name):
+    _chk_any(t, name)
+    if t.dim() != 2 or (t.size(1) > 1 and t.stride(1) != 1):
+        raise ValueError('audiogan_amd: %s must be 2-D with unit stride along dim 1' % name)
+    return t.stride(0) if t.size(0) > 1 else max(t.stride(0), t.size(1))
+
+
+# bf16 STORAGE (BASELINE configs[2], round 4): in 'bf16' precision mode the critic's sequence path keeps its activations,
+# their gradients and the GEMM operands as bfloat16 in HBM (ag_gemm_h reads them straight into LDS); fp32 accumulators,
+# master weights, gate pre-activations / cell states of the recurrent kernels and optimiser state are unchanged.
+# AG_BF16_STORE=0 keeps the round-3 form (fp32 in memory, rounded per use) for A/B runs.
+import os as _os1
+BF16_STORE = [_os1.environ.get('AG_BF16_STORE', '1') != '0']
+
+
+def bf16_storage():
+    return BF16_STORE[0] and lib.ag_get_precision() == 1
+
+
 def _bcl(t, name):
     """(batch stride, channel stride) of a [B,C,L] view with unit time stride."""
     _chk(t, name)
@@ -457,7 +493,7 @@ def gemm(A, B, Cm, ta=False, tb=False, alpha=1.0, beta=0.0, bias=None, res=None,
 def col_sum(X, out, accumulate=True, defer=True):
     """out[n] (+)= sum_m X[m,n].  ``defer=False``: complete when the call returns (in stream order) also inside a recording
     ``deferred_reduces`` scope - for sums that are read before that scope closes."""
-    ldx = _mat(X, 'X')
+    ldx = _mat_any(X, 'X')
     _chk(out, 'out')
     M, N = X.shape
     assert out.numel() == N and out.is_contiguous()
@@ -466,7 +502,7 @@ def col_sum(X, out, accumulate=True, defer=True):
         lib.ag_defer_reduces(2)
     try:
         _ws = _bind_ws(min(_SMALL_WS, 64 * N) if M > 16 else 0, out.device)  # noqa: F841
-        check(lib.ag_col_sum(_p(X), ldx, _p(out), M, N, int(bool(accumulate)), _stream()), 'ag_col_sum')
+        check(lib.ag_col_sum(_p(X), int(_is16(X)), ldx, _p(out), M, N, int(bool(accumulate)), _stream()), 'ag_col_sum')
     finally:
         if hold:
             lib.ag_defer_reduces(3)
@@ -562,26 +598,30 @@ def act_bwd(dy, y, dx, act, slope=LEAKY_SLOPE):
     check(lib.ag_act_bwd(_p(dy), _p(y), _p(dx), dy.numel(), act, slope, _stream()), 'ag_act_bwd')
 
 
-def bct_to_tbc(x, out=None):
-    """[B,C,T] (any batch / channel pitch, time contiguous) -> contiguous [T,B,C] (ag_transpose_batched)"""
-    _chk(x, 'x')
+def bct_to_tbc(x, out=None, out_dtype=None):
+    """[B,C,T] (any batch / channel pitch, time contiguous) -> contiguous [T,B,C] (ag_transpose_batched); fp32 or bf16 on
+    either side (``out_dtype``: default = x's)"""
+    _chk_any(x, 'x')
     B, Cc, T = x.shape
     assert x.stride(2) == 1
     if out is None:
-        out = torch.empty(T, B, Cc, device=x.device)
-    check(lib.ag_transpose_batched(_p(x), x.stride(0), x.stride(1), _p(out), Cc, B * Cc, B, Cc, T, _stream()),
-          'ag_transpose_batched')
+        out = torch.empty(T, B, Cc, device=x.device, dtype=out_dtype or x.dtype)
+    _chk_any(out, 'out')
+    check(lib.ag_transpose_batched(_p(x), int(_is16(x)), x.stride(0), x.stride(1), _p(out), int(_is16(out)), Cc, B * Cc, B, Cc,
+                                   T, _stream()), 'ag_transpose_batched')
     return out
 
 
-def tbc_to_bct(x, out=None):
-    """contiguous [T,B,C] -> contiguous [B,C,T] (ag_transpose_batched)"""
-    _chk(x, 'x')
+def tbc_to_bct(x, out=None, out_dtype=None):
+    """contiguous [T,B,C] -> contiguous [B,C,T] (ag_transpose_batched); fp32 or bf16 on either side"""
+    _chk_any(x, 'x')
     T, B, Cc = x.shape
     assert x.is_contiguous()
     if out is None:
-        out = torch.empty(B, Cc, T, device=x.device)
-    check(lib.ag_transpose_batched(_p(x), Cc, B * Cc, _p(out), Cc * T, T, B, T, Cc, _stream()), 'ag_transpose_batched')
+        out = torch.empty(B, Cc, T, device=x.device, dtype=out_dtype or x.dtype)
+    _chk_any(out, 'out')
+    check(lib.ag_transpose_batched(_p(x), int(_is16(x)), Cc, B * Cc, _p(out), int(_is16(out)), Cc * T, T, B, T, Cc, _stream()),
+          'ag_transpose_batched')
     return out
 
 
@@ -591,31 +631,114 @@ def rowdot_ok(x, w):
 
 
 def rowdot_fwd(x, w, bias, y):
-    """y[m] = x[m,:] . w + bias[0]; y: [M] or [M,1] of any stride"""
-    ldx = _mat(x, 'x')
+    """y[m] = x[m,:] . w + bias[0]; y: [M] or [M,1] of any stride; x fp32 or bf16"""
+    ldx = _mat_any(x, 'x')
     _chk(w, 'w'); _chk(bias, 'bias'); _chk(y, 'y')
     M, Kd = x.shape
     assert rowdot_ok(x, w) and y.numel() == M
     ldy = y.stride(0) if M > 1 else 1
-    check(lib.ag_rowdot_fwd(_p(x), ldx, _p(w), _p(bias), _p(y), ldy, M, Kd, _stream()), 'ag_rowdot_fwd')
+    check(lib.ag_rowdot_fwd(_p(x), int(_is16(x)), ldx, _p(w), _p(bias), _p(y), ldy, M, Kd, _stream()), 'ag_rowdot_fwd')
 
 
 def rowdot_bwd(dy, x, w, dx=None, dw=None, db=None, gate=False, slope=LEAKY_SLOPE, accumulate=True):
     """backward of a one-output Linear in ONE pass over x: dx = dy (x) w (times LeakyReLU'(x) when ``gate``: x is the saved
     output of the LeakyReLU below), dw (+)= dy^T x, db (+)= sum dy.  dw [1,K] / [K] and db [1] must be adjacent in memory
     (db right behind dw: one gradient row), as the views of WNGroup.zero_dws are; dy: [M] or [M,1] of any stride."""
-    ldx = _mat(x, 'x')
-    _chk(dy, 'dy'); _chk(w, 'w'); _chk(dx, 'dx'); _chk(dw, 'dw'); _chk(db, 'db')
+    ldx = _mat_any(x, 'x')
+    _chk(dy, 'dy'); _chk(w, 'w'); _chk_any(dx, 'dx'); _chk(dw, 'dw'); _chk(db, 'db')
     M, Kd = x.shape
     assert rowdot_ok(x, w) and dy.numel() == M
-    lddx = _mat(dx, 'dx') if dx is not None else 0
-    assert dx is None or tuple(dx.shape) == (M, Kd)
+    lddx = _mat_any(dx, 'dx') if dx is not None else 0
+    assert dx is None or (tuple(dx.shape) == (M, Kd) and dx.dtype == x.dtype), 'x and dx share a storage type'
+    h16 = int(_is16(x))
     if dw is not None:
         assert dw.is_contiguous() and dw.numel() == Kd and db is not None and db.numel() == 1
         assert db.data_ptr() == dw.data_ptr() + 4 * Kd, 'db must sit right behind dw'
         _ws = _bind_ws(lib.ag_rowdot_bwd_ws_numel(M, Kd), dw.device)  # noqa: F841
-    check(lib.ag_rowdot_bwd(_p(dy), dy.stride(0) if M > 1 else 1, _p(x), ldx, _p(w), _p(dx), lddx, _p(dw), _p(db),
+    check(lib.ag_rowdot_bwd(_p(dy), dy.stride(0) if M > 1 else 1, _p(x), ldx, _p(w), _p(dx), lddx, h16, _p(dw), _p(db),
                             int(bool(accumulate)), M, Kd, int(bool(gate)), slope, _stream()), 'ag_rowdot_bwd')
+
+
+def to_bf16(src, out=None):
+    """a bfloat16 image of a contiguous or row-pitched 2-D fp32 tensor / of any contiguous fp32 tensor (ag_to_bf16_2d)"""
+    _chk(src, 'src')
+    if src.dim() == 2 and src.stride(1) == 1 and src.size(0) <= 65535:
+        rows, cols, ld = src.size(0), src.size(1), (src.stride(0) if src.size(0) > 1 else src.size(1))
+    else:
+        assert src.is_contiguous()
+        n = src.numel()
+        cols = next((c for c in (8192, 4096, 2048, 1024, 512, 256, 64, 8, 1) if n % c == 0 and n // c <= 65535), None)
+        assert cols is not None, 'to_bf16: tensor too large for one launch'
+        rows, ld = n // cols, cols
+    if out is None:
+        out = torch.empty(src.shape, device=src.device, dtype=torch.bfloat16)
+    _chk(out, 'out', torch.bfloat16)
+    assert out.is_contiguous() and out.numel() == src.numel()
+    check(lib.ag_to_bf16_2d(_p(src), ld, _p(out), cols, rows, cols, _stream()), 'ag_to_bf16_2d')
+    return out
+
+
+def gemm_h_ok(A, B, ta, tb):
+    """can ag_gemm_h take these bf16 operands?  (K % 64 == 0, 16-byte aligned rows, k-strided row counts % 8 == 0)"""
+    if not (_is16(A) and _is16(B) and A.dim() == 2 and B.dim() == 2 and A.stride(1) == 1 and B.stride(1) == 1):
+        return False
+    M, Kd = (A.size(1), A.size(0)) if ta else (A.size(0), A.size(1))
+    N = B.size(0) if tb else B.size(1)
+    lda = A.stride(0) if A.size(0) > 1 else A.size(1)
+    ldb = B.stride(0) if B.size(0) > 1 else B.size(1)
+    return bool(lib.ag_gemm_h_ok(M, N, Kd, int(ta), int(tb), lda, ldb)) and A.data_ptr() % 16 == 0 and B.data_ptr() % 16 == 0
+
+
+def gemm_h(A, B, C=None, C16=None, ta=False, tb=False, alpha=1.0, beta=0.0, bias=None, res=None, gate=None, act=ACT_NONE,
+           slope=LEAKY_SLOPE, defer=False):
+    """C / C16 [M,N] = act(alpha * op(A) @ op(B) + beta * C + bias + res) on operands STORED as bfloat16 (ag_gemm_h).
+    C: fp32 output, C16: bf16 output (either or both); res: fp32 or bf16 residual (with ACT_LEAKY_GATE: the saved activation);
+    gate: bf16 saved LeakyReLU output applied after bias / res.  ``defer`` as for gemm()."""
+    lda, ldb = _mat_any(A, 'A'), _mat_any(B, 'B')
+    assert _is16(A) and _is16(B), 'gemm_h: bf16 operands'
+    out = C if C is not None else C16
+    M, N = out.shape
+    Kd = A.size(0) if ta else A.size(1)
+    assert (A.size(1) if ta else A.size(0)) == M, 'gemm_h: A shape'
+    assert (B.size(1) if tb else B.size(0)) == Kd and (B.size(0) if tb else B.size(1)) == N, 'gemm_h: B shape'
+    ldc = ldc16 = ldres = ldres16 = ldg = 0
+    if C is not None:
+        ldc = _mat(C, 'C')
+        assert tuple(C.shape) == (M, N)
+    if C16 is not None:
+        _chk(C16, 'C16', torch.bfloat16)
+        ldc16 = _mat_any(C16, 'C16')
+        assert tuple(C16.shape) == (M, N)
+    r32 = res if (res is not None and not _is16(res)) else None
+    r16 = res if _is16(res) else None
+    if res is not None:
+        assert tuple(res.shape) == (M, N)
+        ldres, ldres16 = (_mat(r32, 'res') if r32 is not None else 0), (_mat_any(r16, 'res') if r16 is not None else 0)
+    if gate is not None:
+        _chk(gate, 'gate', torch.bfloat16)
+        ldg = _mat_any(gate, 'gate')
+        assert tuple(gate.shape) == (M, N)
+    if bias is not None:
+        _chk(bias, 'bias')
+        assert bias.numel() == N and bias.is_contiguous()
+    nws = lib.ag_gemm_h_ws_numel(M, N, Kd, act, int(C16 is not None)) if gate is None else 0
+    hold = (not defer) and nws > 0 and reduces_recording()
+    if hold:
+        lib.ag_defer_reduces(2)
+    try:
+        _ws = _bind_ws(nws, out.device)  # noqa: F841
+        check(lib.ag_gemm_h(_p(A), lda, int(ta), _p(B), ldb, int(tb), _p(C), ldc, _p(C16), ldc16, M, N, Kd, alpha, beta,
+                            _p(bias), _p(r32), ldres, _p(r16), ldres16, _p(gate), ldg, act, slope, _stream()), 'ag_gemm_h')
+    finally:
+        if hold:
+            lib.ag_defer_reduces(3)
+
+
+def _work_gemm_h(A, B, C=None, C16=None, ta=False, tb=False, *a_, **kw):
+    out = C if C is not None else C16
+    M, N = out.shape
+    Kd = A.size(0) if ta else A.size(1)
+    return 'gemm_bf16s_kernel<%d,%d>' % (int(ta), int(tb)), 2.0 * M * N * Kd, 2.0 * (M * Kd + N * Kd) + (4.0 if C is not None else 2.0) * M * N
 
 
 def build_zc(z, c, out=None):
@@ -1007,7 +1130,7 @@ def lstm_seq_fwd_persist(pre, whh, c_all, y, valid, static=None):
         for t_, shp in ((pre[d], (T, B, 4 * H)), (whh[d], (4 * H, H)), (c_all[d], (T + 1, B, H))):
             _chk(t_, 'lstm_seq tensor')
             assert t_.is_contiguous() and tuple(t_.shape) == shp, (tuple(t_.shape), shp)
-    _chk(y, 'y'); _chk(valid, 'valid', torch.int64)
+    _chk_any(y, 'y'); _chk(valid, 'valid', torch.int64)
     assert y.is_contiguous() and tuple(y.shape) == (T, B, ndir * H)
     if static is not None:
         assert len(static) == ndir
@@ -1016,7 +1139,7 @@ def lstm_seq_fwd_persist(pre, whh, c_all, y, valid, static=None):
             assert t_.is_contiguous() and tuple(t_.shape) == (B, 4 * H)
     nb = int(lib.ag_lstm_persist_ws_bytes(B, H, ndir))
     ws = _persist_workspace(y.device, nb)
-    check(lib.ag_lstm_seq_fwd_persist(_ptr_table(pre), _ptr_table(whh), _ptr_table(c_all), _p(y), _p(valid),
+    check(lib.ag_lstm_seq_fwd_persist(_ptr_table(pre), _ptr_table(whh), _ptr_table(c_all), _p(y), int(_is16(y)), _p(valid),
                                       _ptr_table(static) if static is not None else None, _p(ws), ws.numel(),
                                       T, B, H, ndir, _n_cu(y.device), _stream()), 'ag_lstm_seq_fwd_persist')
 
@@ -1214,9 +1337,10 @@ def lstm_persist_bwd_ok(B, H, ndir, dev):
     return bool(PERSIST[0] and lib.ag_lstm_persist_bwd_ok(B, H, ndir, _n_cu(dev)))
 
 
-def _lstm_seq_bwd_persist_call(gates, whh, c_all, dy, dgates, valid, dgsum=None):
+def _lstm_seq_bwd_persist_call(gates, whh, c_all, dy, dgates, valid, dgsum=None, dg16=None):
     """ONE persistent launch for the whole backward through time (ag_lstm_seq_bwd_persist); dgsum: optional list of
-    [B,4H] outputs (one per direction) = the sum over time of dgates"""
+    [B,4H] outputs (one per direction) = the sum over time of dgates; dy: fp32 or bf16; dg16: optional list of [T,B,4H]
+    bfloat16 outputs = dgates rounded (the operand of the gradient products on bf16 storage)"""
     ndir = len(gates)
     T, B, H4 = gates[0].shape
     H = H4 // 4
@@ -1225,34 +1349,46 @@ def _lstm_seq_bwd_persist_call(gates, whh, c_all, dy, dgates, valid, dgsum=None)
                         (dgates[d], (T, B, 4 * H))):
             _chk(t_, 'lstm_seq tensor')
             assert t_.is_contiguous() and tuple(t_.shape) == shp, (tuple(t_.shape), shp)
-    _chk(dy, 'dy'); _chk(valid, 'valid', torch.int64)
+    _chk_any(dy, 'dy'); _chk(valid, 'valid', torch.int64)
     assert dy.is_contiguous() and tuple(dy.shape) == (T, B, ndir * H)
     if dgsum is not None:
         assert len(dgsum) == ndir
         for t_ in dgsum:
             _chk(t_, 'dgsum')
             assert t_.is_contiguous() and tuple(t_.shape) == (B, 4 * H)
+    ld16 = 0
+    if dg16 is not None:
+        assert len(dg16) == ndir
+        for t_ in dg16:      # views [T,B,4H] of one [T,B,ndir*4H] tensor (or separate contiguous tensors): a common row pitch
+            _chk(t_, 'dg16', torch.bfloat16)
+            assert tuple(t_.shape) == (T, B, 4 * H) and t_.stride(2) == 1 and t_.stride(0) == B * t_.stride(1)
+        ld16 = dg16[0].stride(1)
+        assert all(t_.stride(1) == ld16 for t_ in dg16)
     ws = _persist_workspace(dy.device, 8192 + 256)
-    check(lib.ag_lstm_seq_bwd_persist(_ptr_table(gates), _ptr_table(whh), _ptr_table(c_all), _p(dy),
-                                      _ptr_table(dgates), _ptr_table(dgsum) if dgsum is not None else None, _p(valid),
+    check(lib.ag_lstm_seq_bwd_persist(_ptr_table(gates), _ptr_table(whh), _ptr_table(c_all), _p(dy), int(_is16(dy)),
+                                      _ptr_table(dgates), _ptr_table(dgsum) if dgsum is not None else None,
+                                      _ptr_table(dg16) if dg16 is not None else None, ld16, _p(valid),
                                       _p(ws), ws.numel(), T, B, H, ndir, _n_cu(dy.device), _stream()),
           'ag_lstm_seq_bwd_persist')
 
 
-def _work_seq_bwd_persist(gates, whh, c_all, dy, dgates, valid, dgsum=None):
+def _work_seq_bwd_persist(gates, whh, c_all, dy, dgates, valid, dgsum=None, dg16=None):
     T, B, H4 = gates[0].shape
     nd = len(gates)
     return 'lstm_persist_bwd_kernel' + _bf16_tag(), T * 2.0 * nd * B * H4 * (H4 // 4), \
         4.0 * nd * (H4 * (H4 // 4) + T * 5.5 * B * H4), 1
 
 
-def lstm_seq_bwd(gates, whh, c_all, dy, dgates, dhbuf, dcbuf, valid, dgsum=None):
+def lstm_seq_bwd(gates, whh, c_all, dy, dgates, dhbuf, dcbuf, valid, dgsum=None, dg16=None):
     """``dgsum``: optional list of [B,4H] tensors (one per direction) that receive the sum over time of dgates.  Returns True
-    when they were filled (the persistent launch sums them in registers); False: the caller sums dgates itself."""
+    when they were filled (the persistent launch sums them in registers); False: the caller sums dgates itself.
+    ``dg16`` / a bf16 ``dy``: the persistent launch only (callers check lstm_persist_bwd_ok first)."""
     T = gates[0].size(0)
     if lstm_persist_bwd_ok(gates[0].size(1), gates[0].size(2) // 4, len(gates), dy.device):
-        _lstm_seq_bwd_persist_call(gates, whh, c_all, dy, dgates, valid, dgsum)
+        _lstm_seq_bwd_persist_call(gates, whh, c_all, dy, dgates, valid, dgsum, dg16)
         return dgsum is not None
+    assert dg16 is None and not _is16(dy), 'bf16 storage needs the persistent launch'
+
     if Profiler.enabled:
         H = gates[0].size(2) // 4
         if H % 16 == 0:         # the fused step kernel: the whole chain between one pair of events
@@ -1374,8 +1510,9 @@ def gru_cell_bwd(gates_act, gh, h_prev, dh, dgi, dgh, dh_prev):
           'ag_gru_cell_bwd')
 
 
-for _n in ('gru_cell_fwd', 'gru_cell_bwd', 'rowdot_fwd', 'rowdot_bwd', 'build_zc', 'critic_batch'):
+for _n in ('gru_cell_fwd', 'gru_cell_bwd', 'rowdot_fwd', 'rowdot_bwd', 'build_zc', 'critic_batch', 'to_bf16'):
     _instrument(_n, None)
+_instrument('gemm_h', _work_gemm_h)
 
 
 def act_bwd2d(dy, y, dx, act, slope=LEAKY_SLOPE):

@@ -318,17 +318,31 @@ class Discriminator(nn.Module):
         acts = ops.DConvStackFn.apply(x, self._stack, lens_list, *self._stack.group.params())
         return acts, lens_list
 
+    def stores_bf16(self, batch, dev):
+        """does classify() at this batch size keep its sequence path as bfloat16 in HBM (kernels.bf16_storage: 'bf16'
+        precision mode, AG_BF16_STORE != 0, and the persistent recurrent launches - which write / read those tensors in that
+        type - fit)?  The oracle's ``bf16_mode(store=...)`` states the same contract."""
+        K = ops.K
+        dev = torch.device(dev)
+        h = self._state_size // 2
+        return bool(dev.type == 'cuda' and K.bf16_storage() and K.lstm_step_ok(batch, h) and
+                    K.lstm_persist_ok(batch, h, 2, dev) and K.lstm_persist_bwd_ok(batch, h, 2, dev))
+
     def classify(self, a, n, c):
         """the rest of forward() (audiogan.py:537-549): biLSTM over [conv features, c] + heads -> logits"""
         ss, es = self._state_size, self._embed_size
         b, tq = a.size(0), a.size(2)
+        # bf16 storage (kernels.bf16_storage: 'bf16' precision mode): the sequence path - time-major features, biLSTM
+        # output, every activation of the heads and all their gradients - lives in HBM as bfloat16; it needs the persistent
+        # recurrent launches, which write / read those tensors in that type
+        s16 = self.stores_bf16(b, a.device)
         # layer 0 sees cat([features_t, c]) at every frame (:541): c goes in as the layer's time-invariant input
-        seq = ops.TimeMajorFn.apply(a)                    # [T',B,C], contiguous
+        seq = ops.TimeMajorFn.apply(a, s16)               # [T',B,C], contiguous
         for layer in range(self._num_layers):
             seq = ops.LSTMSeqFn.apply(seq, n, 2, c if layer == 0 else None, *self._rnn_weights(layer))
         # the heads are per-row: keep the LSTM's (time, clip) row order and transpose only the logits
         logits = ops.DHeadFn.apply(seq.reshape(tq * b, ss), self._head, *self._head.group.params())
-        return logits.view(tq, b).t()
+        return logits.view(tq, b).t()       # (fp32 also on bf16 storage)
 
     def early_params(self):
         """parameters whose gradients are complete BEFORE the conv stack's backward runs (heads + biLSTM):

@@ -259,14 +259,17 @@ class TimeMajorFn(torch.autograd.Function):
     transpose launch instead of a strided elementwise copy"""
 
     @staticmethod
-    def forward(ctx, a):
+    def forward(ctx, a, store16=False):
+        """``store16`` (bf16 storage, kernels.bf16_storage): the time-major features are WRITTEN as bfloat16 - the operand
+        type of the products that read them - and their gradient comes back as bfloat16"""
         if a.stride(2) != 1:
             a = a.contiguous()
-        return K.bct_to_tbc(a)
+        ctx.in_dtype = a.dtype
+        return K.bct_to_tbc(a, out_dtype=torch.bfloat16 if store16 else None)
 
     @staticmethod
     def backward(ctx, g):
-        return K.tbc_to_bct(g.contiguous())
+        return K.tbc_to_bct(g.contiguous(), out_dtype=ctx.in_dtype), None
 
 
 _EYE = {}
@@ -280,10 +283,94 @@ def _eye(w):
     return _EYE[key]
 
 
+def _gh(A, B, C=None, C16=None, ta=False, tb=False, bias=None, res=None, gate=None, act=ACT_NONE, defer=False, beta=0.0):
+    """a product on bf16-stored operands: ag_gemm_h when the shape fits it, else the fp32-operand kernel on widened copies
+    (odd test shapes only: every BASELINE shape takes the first branch)"""
+    if K.gemm_h_ok(A, B, ta, tb):
+        K.gemm_h(A, B, C=C, C16=C16, ta=ta, tb=tb, bias=bias, res=res, gate=gate, act=act, defer=defer, beta=beta)
+        return
+    out = C if C is not None else torch.empty(C16.shape, device=C16.device)
+    r = res.float() if (res is not None and res.dtype != torch.float32) else res
+    K.gemm(A.float(), B.float(), out, ta=ta, tb=tb, bias=bias, res=r, act=act, defer=defer, beta=beta)
+    if gate is not None:
+        K.act_bwd(out.view(-1), gate.float().view(-1), out.view(-1), ACT_LEAKY)
+    if C16 is not None:
+        C16.copy_(out)
+
+
 class DHeadFn(torch.autograd.Function):
+    """``rows`` fp32: the round-3 form.  ``rows`` bfloat16 (bf16 storage): every activation of the heads, its gradient and
+    both operands of every product are bfloat16 in HBM (ag_gemm_h); logits, parameter gradients and biases stay fp32."""
+
+    @staticmethod
+    def _forward16(ctx, rows, head, prep):
+        g = head.group
+        M, nr = rows.size(0), head.n_res
+        a = rows.contiguous()
+        saved = [a]
+        for i in range(nr):
+            y = torch.empty(M, prep[2 * i].w.size(0), device=a.device, dtype=torch.bfloat16)
+            _gh(a, g.w16(2 * i), C16=y, tb=True, bias=prep[2 * i + 1].w, res=a, act=ACT_LEAKY)
+            saved.append(y)
+            a = y
+        w1, b0, b1 = prep[2 * nr + 2].w, prep[2 * nr + 1].w, prep[2 * nr + 3].w
+        hmid = torch.empty(M, prep[2 * nr].w.size(0), device=a.device, dtype=torch.bfloat16)
+        _gh(a, g.w16(2 * nr), C16=hmid, tb=True, bias=b0, act=ACT_LEAKY)
+        out = torch.empty(M, w1.size(0), device=a.device)
+        if w1.size(0) == 1 and K.rowdot_ok(hmid, w1):
+            K.rowdot_fwd(hmid, w1, b1, out)
+        else:
+            _gh(hmid, g.w16(2 * nr + 2), C=out, tb=True, bias=b1)
+        saved.append(hmid)
+        ctx.head, ctx.key, ctx.store16 = head, g._key[1:], True
+        ctx.save_for_backward(*saved)
+        return out
+
+    @staticmethod
+    def _backward16(ctx, dout, head, prep):
+        g = head.group
+        saved = ctx.saved_tensors
+        hmid, acts, nr = saved[-1], saved[:-1], head.n_res
+        wg = any(ctx.needs_input_grad[2:])
+        dws = g.zero_dws() if wg else None
+        dout = dout.contiguous()
+        with K.deferred_reduces():
+            w1 = prep[2 * nr + 2].w
+            dh = torch.empty_like(hmid)
+            dw1, db1 = (dws[2 * nr + 2], dws[2 * nr + 3]) if wg else (None, None)
+            if w1.size(0) == 1 and K.rowdot_ok(hmid, w1) and (not wg or db1.data_ptr() == dw1.data_ptr() + 4 * dw1.numel()):
+                K.rowdot_bwd(dout, hmid, w1, dx=dh, dw=dw1, db=db1, gate=True)
+            else:
+                d16 = dout.to(torch.bfloat16)
+                if wg:
+                    _gh(d16, hmid, C=dws[2 * nr + 2], ta=True, defer=True)
+                    K.col_sum(dout, dws[2 * nr + 3])
+                _gh(d16, g.w16(2 * nr + 2), C16=dh, res=hmid, act=ACT_LEAKY_GATE)
+            if wg:
+                _gh(dh, acts[nr], C=dws[2 * nr], ta=True, defer=True)
+                K.col_sum(dh, dws[2 * nr + 1])
+            da = torch.empty_like(acts[nr])
+            if nr > 0:
+                _gh(dh, g.w16(2 * nr), C16=da, res=acts[nr], act=ACT_LEAKY_GATE)
+            else:
+                _gh(dh, g.w16(2 * nr), C16=da)
+            for i in reversed(range(nr)):
+                if wg:
+                    _gh(da, acts[i], C=dws[2 * i], ta=True, defer=True)
+                    K.col_sum(da, dws[2 * i + 1])
+                dprev = torch.empty_like(acts[i])
+                # d(input of residual i) = W^T da + da, times the LeakyReLU derivative of the residual below (gate)
+                _gh(da, g.w16(2 * i), C16=dprev, res=da, gate=acts[i] if i > 0 else None)
+                da = dprev
+        grads = g.backward(dws) if wg else [None] * (2 * len(g.items))
+        return (da if ctx.needs_input_grad[0] else None, None) + tuple(grads)
+
     @staticmethod
     def forward(ctx, rows, head, *params):
         prep = head.group.prepare()
+        if rows.dtype == torch.bfloat16:
+            return DHeadFn._forward16(ctx, rows, head, prep)
+        ctx.store16 = False
         M = rows.size(0)
         a = rows.contiguous()
         saved = [a]
@@ -311,6 +398,8 @@ class DHeadFn(torch.autograd.Function):
         head = ctx.head
         prep = head.group.prepare()
         assert head.group._key[1:] == ctx.key, 'parameters changed between forward and backward'
+        if ctx.store16:
+            return DHeadFn._backward16(ctx, dout, head, prep)
         saved = ctx.saved_tensors
         hmid = saved[-1]
         acts = saved[:-1]          # acts[0] = input rows, acts[i] = output of residual i

@@ -22,6 +22,11 @@ from .common import WNGroup, _zeros_like_list, grad_target
 STOPPER_ONLY = [False]
 
 
+def _gh(*a, **k):
+    from .ops import _gh as f
+    return f(*a, **k)
+
+
 def _small(A, B, Cm, tb=False, beta=0.0, bias=None, act=ACT_NONE, res=None):
     """Cm = act(A @ op(B) + beta*Cm + bias + res) for a product with few rows"""
     if res is None and K.skinny_ok(A, B, tb):
@@ -55,6 +60,39 @@ def _small_acc(A, B, Cm, tb=False):
 # --------------------------------------------------------------------------------------
 # LSTM layer over a padded sequence (uni- or bidirectional), NN.LSTM parameter layout
 # --------------------------------------------------------------------------------------
+_LSTM_IMAGES = {}      # id(first weight Parameter of a layer) -> common.Bf16Images (bf16 images of that layer's weights)
+
+
+def _lstm_images(w):
+    from .common import Bf16Images
+    key = id(w[0])
+    im = _LSTM_IMAGES.get(key)
+    if im is None:
+        if len(_LSTM_IMAGES) > 64:
+            _LSTM_IMAGES.clear()
+        im = _LSTM_IMAGES[key] = Bf16Images()
+    return im
+
+
+def _wih16(w, ndir, Fx):
+    """[ndir * 4H, Fx] bfloat16: the x-columns of every direction's W_ih stacked - the B operand of the input projections
+    (per direction: a row block, k contiguous) and of the input gradient dx = [dg_0 | dg_1] @ stack (k strided)"""
+    im = _lstm_images(w)
+    H4 = w[0].size(0)
+    stack = getattr(im, 'stack', None)
+    if stack is None or stack.shape != (ndir * H4, Fx) or stack.device != w[0].device:
+        stack = im.stack = torch.empty(ndir * H4, Fx, device=w[0].device, dtype=torch.bfloat16)
+        im.keys = [None] * ndir
+    from .common import capture_tag, param_epoch
+    for d in range(ndir):
+        p_ = w[4 * d]
+        key = (capture_tag(p_.device), p_.data_ptr(), p_._version, param_epoch(p_))
+        if im.keys[d] != key:
+            K.to_bf16(p_.data[:, :Fx], out=stack[d * H4:(d + 1) * H4])
+            im.keys[d] = key
+    return stack
+
+
 class LSTMSeqFn(torch.autograd.Function):
     """x: [T,B,Fx]; lengths: int64 [B] on device or None; ``static``: None or [B,Fc], a time-invariant part
     of the input (the layer sees cat([x_t, static]) at every step, audiogan.py:541); weights per direction:
@@ -74,10 +112,32 @@ class LSTMSeqFn(torch.autograd.Function):
         Fc = static.size(1) if static is not None else 0
         assert w[0].size(1) == Fx + Fc
         st = static.contiguous() if static is not None else None
-        y = torch.empty(T, B, ndir * H, device=dev)
+        # bf16 storage (x arrives as bfloat16): x, the layer output y, dgates' operand copy and dx are bfloat16 in HBM and
+        # every large product runs on ag_gemm_h; gate pre-activations, cell states and the persistent kernels' exchange stay
+        # fp32.  Needs the persistent launches (they write y / read dy as bf16).
+        s16 = x.dtype == torch.bfloat16
+        if s16:
+            assert K.lstm_step_ok(B, H) and K.lstm_persist_ok(B, H, ndir, dev) and K.lstm_persist_bwd_ok(B, H, ndir, dev), \
+                'bf16 storage needs the persistent LSTM launches (modules.Discriminator.classify checks this)'
+            wst = _wih16(w, ndir, Fx)
+        y = torch.empty(T, B, ndir * H, device=dev, dtype=torch.bfloat16 if s16 else torch.float32)
         gates_all, c_all, whh, cbs = [], [], [], []
         fused = K.lstm_step_ok(B, H)
-        for d in range(ndir):
+        for d in range(ndir if s16 else 0):
+            w_ih, w_hh, b_ih, b_hh = w[4 * d:4 * d + 4]
+            g = torch.empty(T, B, 4 * H, device=dev)
+            wx16 = wst[d * 4 * H:(d + 1) * 4 * H]
+            if st is not None:
+                cb = torch.empty(B, 4 * H, device=dev)
+                K.gemm(st, w_ih.data[:, Fx:], cb, tb=True, bias=b_ih.data, res=_bcast_rows(b_hh.data, B))
+                _gh(x2, wx16, C=g.view(T * B, 4 * H), tb=True)
+                cbs.append(cb)
+            else:
+                _gh(x2, wx16, C=g.view(T * B, 4 * H), tb=True, bias=b_ih.data, res=_bcast_rows(b_hh.data, T * B))
+            gates_all.append(g)
+            c_all.append(torch.empty(T + 1, B, H, device=dev))
+            whh.append(w_hh.data.contiguous())
+        for d in range(0 if s16 else ndir):
             w_ih, w_hh, b_ih, b_hh = w[4 * d:4 * d + 4]
             g = torch.empty(T, B, 4 * H, device=dev)
             # b_ih + b_hh: one rides as the GEMM's bias, the other as a `res` whose row pitch is 0 (the same row for every
@@ -113,7 +173,7 @@ class LSTMSeqFn(torch.autograd.Function):
                         K.gemm(hp, whh[d], g[t], tb=True, beta=1.0)
                     K.lstm_cell_fwd(g[t], c[k], c[k + 1], h_out=hn, y_out=y[t, :, d * H:(d + 1) * H],
                                     h_prev=hp, valid=lengths, t=t)
-        ctx.ndir, ctx.has_len, ctx.has_static = ndir, lengths is not None, st is not None
+        ctx.ndir, ctx.has_len, ctx.has_static, ctx.s16 = ndir, lengths is not None, st is not None, s16
         ctx.params = w
         ctx.save_for_backward(x2, y, lengths if lengths is not None else x2.new_empty(0),
                               st if st is not None else x2.new_empty(0),
@@ -132,6 +192,8 @@ class LSTMSeqFn(torch.autograd.Function):
         gates_all, c_all, w = list(sv[4:4 + ndir]), list(sv[4 + ndir:4 + 2 * ndir]), sv[4 + 2 * ndir:]
         dev = x2.device
         dy = dy.contiguous()
+        if ctx.s16:
+            return LSTMSeqFn._backward16(ctx, dy, x2, y, lengths, st, gates_all, c_all, w)
         whh = [w[4 * d + 1].contiguous() for d in range(ndir)]
         dgs = [torch.empty(T, B, 4 * H, device=dev) for _ in range(ndir)]
         dhb = [torch.empty(2, B, H, device=dev) for _ in range(ndir)]
@@ -215,6 +277,69 @@ class LSTMSeqFn(torch.autograd.Function):
                 outs += [dw_ih, dw_hh, db, db.clone()]
         dx = dx2.view(T, B, Fx) if ctx.needs_input_grad[0] else None
         return (dx, None, None, dstatic) + tuple(outs)
+
+
+def _lstm_backward16(ctx, dy, x2, y, lengths, st, gates_all, c_all, w):
+    """LSTMSeqFn.backward on bf16 storage: dy, x2, y are bfloat16; the persistent launch leaves dgates in fp32 (its exchange
+    buffer) AND as one bfloat16 tensor [T,B,ndir*4H], the operand of the three gradient products (ag_gemm_h)"""
+    T, B, Fx, H = ctx.shape
+    ndir = ctx.ndir
+    dev = x2.device
+    H4 = 4 * H
+    whh = [w[4 * d + 1].contiguous() for d in range(ndir)]
+    dgs = [torch.empty(T, B, H4, device=dev) for _ in range(ndir)]
+    dg16 = torch.empty(T, B, ndir * H4, device=dev, dtype=torch.bfloat16)
+    wg = any(ctx.needs_input_grad[4:])
+    need_ds = st is not None and ctx.needs_input_grad[3]
+    want_sum = st is not None and (wg or need_ds)
+    dgsums = [torch.empty(B, H4, device=dev) for _ in range(ndir)] if want_sum else None
+    have_sum = K.lstm_seq_bwd(gates_all, whh, c_all, dy, dgs, None, None, lengths, dgsum=dgsums,
+                              dg16=[dg16[:, :, d * H4:(d + 1) * H4] for d in range(ndir)])
+    assert have_sum or not want_sum
+    dg2 = dg16.view(T * B, ndir * H4)
+    dx2 = None
+    if ctx.needs_input_grad[0]:
+        dx2 = torch.empty(T * B, Fx, device=dev, dtype=torch.bfloat16)
+        _gh(dg2, _wih16(w, ndir, Fx), C16=dx2)            # both directions in ONE product (K = ndir * 4H)
+    dstatic = torch.zeros_like(st) if need_ds else None
+    for d in range(ndir if need_ds else 0):
+        K.gemm(dgsums[d], w[4 * d][:, Fx:], dstatic, beta=1.0)
+    outs = []
+    if not wg:
+        outs = [None] * (4 * ndir)
+    tgs = [[grad_target(p_) for p_ in ctx.params[4 * d:4 * d + 4]] for d in range(ndir)] if wg else []
+    direct_all = wg and all(t_ is not None for tg in tgs for t_ in tg)
+    import contextlib
+    with (K.deferred_reduces() if direct_all else contextlib.nullcontext()):
+        for d in range(ndir if wg else 0):
+            w_ih, w_hh = w[4 * d], w[4 * d + 1]
+            tg = tgs[d]
+            direct = all(t_ is not None for t_ in tg)
+            dw_ih, dw_hh = (tg[0], tg[1]) if direct else (torch.zeros_like(w_ih), torch.zeros_like(w_hh))
+            dgd = dg2[:, d * H4:(d + 1) * H4]
+            _gh(dgd, x2, C=dw_ih[:, :Fx] if st is not None else dw_ih, ta=True, beta=1.0, defer=direct_all)
+            if st is not None:
+                K.gemm(dgsums[d], st, dw_ih[:, Fx:], ta=True, beta=1.0, defer=direct_all)
+            if T > 1:
+                y2 = y.view(T * B, ndir * H)
+                if d == 0:
+                    _gh(dgd[B:], y2[:(T - 1) * B, :H], C=dw_hh, ta=True, beta=1.0, defer=direct_all)
+                else:
+                    _gh(dgd[:(T - 1) * B], y2[B:, H:2 * H], C=dw_hh, ta=True, beta=1.0, defer=direct_all)
+            src, rows = (dgsums[d], B) if want_sum else (dgs[d].view(T * B, H4), T * B)
+            if direct:
+                K.col_sum(src.view(rows, H4), tg[2])
+                K.col_sum(src.view(rows, H4), tg[3])
+                outs += [None, None, None, None]
+                continue
+            db = torch.zeros(H4, device=dev)
+            K.col_sum(src.view(rows, H4), db)
+            outs += [dw_ih, dw_hh, db, db.clone()]
+    dx = dx2.view(T, B, Fx) if dx2 is not None else None
+    return (dx, None, None, dstatic) + tuple(outs)
+
+
+LSTMSeqFn._backward16 = staticmethod(_lstm_backward16)
 
 
 # --------------------------------------------------------------------------------------

@@ -185,7 +185,8 @@ int ag_gemm(const float* A, int lda, int ta, const float* B, int ldb, int tb, fl
 
 /* column sums: out[n] = (accumulate ? out[n] : 0) + sum_m X[m, n]   (Linear bias gradient; two-stage through the bound
  * workspace, or one row block per column when none is bound) */
-int ag_col_sum(const float* X, int ldx, float* out, int M, int N, int accumulate, void* stream);
+int ag_col_sum(const void* X, int x_bf16 /* X stored as bfloat16, ldx in 2-byte elements */, int ldx, float* out, int M, int N,
+               int accumulate, void* stream);
 
 /* ---------------------------------------------------------------------------
  * LSTM cell pointwise step (NN.LSTMCell / NN.LSTM, audiogan.py:380,440-442,498):
@@ -251,8 +252,11 @@ int64_t ag_gemm_ws_numel(int M, int N, int K, int act);
 /* Batched 2-D transpose through LDS: out[b][j][i] = in[b][i][j] for i < R, j < Cc; in element (b,i,j) at in + b*ibs + i*irs + j,
  * out element (b,j,i) at out + b*obs + j*ors + i (inner index contiguous on both sides).  The critic's conv features
  * [B,C,T'] -> time-major [T',B,C] for the biLSTM (audiogan.py:542) and the gradient's way back. */
-int ag_transpose_batched(const float* in, int64_t ibs, int64_t irs, float* out, int64_t obs, int64_t ors, int B, int R,
-                         int Cc, void* stream);
+/* (round 4) in_bf16 / out_bf16: that side is stored as bfloat16 (strides in elements of its own type; fp32 -> bf16 rounds to
+ * nearest even): in AG_PREC_BF16 mode with bf16 storage the time-major features are written as bf16, the operand type of
+ * ag_gemm_h, and their gradient comes back as bf16 */
+int ag_transpose_batched(const void* in, int in_bf16, int64_t ibs, int64_t irs, void* out, int out_bf16, int64_t obs,
+                         int64_t ors, int B, int R, int Cc, void* stream);
 
 /* Input assembly, one launch each (round 4; replaces T.cat / expand / transpose / + on the iteration path).
  * ag_build_zc: zc[t,b,:] = [z[b,t,:ns] | c[b,:es]], the non-recurrent part of the Generator front's LSTM input
@@ -265,13 +269,33 @@ int ag_transpose_batched(const float* in, int64_t ibs, int64_t irs, float* out, 
  * 1024 -> 1, :410,:445).  ag_rowdot_fwd: y[m*ldy] = x[m,:K] . w + bias[0] (bias may be NULL).  ag_rowdot_bwd, one pass over
  * x: dx[m,k] = dy[m*lddy] * w[k] (times LeakyReLU'(x[m,k]) when gate: x is then the SAVED OUTPUT of the LeakyReLU below;
  * dx may be NULL), and when dw != NULL: dw[k] (+)= sum_m dy[m] x[m,k], db[0] (+)= sum_m dy[m] with db == dw + K (one
- * [K+1] gradient row), two-stage through a bound workspace of ag_rowdot_bwd_ws_numel floats (deferrable). */
-int ag_rowdot_fwd(const float* x, int ldx, const float* w, const float* bias, float* y, int64_t ldy, int M, int K,
+ * [K+1] gradient row), two-stage through a bound workspace of ag_rowdot_bwd_ws_numel floats (deferrable).
+ * x_bf16 / h16: x (and dx) are stored as bfloat16, pitches in 2-byte elements (the bf16-storage path of AG_PREC_BF16). */
+int ag_rowdot_fwd(const void* x, int x_bf16, int ldx, const float* w, const float* bias, float* y, int64_t ldy, int M, int K,
                   void* stream);
 int64_t ag_rowdot_bwd_ws_numel(int M, int K);
-int ag_rowdot_bwd(const float* dy, int64_t lddy, const float* x, int ldx, const float* w, float* dx, int lddx, float* dw,
+int ag_rowdot_bwd(const float* dy, int64_t lddy, const void* x, int ldx, const float* w, void* dx, int lddx, int h16, float* dw,
                   float* db, int accumulate, int M, int K, int gate, float slope, void* stream);
 int ag_build_zc(const float* z, const float* c, float* zc, int B, int T, int ns, int es, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * GEMM on operands STORED as bfloat16 (BASELINE configs[2]; csrc/gemm_bf16s.hip):
+ *   C[M,N] = act(alpha * op(A) op(B) + beta * C + bias + res), fp32 accumulation, output as fp32 (C) and / or bf16 (C16)
+ * A / B: bfloat16 bit patterns; ta / tb as ag_gemm.  Tiles go global -> LDS by LDS-DMA (no convert, half the bytes of the
+ * fp32-operand kernel); k-strided operands (ta = 1, tb = 0: weight gradients, the weight of a data gradient) are read
+ * with the transposed LDS read of gfx950.  res (fp32) or res16 (bf16): residual, or with AG_ACT_LEAKY_GATE the saved
+ * activation whose derivative scales the result; gate16 (bf16, optional): a saved LeakyReLU output applied AFTER bias /
+ * res (a residual layer's backward: (W^T da + da) gated by the layer below).  Shapes: ag_gemm_h_ok (K % 64 == 0, leading
+ * dimensions % 8 == 0, row counts % 8 == 0 for k-strided operands, 16-byte aligned operands).  Split-K (fp32 output, plain
+ * epilogue) through a bound workspace of ag_gemm_h_ws_numel floats; its second stage is deferrable.
+ * ag_to_bf16_2d: dst[r,c] = bf16(src[r,c]) for a pitched [rows <= 65535, cols] block (weights -> their bf16 image).
+ * ------------------------------------------------------------------------- */
+int ag_gemm_h_ok(int M, int N, int K, int ta, int tb, int lda, int ldb);
+int64_t ag_gemm_h_ws_numel(int M, int N, int K, int act, int has_c16);
+int ag_gemm_h(const uint16_t* A, int lda, int ta, const uint16_t* B, int ldb, int tb, float* C, int ldc, uint16_t* C16,
+              int ldc16, int M, int N, int K, float alpha, float beta, const float* bias, const float* res, int ldres,
+              const uint16_t* res16, int ldres16, const uint16_t* gate16, int ldgate16, int act, float slope, void* stream);
+int ag_to_bf16_2d(const float* src, int64_t ld_src, uint16_t* dst, int64_t ld_dst, int rows, int cols, void* stream);
 int ag_critic_batch(const float* xa, int64_t xa_ld, const float* na, int64_t na_ld, int nA, const float* xb,
                     int64_t xb_ld, const float* nb, int64_t nb_ld, int nB, int L, float* x_out,
                     const int64_t* lenA_i64, const int64_t* lenB_i64, const int32_t* prods_host, int nl,
@@ -347,7 +371,9 @@ int ag_lstm_seq_bwd(const float* const* gates, const float* const* whh, const fl
 int ag_persist_debug(int64_t timeout_ticks, int mute_block);
 int ag_lstm_persist_ok(int B, int H, int ndir, int n_cu);
 int64_t ag_lstm_persist_ws_bytes(int B, int H, int ndir);
-int ag_lstm_seq_fwd_persist(float* const* pre, const float* const* whh, float* const* c_all, float* y,
+/* (round 4) y_bf16: the layer output y is WRITTEN as bfloat16 (y then addresses 2-byte elements) - the operand type of the
+ * products that consume it (ag_gemm_h) */
+int ag_lstm_seq_fwd_persist(float* const* pre, const float* const* whh, float* const* c_all, void* y, int y_bf16,
                             const int64_t* valid_i64, const float* const* static_pre, void* ws, int64_t ws_bytes,
                             int T, int B, int H, int ndir, int n_cu, void* stream);
 
@@ -357,11 +383,14 @@ int ag_lstm_seq_fwd_persist(float* const* pre, const float* const* whh, float* c
  * ndir * ceil(B/16) * H/32 <= n_cu (ag_lstm_persist_bwd_ok); `ws` >= 256 B + 8 KiB, laid out as above.  Tensors as for
  * ag_lstm_seq_bwd (no dhbuf/dcbuf: the state stays in registers). */
 int ag_lstm_persist_bwd_ok(int B, int H, int ndir, int n_cu);
-/* (round 4) dgsum: optional table of ndir [B,4H] outputs, the sum over time of dgates (what the biases and a time-invariant
+/* (round 4) dy_bf16: dy is stored as bfloat16; dg16: optional table of ndir [T,B,4H] bfloat16 outputs, dgates rounded - the
+ * operand type of ag_gemm_h for the weight / input gradient products (dgates itself stays fp32: it is the exchange buffer).
+ * dgsum: optional table of ndir [B,4H] outputs, the sum over time of dgates (what the biases and a time-invariant
  * input see), accumulated in registers by the thread that produces each (clip, gate) pair - no separate pass over dgates */
 int ag_lstm_seq_bwd_persist(const float* const* gates, const float* const* whh, const float* const* c_all,
-                            const float* dy, float* const* dgates, float* const* dgsum, const int64_t* valid_i64,
-                            void* ws, int64_t ws_bytes, int T, int B, int H, int ndir, int n_cu, void* stream);
+                            const void* dy, int dy_bf16, float* const* dgates, float* const* dgsum, uint16_t* const* dg16,
+                            int dg16_ld /* row pitch of dg16 in elements, >= 4H */, const int64_t* valid_i64, void* ws,
+                            int64_t ws_bytes, int T, int B, int H, int ndir, int n_cu, void* stream);
 
 /* The Generator front's whole frame loop (audiogan.py:428-460, one LSTMCell layer + tanh(proj) fed back) as ONE
  * persistent launch with every weight resident in registers (csrc/lstm_persist.hip).  gates [T,B,4S]: in = the z / c

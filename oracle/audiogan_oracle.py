@@ -143,12 +143,40 @@ class _RoundBwd(torch.autograd.Function):
         return _rnd(g)
 
 
+# bf16 STORAGE (round 4): on top of the rounded contractions, the critic's sequence path - time-major conv features,
+# biLSTM output, the activations of the heads - and the gradients flowing back through those tensors are STORED as
+# bfloat16.  A stored tensor is rounded where it is written, so every later use sees the rounded value: the residual add
+# of `Residual`, the column sums behind the bias gradients and the dy entering the recurrent backward, besides the
+# products, whose operands were rounded anyway.  ``_st`` marks such a tensor: value rounded forward, gradient rounded back.
+BF16_STORE = [False]
+
+
+def _st(x):
+    if BF16[0] and BF16_STORE[0]:
+        return _RoundBwd.apply(_RoundFwd.apply(x))
+    return x
+
+
+def _st_act(pre, act):
+    """a stored activation act(pre): the VALUE is rounded where it is written (after the activation), the GRADIENT where it
+    is written (the gradient of the pre-activation, i.e. after the activation's derivative was applied)"""
+    if BF16[0] and BF16_STORE[0]:
+        return _RoundFwd.apply(act(_RoundBwd.apply(pre)))
+    return act(pre)
+
+
 class bf16_mode(object):
     """``with O.bf16_mode(): ...`` - F.conv1d / F.conv_transpose1d / F.linear round their operands (and the gradient
     entering their backward); nn.LSTMCell and the LSTM layers of ``dynamic_rnn`` are computed from F.linear products
-    so that their operands are rounded the same way."""
+    so that their operands are rounded the same way.  ``store=True``: additionally the tensors marked ``_st`` (the
+    critic's sequence path) are rounded where they are produced, value and gradient - the bf16-storage contract."""
+
+    def __init__(self, store=False):
+        self.store = bool(store)
 
     def __enter__(self):
+        self._saved_store = BF16_STORE[0]
+        BF16_STORE[0] = self.store
         self._saved = (F.conv1d, F.conv_transpose1d, F.linear, nn.LSTMCell.forward, BF16[0])
         o_conv, o_convt, o_lin = F.conv1d, F.conv_transpose1d, F.linear
 
@@ -176,6 +204,7 @@ class bf16_mode(object):
         return self
 
     def __exit__(self, *exc):
+        BF16_STORE[0] = self._saved_store
         F.conv1d, F.conv_transpose1d, F.linear, nn.LSTMCell.forward, BF16[0] = self._saved
         torch.nn.functional.conv1d, torch.nn.functional.conv_transpose1d = F.conv1d, F.conv_transpose1d
         torch.nn.functional.linear = F.linear
@@ -267,7 +296,7 @@ class Residual(nn.Module):
         self.relu = nn.LeakyReLU()
 
     def forward(self, x):
-        return self.relu(self.linear(x) + x)
+        return _st_act(self.linear(x) + x, self.relu)
 
 
 class dense_res_bottleneck(nn.Module):
@@ -430,16 +459,18 @@ class Discriminator(nn.Module):
             a = a * length_mask((b, a.size(2)), nframes).unsqueeze(1)
             acts.append(a)
             act_lens.append(nframes)
-        a = a.permute(0, 2, 1)
+        a = _st(a.permute(0, 2, 1))                  # (bf16 storage: the time-major features / their gradient)
         n = a.size(1)
         seq = torch.cat([a, c.unsqueeze(1).expand(b, n, es)], 2).permute(1, 0, 2)
         out, _ = dynamic_rnn(self.rnn, seq, nframes, init)
-        out = out.permute(1, 0, 2)
+        out = _st(out.permute(1, 0, 2))              # (the biLSTM output / the dy entering its backward)
         n = out.size(1)
         # the reference uses .view on the permuted tensor (old torch returned a
         # contiguous tensor from pad_packed_sequence+index); reshape is the same data
         rows = out.reshape(b * n, ss)
-        logits = self.classifier(self.residual_net(rows)).view(b, n)
+        cl = self.classifier.module
+        hmid = _st_act(cl[0](self.residual_net(rows)), cl[1])        # (= self.classifier(...), the hidden layer marked as stored)
+        logits = cl[2](hmid).view(b, n)
         return logits, acts, act_lens, nframes
 
 

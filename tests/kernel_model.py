@@ -368,7 +368,7 @@ def gfront_persist_ok(B, S, fs, dev):
     return False
 
 
-def bct_to_tbc(x, out=None):
+def bct_to_tbc(x, out=None, out_dtype=None):
     r = x.permute(2, 0, 1).contiguous()
     if out is not None:
         out.copy_(r)
@@ -376,7 +376,7 @@ def bct_to_tbc(x, out=None):
     return r
 
 
-def tbc_to_bct(x, out=None):
+def tbc_to_bct(x, out=None, out_dtype=None):
     r = x.permute(1, 2, 0).contiguous()
     if out is not None:
         out.copy_(r)
@@ -395,6 +395,11 @@ class deferred_reduces(object):
 
     def __exit__(self, *exc):
         return False
+
+
+def bf16_storage():
+    """(the CPU model keeps fp32 storage)"""
+    return False
 
 
 def reduces_outer():

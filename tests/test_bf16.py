@@ -11,7 +11,11 @@ DECLARED TOLERANCE:
     (sums over batch and time in which such flips do not cancel) 2e-2 in relative L2 norm and 5e-2 of the largest
     magnitude elementwise (the worst of up to a million elements); the weight-norm gain gradients, cancelling projections
     two orders of magnitude smaller, 5e-2 in both;
-  * vs the fp32 oracle: 3e-2 in relative L2 norm (what bf16 operands cost; informative)."""
+  * vs the fp32 oracle: 3e-2 in relative L2 norm (what bf16 operands cost; informative).
+  * bf16 STORAGE (round 4): where the critic's sequence path is kept as bfloat16 in HBM (Discriminator.stores_bf16) the
+    oracle runs ``bf16_mode(store=True)``, which rounds those tensors - value and gradient - where they are written; the
+    same tolerances apply.  ag_gemm_h alone: fp32 output within 1e-4 of the output scale of a float64 product of the same
+    bf16 operands, a bf16 output within one bf16 ulp (2^-8 relative) of that product."""
 import os
 
 import numpy as np
@@ -151,7 +155,7 @@ def test_networks_bf16_vs_rounded_oracle(K, bf16):
     stop = torch.zeros(B, T, dtype=torch.long)
     x32 = go(z=z, c=c, stop=stop)[0]
     l32 = do(x32, lens, c)[0]
-    with O.bf16_mode():
+    with O.bf16_mode(store=d.stores_bf16(B, 'cuda')):
         xo = go(z=z, c=c, stop=stop)[0]
         xo.retain_grad()
         lo, actso, _, _ = do(xo, lens, c)
@@ -193,7 +197,8 @@ def test_train_step_bf16_vs_rounded_oracle(K, bf16):
     opt_do, opt_go = O.make_optimizer(list(do.parameters()), 'adam', 1e-4), O.make_optimizer(list(go.parameters()), 'adam', 1e-4)
     opt_d, opt_g = optim.make_optimizer(list(d.parameters()), 'adam', 1e-4), optim.make_optimizer(list(g.parameters()), 'adam', 1e-4)
     cu = lambda t: t.cuda()  # noqa: E731
-    with O.bf16_mode():
+    assert d.stores_bf16(2 * B, 'cuda') == d.stores_bf16(B, 'cuda')
+    with O.bf16_mode(store=d.stores_bf16(B, 'cuda')):
         lo, cdo, cgo = O.d_step(go, do, opt_do, real, rl, c, z, nr, nf, 1.0, stop=stop)
         lo2, fo, _ = O.g_step(go, do, opt_go, c, z, nf, 0.1, stop=stop)
     l, cd, cg = train.d_step(g, d, opt_d, cu(real), cu(rl), cu(c), cu(z), cu(nr), cu(nf), 1.0, check=True)
@@ -273,3 +278,159 @@ def test_gemm_f32x3_experiment(K, shape, ta, tb):
     out32 = torch.empty(M, N).cuda()
     K.gemm(A.cuda(), B.cuda(), out32, ta=ta, tb=tb)
     assert not torch.equal(out, out32), 'the mode did not take the split-bf16 kernel'
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# bf16 STORAGE (round 4): ag_gemm_h on operands stored as bfloat16, and the storage variants of the kernels around it
+# ---------------------------------------------------------------------------------------------------------------------
+def _b16(*shape, gen, scale=1.0):
+    return (torch.randn(*shape, generator=gen) * scale).to(torch.bfloat16)
+
+
+@pytest.mark.parametrize('shape', [(8192, 1024, 1024), (2048, 512, 2048), (384, 200, 128), (128, 128, 64), (16384, 2048, 512)])
+@pytest.mark.parametrize('ta,tb', [(False, True), (False, False), (True, False), (True, True)])
+def test_gemm_h_all_operand_layouts(K, shape, ta, tb):
+    """k-contiguous operands through ds_read_b128, k-strided ones through the transposed LDS read, LDS-DMA staging with both
+    swizzles: every (ta, tb), fp32 and bf16 outputs, against a float64 product of the same bf16 values"""
+    M, N, Kd = shape
+    gen = torch.Generator().manual_seed(M + 3 * N + 7 * Kd + 2 * ta + tb)
+    a = _b16(*((Kd, M) if ta else (M, Kd)), gen=gen)
+    b = _b16(*((N, Kd) if tb else (Kd, N)), gen=gen)
+    ref = (a.double().t() if ta else a.double()) @ (b.double().t() if tb else b.double())
+    A, B = a.cuda(), b.cuda()
+    assert K.gemm_h_ok(A, B, ta, tb)
+    c32 = torch.full((M, N), float('nan')).cuda()
+    c16 = torch.full((M, N), float('nan'), dtype=torch.bfloat16).cuda()
+    K.gemm_h(A, B, C=c32, C16=c16, ta=ta, tb=tb)
+    scale = float(ref.abs().max())
+    assert float((c32.cpu().double() - ref).abs().max()) <= 1e-4 * scale
+    got16, want16 = c16.float().cpu().double(), ref.float().bfloat16().double()
+    assert float((got16 - want16).abs().max()) <= 2.0 ** -7 * scale       # one bf16 ulp at the top of the range
+    assert float(((got16 - want16).abs() > 0).double().mean()) < 0.02       # (ties / last-bit sums only)
+
+
+def test_gemm_h_epilogues_views_and_split_k(K):
+    """bias, fp32 / bf16 residuals, LeakyReLU, the gate forms, pitched operand views and outputs, and the split-K weight
+    gradient (beta = 1, deferred second stage) - the forms the critic's heads and biLSTM use"""
+    gen = torch.Generator().manual_seed(77)
+    M, N, Kd = 1024, 512, 1024
+    a, w = _b16(M, Kd, gen=gen).cuda(), _b16(N, Kd, gen=gen, scale=0.05).cuda()
+    bias = torch.randn(N, generator=gen).cuda()
+    res16 = _b16(M, N, gen=gen).cuda()
+    res32 = torch.randn(M, N, generator=gen).cuda()
+    lin = a.double() @ w.double().t() + bias.double()
+    # forward of a residual layer: LeakyReLU(a W^T + b + res), bf16 out
+    y16 = torch.empty(M, N, dtype=torch.bfloat16).cuda()
+    K.gemm_h(a, w, C16=y16, tb=True, bias=bias, res=res16, act=K.ACT_LEAKY)
+    ref = F.leaky_relu(lin + res16.double(), 0.01)
+    assert float((y16.double() - ref.float().bfloat16().double()).abs().max()) <= 2.0 ** -7 * float(ref.abs().max())
+    # fp32 residual + fp32 out, into a pitched view
+    wide = torch.zeros(M, N + 24).cuda()
+    K.gemm_h(a, w, C=wide[:, 8:8 + N], tb=True, bias=bias, res=res32)
+    assert float((wide[:, 8:8 + N].double() - (lin + res32.double())).abs().max()) <= 1e-4 * float(lin.abs().max())
+    assert not wide[:, :8].any() and not wide[:, 8 + N:].any()
+    # data gradient of a residual layer: (da W + da) gated by the saved activation below; W read k-strided
+    da, sv = _b16(M, N, gen=gen).cuda(), _b16(M, N, gen=gen).cuda()
+    w2 = _b16(N, N, gen=gen, scale=0.05).cuda()
+    dp = torch.empty(M, N, dtype=torch.bfloat16).cuda()
+    K.gemm_h(da, w2, C16=dp, res=da, gate=sv)
+    ref = (da.double() @ w2.double() + da.double()) * torch.where(sv.double() > 0, 1.0, 0.01)
+    assert float((dp.double() - ref.float().bfloat16().double()).abs().max()) <= 2.0 ** -7 * float(ref.abs().max())
+    # ACT_LEAKY_GATE with the saved activation as `res`
+    K.gemm_h(da, w2, C16=dp, res=sv, act=K.ACT_LEAKY_GATE)
+    ref = (da.double() @ w2.double()) * torch.where(sv.double() > 0, 1.0, 0.01)
+    assert float((dp.double() - ref.float().bfloat16().double()).abs().max()) <= 2.0 ** -7 * float(ref.abs().max())
+    # weight gradient dW += dY^T X over 16384 rows: split-K, both operands k-strided column blocks of wider tensors
+    R = 16384
+    dy, x = _b16(R, 2 * N, gen=gen, scale=0.1).cuda(), _b16(R, 640, gen=gen).cuda()
+    dyv, xv = dy[:, N:], x[:, 64:576]
+    base = torch.randn(N, 612, generator=gen).cuda()
+    ref = base[:, :512].double() + dyv.double().t() @ xv.double()
+    assert K.lib.ag_gemm_h_ws_numel(N, 512, R, 0, 0) > 0
+    plain, deferred = base.clone(), base.clone()
+    K.gemm_h(dyv, xv, C=plain[:, :512], ta=True, beta=1.0)
+    with K.deferred_reduces():
+        K.gemm_h(dyv, xv, C=deferred[:, :512], ta=True, beta=1.0, defer=True)
+        torch.cuda.synchronize()
+        assert torch.equal(deferred, base), 'the deferred second stage ran before the flush'
+    torch.cuda.synchronize()
+    assert torch.equal(plain, deferred)
+    assert torch.equal(plain[:, 512:], base[:, 512:])
+    assert float((plain[:, :512].double() - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
+
+
+def test_bf16_storage_variants_of_the_small_kernels(K, bf16):
+    """transposes, rowdot forward / backward and column sums with bfloat16 on the storage side vs the fp32 forms"""
+    gen = torch.Generator().manual_seed(78)
+    B, Cc, T = 6, 40, 33
+    a = torch.randn(B, Cc, T, generator=gen).cuda()
+    t16 = K.bct_to_tbc(a, out_dtype=torch.bfloat16)
+    assert t16.dtype == torch.bfloat16 and torch.equal(t16, a.permute(2, 0, 1).contiguous().to(torch.bfloat16))
+    back = K.tbc_to_bct(t16, out_dtype=torch.float32)
+    assert torch.equal(back, t16.float().permute(1, 2, 0).contiguous())
+    M, Kd = 300, 512
+    x16 = _b16(M, Kd, gen=gen).cuda()
+    w, b1 = (torch.randn(1, Kd, generator=gen) * 0.05).cuda(), torch.randn(1, generator=gen).cuda()
+    y = torch.empty(M, 1).cuda()
+    K.rowdot_fwd(x16, w, b1, y)
+    ref = x16.double() @ rnd(w).double().t() + b1.double()
+    assert float((y.double() - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
+    dy = torch.randn(M, 1, generator=gen).cuda()
+    flat = torch.zeros(Kd + 1).cuda()
+    dw, db = flat[:Kd].view(1, Kd), flat[Kd:]
+    dx16 = torch.empty(M, Kd, dtype=torch.bfloat16).cuda()
+    K.rowdot_bwd(dy, x16, w, dx=dx16, dw=dw, db=db, gate=True)
+    g = rnd(dy).double()
+    refdx = (g * rnd(w).double()) * torch.where(x16.double() > 0, 1.0, 0.01)
+    assert float((dx16.double() - refdx.float().bfloat16().double()).abs().max()) <= 2.0 ** -7 * float(refdx.abs().max())
+    refdw = (g * x16.double()).sum(0)
+    assert float((dw.double().view(-1) - refdw).abs().max()) <= 1e-4 * float(refdw.abs().max())
+    assert abs(float(db) - float(dy.double().sum())) <= 1e-4 * float(dy.abs().sum())
+    out = torch.zeros(Kd).cuda()
+    K.col_sum(x16, out)
+    assert float((out.double() - x16.double().sum(0)).abs().max()) <= 1e-4 * float(x16.double().sum(0).abs().max())
+
+
+def test_critic_sequence_path_bf16_storage_vs_fp32_storage(K, bf16):
+    """the critic's classify() - time-major transpose, biLSTM (persistent launches writing y / reading dy as bf16, dgates'
+    bf16 copy), heads - on bf16 storage against the same precision mode on fp32 storage (AG_BF16_STORE off): logits and
+    every gradient inside the declared bf16 tolerance, and really on the bf16 kernels"""
+    import audiogan_amd as A
+    torch.manual_seed(41)
+    d = A.Discriminator(state_size=256, embed_size=16, num_layers=1, cnn_struct=[[7, 2, 16], [7, 2, 64]]).cuda()
+    B, Tq = 24, 64
+    gen = torch.Generator().manual_seed(42)
+    feats = torch.randn(B, 64, Tq, generator=gen).cuda()
+    c = torch.randn(B, 16, generator=gen).cuda()
+    n = torch.randint(10, Tq + 1, (B,), generator=gen).cuda()
+    n[0] = Tq
+    wl = torch.randn(B, Tq, generator=gen).cuda()
+    outs = []
+    old = K.BF16_STORE[0]
+    try:
+        for store in (False, True):
+            K.BF16_STORE[0] = store
+            assert d.stores_bf16(B, 'cuda') == store
+            for p in d.parameters():
+                p.grad = None
+            a = feats.clone().requires_grad_(True)
+            cc = c.clone().requires_grad_(True)
+            K.Profiler.start()
+            logits = d.classify(a, n, cc)
+            (logits * wl).sum().backward()
+            prof = K.Profiler.stop()
+            assert any(k.startswith('gemm_bf16s_kernel') for k in prof) == store, sorted(prof)
+            outs.append((logits.detach().clone(), a.grad.clone(), cc.grad.clone(),
+                         {k: p.grad.clone() for k, p in d.named_parameters() if p.grad is not None}))
+    finally:
+        K.BF16_STORE[0] = old
+    (l0, ga0, gc0, p0), (l1, ga1, gc1, p1) = outs
+    assert l1.dtype == torch.float32
+    close_bf16(l1, l0, 'logits')
+    close_bf16(ga1, ga0, 'd features', elem=5e-2, l2=2e-2)
+    close_bf16(gc1, gc0, 'd c', elem=5e-2, l2=2e-2)
+    assert set(p0) == set(p1)
+    for k in p0:
+        if k.split('.')[-1].startswith('bias') and k.endswith('_v'):
+            continue
+        close_bf16(p1[k], p0[k], k, elem=5e-2, l2=5e-2 if k.endswith('_g') else 2e-2)
