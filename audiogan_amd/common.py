@@ -294,6 +294,16 @@ def prepare_groups(groups):
             gr._mark_fresh(key)
 
 
+def flat_offsets(numels, align=4):
+    """offsets of tensors packed into one flat fp32 buffer, each starting on a 16-byte boundary (``align`` elements): the
+    optimiser and gradient-norm kernels then move every tensor with 16-byte accesses.  Returns (offsets, total)."""
+    offs, o = [], 0
+    for n in numels:
+        offs.append(o)
+        o += (int(n) + align - 1) // align * align
+    return offs, o
+
+
 def _zeros_like_list(tensors):
     """one flat zero buffer, viewed as the given shapes (one memset instead of many)"""
     n = sum(t.numel() for t in tensors)

@@ -42,15 +42,23 @@ struct GemmH {
   float alpha, beta, slope;
 };
 
-__device__ __forceinline__ int h_kc_slot(int r, int c) { return r * 128 + ((c ^ ((r >> 1) & 7)) << 4); }
+// KC image, rows of 2 * BK bytes: BK = 64: chunk c of row r in slot c ^ ((r >> 1) & 7);  BK = 32 (64-byte rows): slot c ^ ((r >> 2) & 3)
+template <int BK>
+__device__ __forceinline__ int h_kc_slot(int r, int c) {
+  return BK == 64 ? r * 128 + ((c ^ ((r >> 1) & 7)) << 4) : r * 64 + ((c ^ ((r >> 2) & 3)) << 4);
+}
 __device__ __forceinline__ int h_ks_f(int k) { return ((k & 3) << 2) | ((k >> 2) & 3); }
 __device__ __forceinline__ float h_bf(unsigned short v) { return __uint_as_float((unsigned)v << 16); }
 
-template <int TA, int TB>
-__global__ __launch_bounds__(256) void gemm_bf16s_kernel(const GemmH p) {
-  constexpr int BM = 128, BN = 128, BK = 64, IMG = 128 * 128;      // bytes per operand image (either form)
+// BK: k per stage (64 or 32);  NBUF: LDS stages (2: the DMA of tile i+1 under the MFMAs of tile i;  1: one stage, 32 KiB (BK
+// 64) per workgroup - latency is hidden by co-resident workgroups instead, four per CU)
+template <int TA, int TB, int BK, int NBUF, int WPE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void gemm_bf16s_kernel(const GemmH p) {
+  constexpr int BM = 128, BN = 128, IMG = 128 * BK * 2;            // bytes per operand image (either form)
+  constexpr int NCH = IMG / 16 / 256;                               // 16-byte chunks per thread, operand and stage
+  constexpr int KCC = BK / 8;                                       // chunks per row of the KC image
   constexpr bool AKS = TA == 1, BKS = TB == 0;
-  extern __shared__ __attribute__((aligned(16))) char sm[];        // 2 buffers x (A image + B image) = 64 KiB
+  extern __shared__ __attribute__((aligned(16))) char sm[];        // NBUF x (A image + B image)
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l31 = lane & 31, h = lane >> 5;
   const int wm0 = (wid >> 1) * 64, wn0 = (wid & 1) * 64;
@@ -67,21 +75,21 @@ __global__ __launch_bounds__(256) void gemm_bf16s_kernel(const GemmH p) {
   const int bz = blockIdx.z;
   const int m0 = by * BM, n0 = bx * BN;
 
-  // per-lane DMA sources at k = 0: four 16-byte chunks per operand per tile
-  const unsigned short* asrc[4];
-  const unsigned short* bsrc[4];
+  // per-lane DMA sources at k = 0
+  const unsigned short* asrc[NCH];
+  const unsigned short* bsrc[NCH];
 #pragma unroll
-  for (int it = 0; it < 4; ++it) {
+  for (int it = 0; it < NCH; ++it) {
     const int j = tid + 256 * it;
     if (!AKS) {
-      const int r = j >> 3, c = (j & 7) ^ ((r >> 1) & 7);
+      const int r = j / KCC, c = (j % KCC) ^ (BK == 64 ? ((r >> 1) & 7) : ((r >> 2) & 3));
       asrc[it] = p.A + (int64_t)min(m0 + r, p.M - 1) * p.lda + 8 * c;
     } else {
       const int k = j >> 4, ch = (j & 15) ^ h_ks_f(k);
       asrc[it] = p.A + (int64_t)k * p.lda + min(m0 + 8 * ch, p.M - 8);
     }
     if (!BKS) {
-      const int r = j >> 3, c = (j & 7) ^ ((r >> 1) & 7);
+      const int r = j / KCC, c = (j % KCC) ^ (BK == 64 ? ((r >> 1) & 7) : ((r >> 2) & 3));
       bsrc[it] = p.B + (int64_t)min(n0 + r, p.N - 1) * p.ldb + 8 * c;
     } else {
       const int k = j >> 4, ch = (j & 15) ^ h_ks_f(k);
@@ -94,7 +102,7 @@ __global__ __launch_bounds__(256) void gemm_bf16s_kernel(const GemmH p) {
     char* As = sm + buf * 2 * IMG;
     char* Bs = As + IMG;
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
+    for (int it = 0; it < NCH; ++it) {
       const int wbase = (wid * 64 + 256 * it) * 16;          // wave-uniform LDS byte offset of this instruction
       __builtin_amdgcn_global_load_lds(H_GLB_AS(asrc[it] + (int64_t)k0 * astep), H_LDS_AS(As + wbase), 16, 0, 0);
       __builtin_amdgcn_global_load_lds(H_GLB_AS(bsrc[it] + (int64_t)k0 * bstep), H_LDS_AS(Bs + wbase), 16, 0, 0);
@@ -112,22 +120,14 @@ __global__ __launch_bounds__(256) void gemm_bf16s_kernel(const GemmH p) {
   // transposed-read lane roles (KS operands): lane 4q + p of a 16-lane group addresses block row q, columns 4p .. 4p+3
   const int tq = (lane & 15) >> 2, tp = lane & 3, tg = (lane >> 4) & 1;
 
-  const int kbeg = bz * p.kchunk;
-  const int kend = (kbeg + p.kchunk < p.K) ? kbeg + p.kchunk : p.K;
-  stage(kbeg, 0);
-  __syncthreads();
-  int buf = 0;
-  for (int k0 = kbeg; k0 < kend; k0 += BK) {
-    if (k0 + BK < kend) stage(k0 + BK, buf ^ 1);
-    const char* As = sm + buf * 2 * IMG;
-    const char* Bs = As + IMG;
+  auto mfma_tile = [&](const char* As, const char* Bs) {
 #pragma unroll
     for (int s_ = 0; s_ < BK / 16; ++s_) {
       hbf16x8 av[2], bv[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         if (!AKS) {
-          av[i] = *reinterpret_cast<const hbf16x8*>(As + h_kc_slot(wm0 + 32 * i + l31, 2 * s_ + h));
+          av[i] = *reinterpret_cast<const hbf16x8*>(As + h_kc_slot<BK>(wm0 + 32 * i + l31, 2 * s_ + h));
         } else {
           hs16x4 v4[2];
 #pragma unroll
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void gemm_bf16s_kernel(const GemmH p) {
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         if (!BKS) {
-          bv[j] = *reinterpret_cast<const hbf16x8*>(Bs + h_kc_slot(wn0 + 32 * j + l31, 2 * s_ + h));
+          bv[j] = *reinterpret_cast<const hbf16x8*>(Bs + h_kc_slot<BK>(wn0 + 32 * j + l31, 2 * s_ + h));
         } else {
           hs16x4 v4[2];
 #pragma unroll
@@ -160,10 +160,102 @@ __global__ __launch_bounds__(256) void gemm_bf16s_kernel(const GemmH p) {
         for (int j = 0; j < 2; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
     }
-    // (keeps the barrier - and its vmcnt(0) on the next tile's DMA - behind ALL of this tile's MFMAs)
-    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  const int kbeg = bz * p.kchunk;
+  const int kend = (kbeg + p.kchunk < p.K) ? kbeg + p.kchunk : p.K;
+  if (NBUF == 2) {
+    stage(kbeg, 0);
     __syncthreads();
-    buf ^= 1;
+    int buf = 0;
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+      if (k0 + BK < kend) stage(k0 + BK, buf ^ 1);
+      mfma_tile(sm + buf * 2 * IMG, sm + buf * 2 * IMG + IMG);
+      // (keeps the barrier - and its vmcnt(0) on the next tile's DMA - behind ALL of this tile's MFMAs)
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();
+      buf ^= 1;
+    }
+  } else {
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+      stage(k0, 0);
+      __syncthreads();                    // vmcnt(0) + barrier: the tile is in LDS
+      mfma_tile(sm, sm + IMG);
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();                    // every wave is done reading before the next tile overwrites it
+    }
+  }
+
+  // ---- epilogue.  Full tiles with 16-byte aligned outputs go through LDS: the accumulators (column per lane) are written as a
+  // [64 rows][128] fp32 image, 64 rows at a time, and read back row-wise, so that every lane stores 4 consecutive columns -
+  // 256 contiguous bytes of bf16 (512 of fp32) per 32 lanes instead of 2-byte (4-byte) pieces; bias / residual / gate are
+  // read the same way.  (A 16384 x 2048 x 512 projection writes 4x the bytes it reads: its store pattern IS its speed.)
+  const bool fast = p.ksplit == 1 && m0 + BM <= p.M && n0 + BN <= p.N &&
+                    (!p.C || ((p.ldc & 3) == 0 && ((uintptr_t)p.C & 15) == 0)) &&
+                    (!p.C16 || ((p.ldc16 & 3) == 0 && ((uintptr_t)p.C16 & 7) == 0)) &&
+                    (!p.res || ((p.ldres & 3) == 0 && ((uintptr_t)p.res & 15) == 0)) &&
+                    (!p.res16 || ((p.ldres16 & 3) == 0 && ((uintptr_t)p.res16 & 7) == 0)) &&
+                    (!p.gate16 || ((p.ldgate16 & 3) == 0 && ((uintptr_t)p.gate16 & 7) == 0)) &&
+                    (!p.bias || ((uintptr_t)p.bias & 15) == 0);
+  if (fast) {
+    typedef unsigned u32x2e __attribute__((ext_vector_type(2)));
+    float* Ct = reinterpret_cast<float*>(sm);                 // [64][128] fp32 = 32 KiB
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      if ((wid >> 1) == half) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int e = 0; e < 16; ++e)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+              Ct[(32 * i + (e & 3) + 8 * (e >> 2) + 4 * h) * 128 + wn0 + 32 * j + l31] = acc[i][j][e];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int idx = tid + 256 * it;
+        const int r = idx >> 5, c4 = (idx & 31) * 4;
+        const int64_t row = m0 + 64 * half + r;
+        const int col = n0 + c4;
+        f32x4 v = *reinterpret_cast<const f32x4*>(Ct + r * 128 + c4);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] *= p.alpha;
+        if (p.beta != 0.f) {
+          const f32x4 o = *reinterpret_cast<const f32x4*>(p.C + row * p.ldc + col);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] += p.beta * o[q];
+        }
+        if (p.bias) {
+          const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + col);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] += b[q];
+        }
+        f32x4 rr = {0.f, 0.f, 0.f, 0.f};
+        const bool hr = p.res != nullptr || p.res16 != nullptr;
+        if (p.res) rr = *reinterpret_cast<const f32x4*>(p.res + row * p.ldres + col);
+        if (p.res16) {
+          const u32x2e w = *reinterpret_cast<const u32x2e*>(p.res16 + row * p.ldres16 + col);
+          rr = f32x4{__uint_as_float(w[0] << 16), __uint_as_float(w[0] & 0xFFFF0000u), __uint_as_float(w[1] << 16),
+                     __uint_as_float(w[1] & 0xFFFF0000u)};
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = ag_res_act(v[q], hr, rr[q], p.act, p.slope);
+        if (p.gate16) {
+          const u32x2e w = *reinterpret_cast<const u32x2e*>(p.gate16 + row * p.ldgate16 + col);
+          const float g0 = __uint_as_float(w[0] << 16), g1 = __uint_as_float(w[0] & 0xFFFF0000u),
+                      g2 = __uint_as_float(w[1] << 16), g3 = __uint_as_float(w[1] & 0xFFFF0000u);
+          if (!(g0 > 0.f)) v[0] *= p.slope;
+          if (!(g1 > 0.f)) v[1] *= p.slope;
+          if (!(g2 > 0.f)) v[2] *= p.slope;
+          if (!(g3 > 0.f)) v[3] *= p.slope;
+        }
+        if (p.C) *reinterpret_cast<f32x4*>(p.C + row * p.ldc + col) = v;
+        if (p.C16) *reinterpret_cast<u32x2e*>(p.C16 + row * p.ldc16 + col) = u32x2e{ag_pack_bf16(v[0], v[1]), ag_pack_bf16(v[2], v[3])};
+      }
+      __syncthreads();
+    }
+    return;
   }
 
   // C layout of a 32x32 tile: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * h
@@ -195,11 +287,30 @@ __global__ __launch_bounds__(256) void gemm_bf16s_kernel(const GemmH p) {
     }
 }
 
+// variant of the staging structure (AG_GEMMH_VARIANT, for A/B runs): 1 (default) = BK 64, ONE stage (32 KiB) and registers
+// capped at 128: four workgroups per CU hide each other's DMA latency;  0 = BK 64, two stages (64 KiB: 2 workgroups per CU,
+// the DMA of tile i+1 under the MFMAs of tile i - 16 MFMAs of 32 cycles do not cover an HBM round trip);  2 = BK 32, two
+// stages (32 KiB), 4 per CU;  3 / 4 = as 1 / 2 with the registers uncapped (3 per CU).
+// Measured over the critic's 11 product shapes (tools/prof_gemm_h.py, sum of the launch times): 0: 830 us, 1: 686, 2: 764,
+// 3: 807, 4: 859 (the fp32-operand bf16 kernel: 885).
+static const int g_h_variant = [] { const char* e = getenv("AG_GEMMH_VARIANT"); return e ? atoi(e) : 1; }();
+
+template <int TA, int TB, int BK, int NBUF, int WPE>
+static void launch_h2(const GemmH& p, dim3 grid, hipStream_t st) {
+  auto kern = gemm_bf16s_kernel<TA, TB, BK, NBUF, WPE>;
+  const int stage_bytes = NBUF * 2 * 128 * BK * 2;
+  const int lds = stage_bytes < 32 * 1024 ? 32 * 1024 : stage_bytes;       // (the epilogue's [64][128] fp32 image)
+  (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
+}
+
 template <int TA, int TB>
 static void launch_h(const GemmH& p, dim3 grid, hipStream_t st) {
-  auto kern = gemm_bf16s_kernel<TA, TB>;
-  (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-  hipLaunchKernelGGL(kern, grid, dim3(256), 64 * 1024, st, p);
+  if (g_h_variant == 1) launch_h2<TA, TB, 64, 1, 4>(p, grid, st);
+  else if (g_h_variant == 2) launch_h2<TA, TB, 32, 2, 4>(p, grid, st);
+  else if (g_h_variant == 3) launch_h2<TA, TB, 64, 1, 3>(p, grid, st);
+  else if (g_h_variant == 4) launch_h2<TA, TB, 32, 2, 3>(p, grid, st);
+  else launch_h2<TA, TB, 64, 2, 2>(p, grid, st);
 }
 
 static int h_pick_ksplit(int64_t tiles, int64_t mn, int K) {

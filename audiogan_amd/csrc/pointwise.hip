@@ -414,13 +414,29 @@ __global__ __launch_bounds__(256) void grad_norms_kernel(const ag_opt_desc* __re
   const ag_opt_desc d = descs[blockIdx.y];
   float* fpart = part + (int64_t)gridDim.y * OPT_CHUNKS;
   const int64_t slot = (int64_t)blockIdx.y * OPT_CHUNKS + blockIdx.x;
-  if ((int64_t)blockIdx.x * 256 >= d.n) {  // uniform per block
+  if ((int64_t)blockIdx.x * 256 >= d.n) {  // uniform per block (a longer tensor's 16-byte path needs no more chunks either)
     if (threadIdx.x == 0) { part[slot] = 0.f; fpart[slot] = __int_as_float(0); }
     return;
   }
   if (threadIdx.x == 0) fsh = 0;
   float s = 0.f;
   int f = 0;
+  // (a workgroup's elements and their order do not depend on the path: chunk c owns elements [256 c, 256 c + 256) of every
+  // stripe of 256 * gridDim.x; the 16-byte path reads the same elements four at a time when the tensor is aligned)
+  if ((((uintptr_t)d.grad) & 15) == 0 && (d.n & 3) == 0) {
+    const int64_t n4 = d.n >> 2;
+    const f32x4* g4 = reinterpret_cast<const f32x4*>(d.grad);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+      const f32x4 v = g4[i];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float g = v[e] * gscale;
+        s += g * g;
+        if (g != g) f |= AG_FLAG_NAN;
+        if (fabsf(g) > 1e5f) f |= AG_FLAG_BIG;
+      }
+    }
+  } else
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < d.n; i += (int64_t)gridDim.x * 256) {
     const float g = d.grad[i] * gscale;
     s += g * g;
@@ -520,21 +536,46 @@ __global__ __launch_bounds__(256) void opt_step_kernel(const ag_opt_desc* __rest
   if ((int64_t)blockIdx.x * 256 >= d.n) return;
   const bool do_clip = clip > 0.f && nr > clip;
   const float div = do_clip ? nr / clip : 1.f;  // reference: grad /= (norm / clip), audiogan.py:252
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < d.n; i += (int64_t)gridDim.x * 256) {
-    float g = d.grad[i] * gscale;
+  auto upd = [&](float gr, float& pv, float& m1, float& m2) {
+    float g = gr * gscale;
     if (do_clip) g = g / div;
     if (kind == AG_OPT_RMSPROP) {
-      const float sq = a1 * d.s1[i] + (1.f - a1) * g * g;
-      d.s1[i] = sq;
-      d.p[i] = d.p[i] - lr * (g / (sqrtf(sq) + eps));
+      m1 = a1 * m1 + (1.f - a1) * g * g;
+      pv = pv - lr * (g / (sqrtf(m1) + eps));
     } else {
-      const float m = a1 * d.s1[i] + (1.f - a1) * g;
-      const float v = b2 * d.s2[i] + (1.f - b2) * g * g;
-      d.s1[i] = m;
-      d.s2[i] = v;
-      const float denom = sqrtf(v) / bc2sqrt + eps;
-      d.p[i] = d.p[i] - (lr / bc1) * (m / denom);
+      m1 = a1 * m1 + (1.f - a1) * g;
+      m2 = b2 * m2 + (1.f - b2) * g * g;
+      pv = pv - (lr / bc1) * (m1 / (sqrtf(m2) / bc2sqrt + eps));
     }
+  };
+  const bool adam = kind == AG_OPT_ADAM;
+  // 16-byte path: the same arithmetic per element, four elements per load / store (this pass moves 7 floats per element;
+  // scalar accesses ran it at 3 TB/s)
+  if (((((uintptr_t)d.p | (uintptr_t)d.grad | (uintptr_t)d.s1 | (adam ? (uintptr_t)d.s2 : 0)) & 15) == 0) && (d.n & 3) == 0) {
+    const int64_t n4 = d.n >> 2;
+    f32x4* p4 = reinterpret_cast<f32x4*>(d.p);
+    const f32x4* g4 = reinterpret_cast<const f32x4*>(d.grad);
+    f32x4* s14 = reinterpret_cast<f32x4*>(d.s1);
+    f32x4* s24 = reinterpret_cast<f32x4*>(d.s2);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+      const f32x4 gv = g4[i];
+      f32x4 pv = p4[i], m1 = s14[i], m2 = adam ? s24[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float a = pv[e], b = m1[e], c = m2[e];
+        upd(gv[e], a, b, c);
+        pv[e] = a; m1[e] = b; m2[e] = c;
+      }
+      p4[i] = pv; s14[i] = m1;
+      if (adam) s24[i] = m2;
+    }
+    return;
+  }
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < d.n; i += (int64_t)gridDim.x * 256) {
+    float pv = d.p[i], m1 = d.s1[i], m2 = adam ? d.s2[i] : 0.f;
+    upd(d.grad[i], pv, m1, m2);
+    d.p[i] = pv; d.s1[i] = m1;
+    if (adam) d.s2[i] = m2;
   }
 }
 

@@ -20,18 +20,18 @@ class GradBucket(object):
         early = [p for p in (early or [])]
         eid = set(id(p) for p in early)
         self.params = early + [p for p in params if id(p) not in eid]
-        self.n_early = sum(p.numel() for p in early)
+        from .common import flat_offsets
+        # (every tensor starts on a 16-byte boundary of the flat buffer: the optimiser kernels read it 16 bytes at a time)
+        self.offsets, n = flat_offsets([p.numel() for p in self.params])
+        self.n_early = self.offsets[len(early)] if len(early) < len(self.params) else n
         self.group = group
-        n = sum(p.numel() for p in self.params)
         dev = self.params[0].device
         self.flat = torch.zeros(n, device=dev, dtype=torch.float32)
         assert comm_dtype in ('f32', 'bf16')
         self.comm = torch.zeros(n, device=dev, dtype=torch.bfloat16) if comm_dtype == 'bf16' else None
         self._pending = []        # (work or None, lo, hi) of every all-reduce not yet waited for / widened
-        o = 0
-        for p in self.params:
+        for p, o in zip(self.params, self.offsets):
             p.grad = self.flat[o:o + p.numel()].view(p.shape)
-            o += p.numel()
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         # force_collective: issue the all-reduce even in a 1-rank group (single-GPU rehearsal of the RCCL path)
         self.force = bool(force_collective) and dist.is_available() and dist.is_initialized()
@@ -42,11 +42,9 @@ class GradBucket(object):
     def check_views(self):
         """autograd must have accumulated IN PLACE into the flat buffer"""
         base = self.flat.data_ptr()
-        o = 0
-        for p in self.params:
+        for p, o in zip(self.params, self.offsets):
             if p.grad is None or p.grad.data_ptr() != base + 4 * o:
                 return False
-            o += p.numel()
         return True
 
     def all_reduce(self, async_op=False, part='all'):

@@ -25,15 +25,14 @@ class _Fused(object):
     # -- state -----------------------------------------------------------------------
     def _init_state(self):
         dev = self.params[0].device
-        n = sum(p.numel() for p in self.params)
+        offs, n = common.flat_offsets([p.numel() for p in self.params])      # every tensor's state 16-byte aligned
         flat1 = torch.zeros(n, device=dev)
         flat2 = torch.zeros(n, device=dev) if self.kind == K.OPT_ADAM else None
-        s1, s2, o = [], [], 0
-        for p in self.params:
+        s1, s2 = [], []
+        for p, o in zip(self.params, offs):
             s1.append(flat1[o:o + p.numel()])
             if flat2 is not None:
                 s2.append(flat2[o:o + p.numel()])
-            o += p.numel()
         self._state = dict(s1=s1, s2=s2 if flat2 is not None else None,
                            norms=torch.zeros(len(self.params), device=dev),
                            norm_sum=torch.zeros(1, device=dev),
@@ -53,12 +52,12 @@ class _Fused(object):
             have = [p for p in self.params if p.grad is not None]
             if not have:
                 return
-            flat = torch.zeros(sum(p.numel() for p in have), device=have[0].device, dtype=torch.float32)
-            views, o = [], 0
-            for p in have:
+            offs, n = common.flat_offsets([p.numel() for p in have])
+            flat = torch.zeros(n, device=have[0].device, dtype=torch.float32)
+            views = []
+            for p, o in zip(have, offs):
                 p.grad = flat[o:o + p.numel()].view(p.shape)
                 views.append((p, p.grad))
-                o += p.numel()
             self._gflat, self._gviews = flat, views
             return
         self._gflat.zero_()

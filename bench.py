@@ -191,6 +191,125 @@ class _AltGraph(object):
         return self.losses['d'], self.losses['g']
 
 
+def _full_setup(M, optim_mod, dev, batch, opt_kind, seed=0):
+    """the reference's CURRENT iteration at the C2 widths (audiogan.py:620-637: Generator, Discriminator, the two text
+    Embedders; :690-694: one optimiser over g + e_g, one over d + e_d), on loader data: ``M`` = audiogan_amd or the oracle"""
+    import types
+    from audiogan_amd import dataset as D
+    torch.manual_seed(seed)
+    g = M.Generator(frame_size=FRAME, embed_size=100, noise_size=100, state_size=1024).to(dev)
+    d = M.Discriminator(state_size=1024, embed_size=100).to(dev)
+    e_g = M.Embedder(output_size=100, char_embed_size=50, num_layers=1, num_chars=256).to(dev)
+    e_d = M.Embedder(output_size=100, char_embed_size=50, num_layers=1, num_chars=256).to(dev)
+    opt_g = optim_mod.make_optimizer(list(g.parameters()) + list(e_g.parameters()), opt_kind, 1e-4)
+    opt_d = optim_mod.make_optimizer(list(d.parameters()) + list(e_d.parameters()), opt_kind, 1e-4)
+    words = ['word%02d' % i + 'x' * (i % 5) for i in range(40)]
+    ds = D.SyntheticWordDataset(words, n_per_word=8, min_len=L // 2, max_len=L, kind='noise', seed=seed)
+    a = types.SimpleNamespace(conditional=True, dataset=ds, minwordlen=1, subset=None, amplitudes=0)
+    np.random.seed(seed)
+    h5, maxlen, gen_train, _, keys_train, _ = D.dataloader(batch, a, maxlen=L, frame_size=FRAME)
+    return (g, d, e_g, e_d, opt_g, opt_d), (D, h5, maxlen, gen_train, keys_train, a)
+
+
+def run_full(args, dev):
+    """``--workload full``: what audiogan.py executes per pass of its ``while True`` body (:703-940) - here with a DECLARED fixed
+    critic_iter of 2 (one odd = FGSM critic iteration, one even = instance-noise critic iteration; the reference runs up to
+    100 and stops once both accuracies pass 0.5, a data-dependent count) and gencatchup 1: adversarial movement of the
+    generated clips (an input-gradient pass through D), adversarial z (a gradient pass through D and G), the feature-matching
+    penalty over the critic's six activations, the two Embedder biLSTMs, the REINFORCE surrogate of the stop head; ragged
+    real clips from the loader interface, fixed-length generated clips (stop='never': an untrained stop head would end every
+    clip after a frame or two), RMSprop + per-parameter clip as the reference.  Eager (Python-issued) launches: the
+    iterations read accuracies / the baseline back on the host like the reference does, which a hipGraph cannot."""
+    import audiogan_amd as A
+    from audiogan_amd import kernels as K, loop, optim
+    K.set_precision(args.dtype)
+    mods, (D, h5, maxlen, gen_train, keys_train, a) = _full_setup(A, optim, dev, args.batch, 'rmsprop')
+    g, d, e_g, e_d, opt_g, opt_d = mods
+    pick = loop.words_picker(D, args.batch, maxlen, h5, keys_train, a, frame_size=FRAME)
+    lp = loop.TrainLoop(g, d, e_g, e_d, opt_g, opt_d, gen_train, pick, args.batch, maxlen, dev, fixed_critic_iter=2,
+                        gencatchup=1, stop='never', checkpoint_every=0, check=False)
+    for _ in range(max(args.warmup, 1)):
+        lp.outer()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        lp.outer()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    # the same pass with device time only (launches enqueued back to back inside one profiler window): how much of the wall
+    # time is the host issuing ~3000 launches
+    K.Profiler.start(only=None)
+    lp.outer()
+    prof = K.Profiler.stop()
+    dev_ms = sum(v['ms'] for v in prof.values())
+    status = K.lstm_persist_status(dev)
+    finite = all(np.isfinite(v) for rec in lp.log for v in rec[2:])
+    ms = dt / args.steps * 1e3
+    out = {
+        'metric': 'audio-samples/sec per pass of the reference\'s training loop body (2 critic iterations + 1 generator iteration)',
+        'value': args.batch * L / (dt / args.steps), 'unit': 'audio-samples/sec', 'n_gpus': 1, 'steps': args.steps,
+        'warmup': args.warmup, 'ms_per_step': ms, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': args.dtype, 'data': 'synthetic',
+        'config': {'workload': 'FULL: audiogan.py:703-940 loop body at the C2 widths, batch %d, ragged 4096-8192-sample loader '
+                               'clips (SyntheticWordDataset through dataset.dataloader / pick_words), declared fixed critic_iter 2 '
+                               '(odd = FGSM branch, even = instance noise) + gencatchup 1, both Embedders, adversarial z, feature '
+                               'penalty, REINFORCE surrogate, stop=never, rmsprop, clip d=1 g=0.1' % args.batch,
+                   'global_batch': args.batch, 'clip_len': L, 'parallelism': 'dp1',
+                   'launch': 'eager (host reads of accuracies / baseline every iteration, as the reference)'},
+        'persist_status': status, 'losses_finite': bool(finite),
+        'kernel_ms_per_step': dev_ms, 'launches_per_step': int(sum(v['n'] for v in prof.values())),
+        'kernel_table': [{'kernel': k, 'share': round(v['ms'] / dev_ms, 4), 'launches': v['n']}
+                         for k, v in sorted(prof.items(), key=lambda kv: -kv[1]['ms'])[:10]],
+    }
+    if not args.no_cpu_baseline:
+        out['cpu_baseline'] = cpu_baseline_full(min(args.cpu_batch, 8), 'rmsprop', min(32, os.cpu_count() or 1))
+    print(json.dumps(out), flush=True)
+    if status != 0 or not finite:
+        sys.exit(2)
+
+
+def cpu_baseline_full(batch, opt_kind, threads):
+    """the oracle's restatement of the same pass (O.d_step_full x 2 + O.g_step_full) on `batch` clips, once after one warm-up"""
+    from oracle import audiogan_oracle as O
+    if threads:
+        torch.set_num_threads(threads)
+
+    class _OptMod(object):
+        make_optimizer = staticmethod(O.make_optimizer)
+    (g, d, e_g, e_d, opt_g, opt_d), (D, h5, maxlen, gen_train, keys_train, a) = _full_setup(O, _OptMod, torch.device('cpu'), batch,
+                                                                                       opt_kind)
+    T = maxlen // FRAME
+    maxchar = max(len(k) for k in keys_train)
+    times = []
+    gen = torch.Generator().manual_seed(0)
+    for it in range(2):
+        t0 = time.perf_counter()
+        for dis_iter in (1, 2):
+            _, _, samples, lengths, _, cseq, clen = next(gen_train)
+            w2 = D.pick_words(batch, maxlen, h5, keys_train, maxchar, a, frame_size=FRAME, skip_samples=True)
+            real = torch.from_numpy(np.ascontiguousarray(samples[:, :maxlen], dtype=np.float32))
+            stop = torch.zeros(batch, T, dtype=torch.long)
+            O.d_step_full(g, d, e_g, e_d, opt_d, dis_iter, real, torch.from_numpy(np.asarray(lengths)).long(),
+                          torch.from_numpy(np.asarray(cseq)).long(), torch.from_numpy(np.asarray(clen)).long(),
+                          torch.from_numpy(np.asarray(w2[1])).long(), torch.from_numpy(np.asarray(w2[2])).long(),
+                          torch.randn(batch, T, 100, generator=gen), torch.randn(batch, maxlen, generator=gen) * 0.01,
+                          torch.randn(batch, maxlen, generator=gen) * 0.01, 1.0, stop=stop)
+        _, _, samples, lengths, _, _, _ = next(gen_train)
+        w2 = D.pick_words(batch, maxlen, h5, keys_train, maxchar, a, frame_size=FRAME, skip_samples=True)
+        real = torch.from_numpy(np.ascontiguousarray(samples[:, :maxlen], dtype=np.float32))
+        stop = torch.zeros(batch, T, dtype=torch.long)
+        O.g_step_full(g, d, e_g, e_d, opt_g, real, torch.from_numpy(np.asarray(lengths)).long(),
+                      torch.from_numpy(np.asarray(w2[1])).long(), torch.from_numpy(np.asarray(w2[2])).long(),
+                      torch.randn(batch, T, 100, generator=gen), torch.randn(batch, maxlen, generator=gen) * 0.01,
+                      torch.randn(batch, maxlen, generator=gen) * 0.01, torch.randn(batch, maxlen, generator=gen) * 0.01, stop, stop, None)
+        times.append(time.perf_counter() - t0)
+        sys.stderr.write('cpu_baseline(full): pass %d took %.1f s\n' % (it, times[-1]))
+    t = times[-1]
+    return dict(value=batch * L / t, unit='audio-samples/sec', cores=torch.get_num_threads(), host_cores=os.cpu_count() or 0,
+                kind='port', sample='%d clips per pass, 1 timed pass after 1 warm-up (%.2f s/pass), torch %s CPU, %d threads, %s'
+                % (batch, t, torch.__version__, torch.get_num_threads(), opt_kind))
+
+
 class _StdoutToStderr(object):
     """RCCL prints a version banner on fd 1 when a communicator is created; the bench's stdout must stay
     ONE JSON line, so fd 1 points at fd 2 while the process group comes up"""
@@ -218,10 +337,11 @@ def main():
                     help='f32 = BASELINE configs[1] (the headline); bf16 = configs[2]: every contraction rounds its '
                          'operands to bfloat16 and accumulates in fp32, gradients cross ranks as bfloat16; f32x3 = an EXPERIMENT, never '
                          'the headline: the large GEMMs on three bf16 MFMAs per product of bf16 hi + lo operand parts')
-    ap.add_argument('--workload', default='c2', choices=['c2', 'c4', 'c5'],
+    ap.add_argument('--workload', default='c2', choices=['c2', 'c4', 'c5', 'full'],
                     help='c2 = the headline (BASELINE configs[1]; with --dtype bf16: configs[2]); c4 = GRU-front '
                          'generator + conv critic (configs[3]); c5 = WGAN-GP with the conv critic (configs[4]): extra '
-                         'lines, never the headline')
+                         'lines, never the headline; full = the reference\'s current loop body (FGSM passes, adversarial z, '
+                         'feature penalty, Embedders, REINFORCE) at the C2 widths, eager: an extra line')
     ap.add_argument('--cpu-batch', type=int, default=64)
     ap.add_argument('--cpu-steps', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -261,6 +381,10 @@ def main():
             torch.cuda.synchronize()
         assert dist.get_world_size() == (args.gpus if world > 1 else 1), 'process group size != --gpus'
         assert int(t_.item()) == dist.get_world_size(), 'RCCL all-reduce did not see every rank'
+
+    if args.workload == 'full':
+        assert world == 1, '--workload full is a single-GPU line'
+        return run_full(args, dev)
 
     import audiogan_amd as A
     from audiogan_amd import train, ddp, kernels as K

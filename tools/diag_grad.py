@@ -25,7 +25,11 @@ stop = torch.zeros(B, bench.L // bench.FRAME, dtype=torch.long)
 
 
 def oracle_grads(dtype):
-    g2, d2 = copy.deepcopy(go).to(dtype), copy.deepcopy(do).to(dtype)
+    g2 = O.Generator(frame_size=256, embed_size=100, noise_size=100, state_size=1024)
+    d2 = O.Discriminator(state_size=1024, embed_size=100)
+    g2.load_state_dict(go.state_dict()); d2.load_state_dict(do.state_dict())
+    g2, d2 = g2.to(dtype), d2.to(dtype)
+    torch.set_default_dtype(dtype)          # (the oracle's forward creates its initial states with the default dtype)
     bb = {k: (t.to(dtype) if t.is_floating_point() else t) for k, t in b.items()}
     with torch.no_grad():
         fake, _, _, fl = g2(z=bb['z'], c=bb['c'], stop=stop)
@@ -36,6 +40,7 @@ def oracle_grads(dtype):
     loss = (bce(cd, torch.full_like(cd, 0.9), weight=O.length_mask(cd.size(), nd)) / nd.to(dtype)).mean() + \
         (bce(cg, torch.zeros_like(cg), weight=O.length_mask(cg.size(), ng)) / ng.to(dtype)).mean()
     loss.backward()
+    torch.set_default_dtype(torch.float32)
     return {k: p.grad.double() for k, p in d2.named_parameters()}, float(loss)
 
 
