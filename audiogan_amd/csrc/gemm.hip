@@ -333,8 +333,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
 #define LDS_AS(p) ((__attribute__((address_space(3))) void*)(p))
 #define GLB_AS(p) ((const __attribute__((address_space(1))) void*)(p))
 
+// (waves_per_eu 4: the kernel compiled to 152 VGPRs = 3 workgroups per CU; a [16384 x 1024] output is 1024 tiles = 4 per CU,
+// which then ran as 3 + 1 - the last one alone on its CU with one wave per SIMD.  Capped at 128 VGPRs all four are resident)
 template <int TA, int TB>
-__global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmP p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void gemm_dma_kernel(const GemmP p) {
   constexpr int BM = 128, BN = 128, TILE = 128 * 16;      // floats per operand tile
   __shared__ __attribute__((aligned(16))) float sm[2 * 2 * TILE];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -760,12 +762,17 @@ int ag_splitk_reduce(const float* part, int Z, int64_t pitch, int M, int N, floa
   return AG_OK;
 }
 
+// AG_GEMM_LDS_PAD (bytes of unused dynamic LDS per workgroup): caps the workgroups per CU (32 KiB static + pad), an A/B knob
+// for the occupancy / dispatch-balance experiments of tools/prof_gemm.py
+static const int g_gemm_lds_pad = [] { const char* e = getenv("AG_GEMM_LDS_PAD"); return e ? atoi(e) : 0; }();
+
 static int launch_gemm_dma(const GemmP& p, int ta, int tb, hipStream_t st) {
   dim3 grid(ag_cdiv(p.N, 128), ag_cdiv(p.M, 128), p.ksplit);
-  if (ta == 0 && tb == 0) hipLaunchKernelGGL((gemm_dma_kernel<0, 0>), grid, dim3(256), 0, st, p);
-  if (ta == 0 && tb == 1) hipLaunchKernelGGL((gemm_dma_kernel<0, 1>), grid, dim3(256), 0, st, p);
-  if (ta == 1 && tb == 0) hipLaunchKernelGGL((gemm_dma_kernel<1, 0>), grid, dim3(256), 0, st, p);
-  if (ta == 1 && tb == 1) hipLaunchKernelGGL((gemm_dma_kernel<1, 1>), grid, dim3(256), 0, st, p);
+  const int pad = g_gemm_lds_pad;
+  if (ta == 0 && tb == 0) hipLaunchKernelGGL((gemm_dma_kernel<0, 0>), grid, dim3(256), pad, st, p);
+  if (ta == 0 && tb == 1) hipLaunchKernelGGL((gemm_dma_kernel<0, 1>), grid, dim3(256), pad, st, p);
+  if (ta == 1 && tb == 0) hipLaunchKernelGGL((gemm_dma_kernel<1, 0>), grid, dim3(256), pad, st, p);
+  if (ta == 1 && tb == 1) hipLaunchKernelGGL((gemm_dma_kernel<1, 1>), grid, dim3(256), pad, st, p);
   AG_CHECK_LAUNCH("ag_gemm");
   return AG_OK;
 }

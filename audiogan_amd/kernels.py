@@ -273,6 +273,8 @@ def _table(kind, structs, device):
     if capturing:
         _table_pinned[key] = (t, host)
         _capture_log.append(key)
+        TABLE_STATS['uploads_in_capture'] += 1
+        TABLE_STATS['kinds'].append(kind)
     else:
         _table_cache[key] = (t, host)
         while len(_table_cache) > _TABLE_LRU:
@@ -281,6 +283,9 @@ def _table(kind, structs, device):
 
 
 _capture_log = []
+# descriptor tables that had to be UPLOADED by a copy node of a captured graph (their content was not seen by an eager step
+# before the capture): each costs a ~5 us node per replay - bench.py reports the count
+TABLE_STATS = dict(uploads_in_capture=0, kinds=[])
 
 
 def capture_mark():

@@ -13,7 +13,14 @@ Data comes from the reference's loader interface (``dataset.dataloader`` generat
 ``RNG.randn`` / ``T.randn`` and uploads them, :724, :749, :825).  The accuracy test of :813 needs the two accuracies on the
 host after every critic iteration, exactly as the reference reads them back for its summaries (:790-792): that host read
 stays (``fixed_critic_iter`` replaces it by a fixed count, for benchmarks).  Checkpoints are ``state_dict`` files under the
-reference's names (``checkpoint.save``)."""
+reference's names (``checkpoint.save``).
+
+``graphed=True`` (needs ``stop='never'``, a CUDA device): the three iteration bodies - odd critic iteration, even critic
+iteration, generator iteration - are captured ONCE into three hipGraphs over static input tensors and replayed; a minibatch
+is uploaded into the static tensors and z / the instance noise are drawn in place on the device before each replay.  The
+iterations run with ``host=False, check=False`` (no host read inside a graph): accuracies and the REINFORCE baseline are
+device scalars; the accuracy test of :813 reads two of them back after the replay, as the reference does after its
+iteration.  ~3000 launches per pass are then paced by the GPU, not by the Python interpreter."""
 import numpy as np
 import torch
 
@@ -23,7 +30,7 @@ from . import checkpoint, train
 class TrainLoop(object):
     def __init__(self, g, d, e_g, e_d, opt_g, opt_d, loader, pick_words, batch_size, maxlen, device, noisescale=0.01,
                  critic_iter=100, require_acc=0.5, gencatchup=1, dgradclip=1.0, ggradclip=0.1, g_optim='boundary_seeking',
-                 checkpoint_every=500, checkpoint_prefix=None, fixed_critic_iter=None, stop=None, check=True):
+                 checkpoint_every=500, checkpoint_prefix=None, fixed_critic_iter=None, stop=None, check=True, graphed=False):
         """``loader``: the generator ``dataset.dataloader`` returns (``next()`` -> [epoch, batch, samples, lengths, keys, cseq,
         clen], dataset.py:91); ``pick_words``: a callable () -> (cseq, clen) numpy arrays for ``batch_size`` random words
         (``dataset.pick_words(..., skip_samples=True)[1:3]``, audiogan.py:715-716); ``stop``: None = Bernoulli stop draws
@@ -42,6 +49,10 @@ class TrainLoop(object):
         fs = g._frame_size
         self.nframes = (maxlen + fs - 1) // fs
         self.L = self.nframes * fs
+        self.graphed = bool(graphed)
+        self._graphs = None
+        if self.graphed:
+            assert stop == 'never' and self.dev.type == 'cuda', "graphed=True needs stop='never' and a CUDA device"
 
     # ---- minibatch pieces ---------------------------------------------------------------
     def _up(self, a, dtype):
@@ -66,8 +77,102 @@ class TrainLoop(object):
     def _stop_arg(self, nframes):
         return None if self.stop is None else self.stop
 
+    # ---- captured iterations ---------------------------------------------------------------
+    def _capture(self):
+        """eager warm-up of the three bodies (every lazily created resource - optimiser state, workspaces, descriptor tables,
+        gradient buffers - must exist before a capture), then one capture each.  Capturing records without executing: the
+        warm-up iterations are real training iterations (they count), the captures change nothing."""
+        from . import common, kernels as K
+        dev, B, L, T = self.dev, self.B, self.L, self.nframes
+        ns = self.g._noise_size
+        # one eager pass of each body on real data
+        self.graphed = False
+        try:
+            for _ in range(2):
+                self.d_iteration()
+            self.g_iteration()
+            self.d_iteration(); self.d_iteration()          # (.grad buffers flattened by the second zero_grad: stable from here)
+            self.g_iteration()
+        finally:
+            self.graphed = True
+        mc = max(int(next(iter(self._words_probe())).shape[1]), 1)
+        st = dict(real=torch.zeros(B, L, device=dev), real_len=torch.full((B,), L, dtype=torch.long, device=dev),
+                  cs=torch.zeros(B, mc, dtype=torch.long, device=dev), cl=torch.ones(B, dtype=torch.long, device=dev),
+                  cs2=torch.zeros(B, mc, dtype=torch.long, device=dev), cl2=torch.ones(B, dtype=torch.long, device=dev),
+                  z=torch.zeros(B, T, ns, device=dev), n1=torch.zeros(B, L, device=dev), n2=torch.zeros(B, L, device=dev),
+                  n3=torch.zeros(B, L, device=dev),
+                  baseline=torch.zeros((), device=dev) if self.baseline is None else
+                  torch.as_tensor(float(self.baseline), device=dev, dtype=torch.float32))
+        self._static, self._out = st, {}
+        K.reserve_table_arena()
+        mark = K.capture_mark()
+
+        def cap(fn):
+            torch.cuda.synchronize()
+            gr = torch.cuda.CUDAGraph()
+            common.new_capture()
+            with torch.cuda.graph(gr, capture_error_mode='thread_local'):
+                fn()
+            return gr
+
+        def d_body(parity):
+            def body():
+                even = parity == 0
+                self._out['d%d' % parity] = train.d_step_full(
+                    self.g, self.d, self.e_g, self.e_d, self.opt_d, 2 if even else 1, st['real'], st['real_len'], st['cs'],
+                    st['cl'], st['cs2'], st['cl2'], st['z'], st['n1'] if even else None, st['n2'] if even else None,
+                    self.dgradclip, stop='never', check=False, host=False)
+            return body
+
+        def g_body():
+            r = train.g_step_full(self.g, self.d, self.e_g, self.e_d, self.opt_g, st['real'], st['real_len'], st['cs'], st['cl'],
+                                  st['z'], st['n1'], st['n2'], st['n3'], 'never', 'never', st['baseline'], self.ggradclip,
+                                  self.g_optim, check=False, host=False)
+            st['baseline'].copy_(r['baseline'])           # the running baseline lives on the device, updated by the graph
+            self._out['g'] = r
+
+        try:
+            self._graphs = dict(d1=cap(d_body(1)), d0=cap(d_body(0)), g=cap(g_body))
+            torch.cuda.synchronize()
+        except Exception:
+            K.drop_captured_tables(mark)
+            torch.cuda.synchronize()
+            raise
+
+    def _words_probe(self):
+        cs, _ = self.pick_words()
+        return [cs]
+
+    def _fill(self, real, real_len, cs, cl, cs2=None, cl2=None, noises=0):
+        st = self._static
+
+        def put(dst, src):
+            if src.shape == dst.shape:
+                dst.copy_(src, non_blocking=True)
+            else:                       # character matrices are as wide as the batch's longest word: pad into the static width
+                dst.zero_()
+                n = min(dst.size(1), src.size(1))
+                dst[:, :n].copy_(src[:, :n], non_blocking=True)
+        put(st['real'], real); st['real_len'].copy_(real_len, non_blocking=True)
+        put(st['cs'], cs); st['cl'].copy_(cl, non_blocking=True)
+        if cs2 is not None:
+            put(st['cs2'], cs2); st['cl2'].copy_(cl2, non_blocking=True)
+        st['z'].normal_()
+        for k in ('n1', 'n2', 'n3')[:noises]:
+            st[k].normal_().mul_(self.noisescale)
+
     # ---- iterations -----------------------------------------------------------------------
     def d_iteration(self):
+        if self.graphed:
+            if self._graphs is None:
+                self._capture()
+            self.dis_iter += 1
+            real, real_len, cs, cl = self._real()
+            cs2, cl2 = self._words()
+            even = self.dis_iter % 2 == 0
+            self._fill(real, real_len, cs, cl, cs2, cl2, noises=2 if even else 0)
+            self._graphs['d0' if even else 'd1'].replay()
+            return self._out['d0' if even else 'd1']
         self.dis_iter += 1
         real, real_len, cs, cl = self._real()
         cs2, cl2 = self._words()
@@ -78,7 +183,25 @@ class TrainLoop(object):
                               stop=self._stop_arg(self.nframes), check=self.check)
         return r
 
+    def _maybe_checkpoint(self):
+        if self.prefix is not None and self.checkpoint_every and self.gen_iter % self.checkpoint_every == 0:
+            b = self.baseline
+            checkpoint.save(self.prefix, self.gen_iter, d=self.d, g=self.g, e_g=self.e_g, e_d=self.e_d, opt_d=self.opt_d,
+                            opt_g=self.opt_g, extra=dict(dis_iter=self.dis_iter, gen_iter=self.gen_iter,
+                                                         baseline=float(b) if b is not None else None))
+
     def g_iteration(self):
+        if self.graphed:
+            if self._graphs is None:
+                self._capture()
+            self.gen_iter += 1
+            real, real_len, _, _ = self._real()
+            cs, cl = self._words()
+            self._fill(real, real_len, cs, cl, noises=3)
+            self._graphs['g'].replay()
+            self.baseline = self._static['baseline']
+            self._maybe_checkpoint()
+            return self._out['g']
         self.gen_iter += 1
         real, real_len, _, _ = self._real()
         cs, cl = self._words()
@@ -87,10 +210,7 @@ class TrainLoop(object):
                               self._noise(), self._noise(), self._stop_arg(self.nframes), self._stop_arg(self.nframes),
                               self.baseline, self.ggradclip, self.g_optim, check=self.check)
         self.baseline = r['baseline']
-        if self.prefix is not None and self.checkpoint_every and self.gen_iter % self.checkpoint_every == 0:
-            checkpoint.save(self.prefix, self.gen_iter, d=self.d, g=self.g, e_g=self.e_g, e_d=self.e_d, opt_d=self.opt_d,
-                            opt_g=self.opt_g, extra=dict(dis_iter=self.dis_iter, gen_iter=self.gen_iter,
-                                                         baseline=self.baseline))
+        self._maybe_checkpoint()
         return r
 
     def outer(self):
@@ -101,12 +221,17 @@ class TrainLoop(object):
         for _ in range(n_d):
             rd = self.d_iteration()
             ran += 1
-            self.log.append(('D', self.dis_iter, float(rd['loss']), rd['acc_d'], rd['acc_g']))
-            if self.fixed_critic_iter is None and rd['acc_d'] > self.require_acc and rd['acc_g'] > self.require_acc:
-                break
+            if self.fixed_critic_iter is None:
+                # the accuracy test of :813: two host reads per critic iteration, as the reference
+                self.log.append(('D', self.dis_iter, float(rd['loss']), float(rd['acc_d']), float(rd['acc_g'])))
+                if float(rd['acc_d']) > self.require_acc and float(rd['acc_g']) > self.require_acc:
+                    break
+            elif not self.graphed:
+                self.log.append(('D', self.dis_iter, float(rd['loss']), float(rd['acc_d']), float(rd['acc_g'])))
         for _ in range(self.gencatchup):
             rg = self.g_iteration()
-            self.log.append(('G', self.gen_iter, float(rg['loss']), float(rg['feature_penalty'])))
+            if not self.graphed:
+                self.log.append(('G', self.gen_iter, float(rg['loss']), float(rg['feature_penalty'])))
         return ran, rd, rg
 
     def run(self, n_outer):
@@ -120,6 +245,9 @@ class TrainLoop(object):
                                 opt_g=self.opt_g) or {}
         self.dis_iter, self.gen_iter = int(extra.get('dis_iter', 0)), int(extra.get('gen_iter', iteration))
         self.baseline = extra.get('baseline', None)
+        if self.graphed and self._graphs is not None and self.baseline is not None:
+            self._static['baseline'].fill_(float(self.baseline))
+            self.baseline = self._static['baseline']
         return extra
 
 

@@ -228,19 +228,22 @@ def g_backward_late(keep, persist=False):
 # feature-matching penalty (:847-855) and the REINFORCE update of the stop head (:444-460, :866-908).  Same arguments
 # and results as oracle.audiogan_oracle.d_step_full / g_step_full (every random quantity is an argument).
 # --------------------------------------------------------------------------------------
-def _acc(cls, nframes, positive):
+def _acc(cls, nframes, positive, host=True):
     w = length_mask(cls.size(), nframes)
     hit = (cls > 0) if positive else (cls < 0)
-    return float((hit.float() * w).sum() / w.sum())
+    a = (hit.float() * w).sum() / w.sum()
+    return float(a) if host else a
 
 
 def d_step_full(g, d, e_g, e_d, opt_d, dis_iter, real, real_len, cs, cl, cs2, cl2, z, noise_real, noise_fake,
-                dgradclip=1.0, stop=None, check=True):
+                dgradclip=1.0, stop=None, check=True, host=True):
     """critic iteration ``dis_iter`` of audiogan.py:706-788.  Even iterations: instance noise on the real and the
     generated clips (:724-728, :749-751).  Odd iterations: clean real clips (the FGSM perturbation of :735-736 is
     computed after ``cls_d`` and never reaches the loss, so it is not computed here) and generated clips moved by
     +-1e-3 along the sign of the critic's input gradient (:752-759, ``extras.adversarial_movement_d``: an
-    input-gradient pass that leaves every ``.grad`` untouched).  ``opt_d`` holds the parameters of d and e_d (:691)."""
+    input-gradient pass that leaves every ``.grad`` untouched).  ``opt_d`` holds the parameters of d and e_d (:691).
+    ``host=False``: the accuracies stay device scalars - with ``check=False`` and ``stop='never'`` the iteration then issues no
+    host read at all and can be captured into a hipGraph (loop.TrainLoop(graphed=True))."""
     even = dis_iter % 2 == 0
     embed_real = e_d(cs, cl)
     cls_d, _, _, nf_d = d(real + noise_real if even else real, real_len, embed_real)
@@ -261,15 +264,17 @@ def d_step_full(g, d, e_g, e_d, opt_d, dis_iter, real, real_len, cs, cl, cs2, cl
     opt_d.step(clip_norm=dgradclip, check=check)
     return dict(loss=loss.detach(), loss_d=loss_d.detach(), loss_g=loss_g.detach(), cls_d=cls_d.detach(),
                 cls_g=cls_g.detach(), grad_norm=opt_d.last_norm_sum,
-                acc_d=_acc(cls_d.detach(), nf_d, True), acc_g=_acc(cls_g.detach(), nf_g, False))
+                acc_d=_acc(cls_d.detach(), nf_d, True, host), acc_g=_acc(cls_g.detach(), nf_g, False, host))
 
 
 def g_step_full(g, d, e_g, e_d, opt_g, real, real_len, cs, cl, z0, noise_real, noise_adv, noise_fake, stop_adv, stop,
-                baseline=None, ggradclip=0.1, g_optim='boundary_seeking', lambda_fp=1.0, check=True):
+                baseline=None, ggradclip=0.1, g_optim='boundary_seeking', lambda_fp=1.0, check=True, host=True):
     """generator iteration of audiogan.py:816-921: adversarial z (:836), generator + critic forward (:841-847), feature
     penalty against the critic's statistics on the real clips (:847-855), BCE towards 0.5 (:857-864), reward / baseline
     (:873-887), loss + penalty (:897), REINFORCE of the stop draws into the stop head only (:898-908), per-parameter clip
-    and step over the parameters of g and e_g (:909-921).  Returns a dict with the new ``baseline``."""
+    and step over the parameters of g and e_g (:909-921).  Returns a dict with the new ``baseline``.  ``baseline``: None (first
+    iteration), a float, or a device scalar; ``host=False``: it is kept / returned as a device scalar (no host read: the
+    iteration can be captured into a hipGraph, see d_step_full)."""
     B = real.size(0)
     fs, ns = g._frame_size, g._noise_size
     embed_g = e_g(cs, cl)
@@ -285,10 +290,15 @@ def g_step_full(g, d, e_g, e_d, opt_g, real, real_len, cs, cl, z0, noise_real, n
         pen = feature_penalty(calc_dists(hs_d, hl_d), calc_dists(hs_g, hl_g), B)
         bce, per = masked_bce_mean(cls_g, 0.5 if g_optim == 'boundary_seeking' else 0.0, nf_g.contiguous())
         reward = -(per / nf_g.float())                       # per-sample loss, a constant for the stop head
-        rmean = float(reward.mean())
+        rmean = reward.mean().detach()
+        if host:
+            rmean = float(rmean)
+            if torch.is_tensor(baseline):
+                baseline = float(baseline)
         baseline = rmean if baseline is None else baseline * 0.5 + rmean * 0.5
         frames = fake_len // fs
-        weight_r = length_mask((B, int(frames.max())), frames)
+        # (the frames that were generated: max_b frames[b] == s.size(1) by construction of Generator.forward - no host read)
+        weight_r = length_mask((B, s.size(1)), frames)
         reward = (reward - baseline).unsqueeze(1) * weight_r
         loss = bce + pen * lambda_fp
         opt_g.zero_grad()

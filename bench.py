@@ -533,6 +533,7 @@ def main():
                                   else 'eager' + (' (capture failed: %s)' % capture_error if capture_error else ''))},
         }
         out['persist_status'] = persist_status
+        out['table_uploads_in_graph'] = dict(count=K.TABLE_STATS['uploads_in_capture'], kinds=K.TABLE_STATS['kinds'][:8])
         if replay is not None:
             out['replay_check'] = 'ok' if replay['ok'] else 'FAILED'
             out['replay_check_detail'] = {k: v for k, v in replay.items() if k != 'ok'}
