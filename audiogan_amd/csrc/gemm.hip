@@ -10,29 +10,13 @@
 #include <type_traits>
 
 #include "common.h"
+#include "gemm_tile.h"
 
 #ifndef GBK
 #define GBK 16
 #endif
 #define GKQ (GBK / 4)
 
-struct GemmP {
-  const float* A;
-  const float* B;
-  float* C;
-  const float* bias;
-  const float* res;
-  int lda, ldb, ldc, ldres;
-  int M, N, K;
-  float alpha, beta, slope;
-  int act;
-  int vecA, vecB;  // 16-B vector loads allowed for A / B
-  int rb;          // AG_PREC_BF16: operands are rounded to bf16 on the way into LDS (fp32 MFMA on rounded values)
-  int ksplit;      // > 1: grid.z K slices; partial tiles go to `part` (two-stage, fixed-order reduction) or, when
-                   // part == NULL, are added with fp32 atomics into a pre-initialised C
-  int kchunk;      // K per slice (multiple of GBK)
-  float* part;     // [ksplit][M][N] partial products (alpha applied), or NULL
-};
 
 // Tile loaders, split into "global -> registers" and "registers -> LDS" so that the loads of
 // tile i+1 are in flight while tile i is being multiplied (one barrier per k-step, two LDS buffers).
@@ -174,30 +158,6 @@ struct RContig {
   }
 };
 
-// XCD-aware placement.  Workgroup ids go round-robin over the 8 XCDs, each with its own L2.  In plain order the column
-// tiles of one row band land on 8 different XCDs and every XCD pulls ALL of A through the fabric; with K split over
-// grid.z every XCD additionally pulls every K slice of B.  Remapped: with 8 | ksplit one XCD works on whole K slices (its
-// L2 fetches that slice of A and of B once); with ksplit in {1, 2, 4} a slice is shared by 8 / ksplit XCDs, each taking a
-// contiguous band of the slice's tiles.  Speed only: the result does not depend on placement (slices are indexed by bz).
-__device__ __forceinline__ void xcd_place(int& bx, int& by, int& bz) {
-  const int gx = gridDim.x, nwg = gx * gridDim.y, ks = gridDim.z;
-  const int lin = (blockIdx.z * gridDim.y + blockIdx.y) * gx + blockIdx.x;
-  const int x = lin & 7, q = lin >> 3;
-  bx = blockIdx.x; by = blockIdx.y; bz = blockIdx.z;
-  int tile;
-  if ((ks & 7) == 0) {
-    bz = x + 8 * (q / nwg);
-    tile = q % nwg;
-  } else if (ks <= 4 && (8 % ks) == 0 && nwg % (8 / ks) == 0) {
-    bz = x % ks;
-    tile = (x / ks) * (nwg / (8 / ks)) + q;
-  } else {
-    return;
-  }
-  by = tile / gx;
-  bx = tile - by * gx;
-}
-
 template <int TM, int TN, int WM, int WN, int TA, int TB>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
   static_assert(WM * WN == 4, "4 waves");
@@ -301,169 +261,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
       if (row >= p.M) continue;
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        const int col = n0 + wn0 + 32 * j + l31;
-        if (col >= p.N) continue;
-        float v = p.alpha * acc[i][j][e];
-        float* dst = p.C + (int64_t)row * p.ldc + col;
-        if (p.ksplit > 1) {      // K slice: a partial tile into its slab (the host never splits K without one)
-          p.part[((int64_t)bz * p.M + row) * p.N + col] = v;
-          continue;
-        }
-        if (p.beta != 0.f) v += p.beta * *dst;
-        if (p.bias) v += p.bias[col];
-        *dst = ag_res_act(v, p.res != nullptr, p.res ? p.res[(int64_t)row * p.ldres + col] : 0.f, p.act, p.slope);
-      }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// 128x128 tile fed by LDS-DMA (global_load_lds_dwordx4: global -> LDS without a VGPR stop, no ds_write):
-// ablation builds of gemm_kernel showed its MFMA + LDS-read loop alone at 116-129 TF and the register-staged
-// global -> LDS traffic costing the other 15 %.
-//   * A DMA instruction writes LDS at (wave-uniform base + lane * 16 B), so the LDS image is the lane order:
-//     k-contiguous operands land as [row][16 k] (64-byte rows), row-contiguous ones as [k][128 rows].
-//   * [row][16 k] is read with ONE ds_read_b128 per 8 k: a lane takes 4 consecutive k of its row and the four
-//     MFMAs of the group use them as k = 8q + 4h + e (h = lane >> 5; both operands use that k order).  64-byte rows
-//     would put rows m, m+4, m+8, m+12 on the same banks, so the 16-byte piece kq of row r is stored in slot
-//     kq ^ ((r >> 2) & 3) - applied to the SOURCE address of the DMA lane and to the reader's slot.
-//   * two LDS buffers in ONE array; tile i+1 is requested before the MFMAs of tile i, and the __syncthreads() that
-//     ends the iteration (vmcnt(0) + barrier) is what orders the DMA bytes before the next iteration's reads.
-// Needs K % 16 == 0 (per slice), 16-byte aligned rows, and row counts % 4 == 0 for row-contiguous operands.
-// ------------------------------------------------------------------------------------------
-#define LDS_AS(p) ((__attribute__((address_space(3))) void*)(p))
-#define GLB_AS(p) ((const __attribute__((address_space(1))) void*)(p))
-
-// (waves_per_eu 4: the kernel compiled to 152 VGPRs = 3 workgroups per CU; a [16384 x 1024] output is 1024 tiles = 4 per CU,
-// which then ran as 3 + 1 - the last one alone on its CU with one wave per SIMD.  Capped at 128 VGPRs all four are resident)
-template <int TA, int TB>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void gemm_dma_kernel(const GemmP p) {
-  constexpr int BM = 128, BN = 128, TILE = 128 * 16;      // floats per operand tile
-  __shared__ __attribute__((aligned(16))) float sm[2 * 2 * TILE];
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int l31 = lane & 31, h = lane >> 5;
-  const int wm0 = (wid >> 1) * 64, wn0 = (wid & 1) * 64;
-  int bx, by, bz;
-  xcd_place(bx, by, bz);
-  const int m0 = by * BM, n0 = bx * BN;
-
-  // per-lane DMA sources at k = 0 (two 16-byte pieces per operand per tile)
-  const float* asrc[2];
-  const float* bsrc[2];
-#pragma unroll
-  for (int it = 0; it < 2; ++it) {
-    const int idx = tid + 256 * it;
-    if (TA == 0) {        // A [M][K]: piece (row r, slot s) <- k piece s ^ ((r >> 2) & 3)
-      const int r = idx >> 2, sl = idx & 3;
-      asrc[it] = p.A + (int64_t)min(m0 + r, p.M - 1) * p.lda + 4 * (sl ^ ((r >> 2) & 3));
-    } else {              // A [K][M]
-      const int k = idx >> 5, r4 = idx & 31;
-      asrc[it] = p.A + (int64_t)k * p.lda + min(m0 + 4 * r4, p.M - 4);
-    }
-    if (TB == 1) {        // B [N][K]
-      const int r = idx >> 2, sl = idx & 3;
-      bsrc[it] = p.B + (int64_t)min(n0 + r, p.N - 1) * p.ldb + 4 * (sl ^ ((r >> 2) & 3));
-    } else {              // B [K][N]
-      const int k = idx >> 5, r4 = idx & 31;
-      bsrc[it] = p.B + (int64_t)k * p.ldb + min(n0 + 4 * r4, p.N - 4);
-    }
-  }
-  const int64_t astep = TA == 0 ? 1 : (int64_t)p.lda, bstep = TB == 1 ? 1 : (int64_t)p.ldb;   // per unit of k
-
-  auto stage = [&](int k0, int buf) {
-    float* As = sm + buf * 2 * TILE;
-    float* Bs = As + TILE;
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-      const int wbase = (wid * 64 + 256 * it) * 4;          // wave-uniform LDS float offset of this instruction
-      __builtin_amdgcn_global_load_lds(GLB_AS(asrc[it] + (int64_t)k0 * astep), LDS_AS(As + wbase), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds(GLB_AS(bsrc[it] + (int64_t)k0 * bstep), LDS_AS(Bs + wbase), 16, 0, 0);
-    }
-  };
-
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-  const int kbeg = bz * p.kchunk;
-  const int kend = (kbeg + p.kchunk < p.K) ? kbeg + p.kchunk : p.K;
-  stage(kbeg, 0);
-  __syncthreads();
-  int buf = 0;
-  for (int k0 = kbeg; k0 < kend; k0 += 16) {
-    if (k0 + 16 < kend) stage(k0 + 16, buf ^ 1);
-    const float* As = sm + buf * 2 * TILE;
-    const float* Bs = As + TILE;
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      f32x4 av[2], bv[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int m = wm0 + 32 * i + l31;
-        if (TA == 0) {
-          av[i] = *reinterpret_cast<const f32x4*>(As + m * 16 + 4 * ((2 * q + h) ^ ((m >> 2) & 3)));
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) av[i][e] = As[(8 * q + 4 * h + e) * 128 + m];
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int n = wn0 + 32 * j + l31;
-        if (TB == 1) {
-          bv[j] = *reinterpret_cast<const f32x4*>(Bs + n * 16 + 4 * ((2 * q + h) ^ ((n >> 2) & 3)));
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) bv[j][e] = Bs[(8 * q + 4 * h + e) * 128 + n];
-        }
-      }
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][e], bv[j][e], acc[i][j], 0, 0, 0);
-    }
-    // (without this the scheduler hoists the barrier - and its vmcnt(0) on the next tile's DMA - in front of the second
-    // half of the tile's MFMAs: the DMA then has half an iteration to land)
-    __builtin_amdgcn_sched_barrier(0);
-    __syncthreads();
-    buf ^= 1;
-  }
-
-  if (p.ksplit == 1 && m0 + BM <= p.M && n0 + BN <= p.N) {
-    const bool hb = p.bias != nullptr, hr = p.res != nullptr, hbeta = p.beta != 0.f;
-    float bj[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) bj[j] = hb ? p.bias[n0 + wn0 + 32 * j + l31] : 0.f;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row = m0 + wm0 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
-        float* dst = p.C + (int64_t)row * p.ldc + n0 + wn0 + l31;
-        const float* rs = p.res + (int64_t)row * p.ldres + n0 + wn0 + l31;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          float v = p.alpha * acc[i][j][e] + bj[j];
-          if (hbeta) v += p.beta * dst[32 * j];
-          dst[32 * j] = ag_res_act(v, hr, hr ? rs[32 * j] : 0.f, p.act, p.slope);
-        }
-      }
-    return;
-  }
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int row = m0 + wm0 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
-      if (row >= p.M) continue;
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
         const int col = n0 + wn0 + 32 * j + l31;
         if (col >= p.N) continue;
         float v = p.alpha * acc[i][j][e];
@@ -762,17 +559,34 @@ int ag_splitk_reduce(const float* part, int Z, int64_t pitch, int M, int N, floa
   return AG_OK;
 }
 
-// AG_GEMM_LDS_PAD (bytes of unused dynamic LDS per workgroup): caps the workgroups per CU (32 KiB static + pad), an A/B knob
-// for the occupancy / dispatch-balance experiments of tools/prof_gemm.py
-static const int g_gemm_lds_pad = [] { const char* e = getenv("AG_GEMM_LDS_PAD"); return e ? atoi(e) : 0; }();
+// Tile shape of the LDS-DMA kernel (gemm_tile.h) for an [M x N] output in `ksplit` K slices.  A CU's matrix pipes are shared
+// by the workgroups resident on it, so a launch takes about ceil(workgroups / 256) x (BM x BN) / rate(shape): prefer the
+// largest tile that still gives every CU a workgroup.  Rates: TF measured by tools/gemm_lab.hip (profiles/r04_gemm_lab.txt).
+// AG_GEMM_TILE=0..3 in the environment forces a shape (A/B switch of tools/prof_gemm.py).
+static const int g_gemm_tile_force = [] { const char* e = getenv("AG_GEMM_TILE"); return e ? atoi(e) : -1; }();
+static int gemm_pick_tile(int M, int N, int ksplit) {
+  if (g_gemm_tile_force >= 0 && g_gemm_tile_force <= 3) return g_gemm_tile_force;
+  static const int order[4] = {3, 1, 2, 0};
+  static const double rate[4] = {120., 133., 133., 137.};
+  int best = 0;
+  double best_t = 0.;
+  for (int s : order) {
+    int bm, bn;
+    gemm_tile_dims(s, bm, bn);
+    const int64_t wgs = (int64_t)ag_cdiv(M, bm) * ag_cdiv(N, bn) * ksplit;
+    // (ties: the shape that computes fewer padded elements)
+    const double t = (double)ag_cdiv64(wgs, 256) * bm * bn / rate[s] + 1e-9 * (double)wgs * bm * bn;
+    if (best_t == 0. || t < best_t * 0.98) { best = s; best_t = t; }
+  }
+  return best;
+}
 
 static int launch_gemm_dma(const GemmP& p, int ta, int tb, hipStream_t st) {
-  dim3 grid(ag_cdiv(p.N, 128), ag_cdiv(p.M, 128), p.ksplit);
-  const int pad = g_gemm_lds_pad;
-  if (ta == 0 && tb == 0) hipLaunchKernelGGL((gemm_dma_kernel<0, 0>), grid, dim3(256), pad, st, p);
-  if (ta == 0 && tb == 1) hipLaunchKernelGGL((gemm_dma_kernel<0, 1>), grid, dim3(256), pad, st, p);
-  if (ta == 1 && tb == 0) hipLaunchKernelGGL((gemm_dma_kernel<1, 0>), grid, dim3(256), pad, st, p);
-  if (ta == 1 && tb == 1) hipLaunchKernelGGL((gemm_dma_kernel<1, 1>), grid, dim3(256), pad, st, p);
+  const int rc = gemm_tile_launch(p, ta, tb, gemm_pick_tile(p.M, p.N, p.ksplit), st);
+  if (rc != AG_OK) {
+    ag_set_error("ag_gemm: tile kernel set-up failed");
+    return rc;
+  }
   AG_CHECK_LAUNCH("ag_gemm");
   return AG_OK;
 }

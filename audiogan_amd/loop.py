@@ -21,16 +21,22 @@ is uploaded into the static tensors and z / the instance noise are drawn in plac
 iterations run with ``host=False, check=False`` (no host read inside a graph): accuracies and the REINFORCE baseline are
 device scalars; the accuracy test of :813 reads two of them back after the replay, as the reference does after its
 iteration.  ~3000 launches per pass are then paced by the GPU, not by the Python interpreter."""
+import time
+
 import numpy as np
 import torch
 
 from . import checkpoint, train
 
+import os as _os
+_EXP = _os.environ.get('AG_LOOP_EXP', '')     # measurement knob of tools/r4_call11.sh (nofeed | mainstream | noload)
+
 
 class TrainLoop(object):
     def __init__(self, g, d, e_g, e_d, opt_g, opt_d, loader, pick_words, batch_size, maxlen, device, noisescale=0.01,
                  critic_iter=100, require_acc=0.5, gencatchup=1, dgradclip=1.0, ggradclip=0.1, g_optim='boundary_seeking',
-                 checkpoint_every=500, checkpoint_prefix=None, fixed_critic_iter=None, stop=None, check=True, graphed=False):
+                 checkpoint_every=500, checkpoint_prefix=None, fixed_critic_iter=None, stop=None, check=True, graphed=False,
+                 host=None):
         """``loader``: the generator ``dataset.dataloader`` returns (``next()`` -> [epoch, batch, samples, lengths, keys, cseq,
         clen], dataset.py:91); ``pick_words``: a callable () -> (cseq, clen) numpy arrays for ``batch_size`` random words
         (``dataset.pick_words(..., skip_samples=True)[1:3]``, audiogan.py:715-716); ``stop``: None = Bernoulli stop draws
@@ -50,7 +56,13 @@ class TrainLoop(object):
         self.nframes = (maxlen + fs - 1) // fs
         self.L = self.nframes * fs
         self.graphed = bool(graphed)
+        # host=False: the iterations return device scalars and keep the REINFORCE baseline on the device (fp32) - what the
+        # captured iterations do; an eager loop with host=False runs the very same arithmetic (tests compare the two bit for bit)
+        self.host = (not self.graphed) if host is None else bool(host)
         self._graphs = None
+        # host milliseconds spent per phase of the captured iterations (enqueueing a replay, the loader, staging the upload,
+        # feeding the static inputs), summed since construction: bench.py --workload full reports them per pass
+        self.host_ms = dict(replay=0.0, loader=0.0, stage=0.0, inputs=0.0)
         if self.graphed:
             assert stop == 'never' and self.dev.type == 'cuda', "graphed=True needs stop='never' and a CUDA device"
 
@@ -69,6 +81,7 @@ class TrainLoop(object):
 
     def _words(self):
         cs, cl = self.pick_words()
+        self._cwidth = int(np.asarray(cs).shape[1])
         return self._up(cs, torch.long), self._up(cl, torch.long)
 
     def _noise(self):
@@ -95,15 +108,19 @@ class TrainLoop(object):
             self.g_iteration()
         finally:
             self.graphed = True
-        mc = max(int(next(iter(self._words_probe())).shape[1]), 1)
+        mc = max(self._cwidth, 1)          # character matrices are maxchar wide (dataset.word_to_seq), the same every batch
         st = dict(real=torch.zeros(B, L, device=dev), real_len=torch.full((B,), L, dtype=torch.long, device=dev),
-                  cs=torch.zeros(B, mc, dtype=torch.long, device=dev), cl=torch.ones(B, dtype=torch.long, device=dev),
-                  cs2=torch.zeros(B, mc, dtype=torch.long, device=dev), cl2=torch.ones(B, dtype=torch.long, device=dev),
+                  # lcs / lcl: the loader batch's words (the critic iteration's matching text), wcs / wcl: the pick_words batch
+                  # (the critic's mismatched text, the generator iteration's text)
+                  lcs=torch.zeros(B, mc, dtype=torch.long, device=dev), lcl=torch.ones(B, dtype=torch.long, device=dev),
+                  wcs=torch.zeros(B, mc, dtype=torch.long, device=dev), wcl=torch.ones(B, dtype=torch.long, device=dev),
                   z=torch.zeros(B, T, ns, device=dev), n1=torch.zeros(B, L, device=dev), n2=torch.zeros(B, L, device=dev),
                   n3=torch.zeros(B, L, device=dev),
                   baseline=torch.zeros((), device=dev) if self.baseline is None else
-                  torch.as_tensor(float(self.baseline), device=dev, dtype=torch.float32))
+                  (self.baseline.detach().clone().float().reshape(()) if torch.is_tensor(self.baseline) else
+                   torch.as_tensor(float(self.baseline), device=dev, dtype=torch.float32)))
         self._static, self._out = st, {}
+        self._feeder = train.Feeder(st, keys=['real', 'real_len', 'lcs', 'lcl', 'wcs', 'wcl'])
         K.reserve_table_arena()
         mark = K.capture_mark()
 
@@ -119,13 +136,13 @@ class TrainLoop(object):
             def body():
                 even = parity == 0
                 self._out['d%d' % parity] = train.d_step_full(
-                    self.g, self.d, self.e_g, self.e_d, self.opt_d, 2 if even else 1, st['real'], st['real_len'], st['cs'],
-                    st['cl'], st['cs2'], st['cl2'], st['z'], st['n1'] if even else None, st['n2'] if even else None,
+                    self.g, self.d, self.e_g, self.e_d, self.opt_d, 2 if even else 1, st['real'], st['real_len'], st['lcs'],
+                    st['lcl'], st['wcs'], st['wcl'], st['z'], st['n1'] if even else None, st['n2'] if even else None,
                     self.dgradclip, stop='never', check=False, host=False)
             return body
 
         def g_body():
-            r = train.g_step_full(self.g, self.d, self.e_g, self.e_d, self.opt_g, st['real'], st['real_len'], st['cs'], st['cl'],
+            r = train.g_step_full(self.g, self.d, self.e_g, self.e_d, self.opt_g, st['real'], st['real_len'], st['wcs'], st['wcl'],
                                   st['z'], st['n1'], st['n2'], st['n3'], 'never', 'never', st['baseline'], self.ggradclip,
                                   self.g_optim, check=False, host=False)
             st['baseline'].copy_(r['baseline'])           # the running baseline lives on the device, updated by the graph
@@ -139,27 +156,53 @@ class TrainLoop(object):
             torch.cuda.synchronize()
             raise
 
-    def _words_probe(self):
-        cs, _ = self.pick_words()
-        return [cs]
+    def _host_pair(self):
+        """what every iteration takes from the host, in the order the eager iterations draw it: the loader's next minibatch
+        (:714) and one pick_words batch (:715-716), at the static shapes / dtypes"""
+        _, _, samples, lengths, _, cseq, clen = next(self.loader)
+        x = np.zeros((self.B, self.L), dtype=np.float32)
+        n = min(self.L, samples.shape[1])
+        x[:, :n] = samples[:, :n]
+        ws, wl = self.pick_words()
+        i64 = lambda v: np.ascontiguousarray(np.asarray(v), dtype=np.int64)   # noqa: E731
+        return dict(real=x, real_len=i64(lengths), lcs=i64(cseq), lcl=i64(clen), wcs=i64(ws), wcl=i64(wl))
 
-    def _fill(self, real, real_len, cs, cl, cs2=None, cl2=None, noises=0):
-        st = self._static
-
-        def put(dst, src):
-            if src.shape == dst.shape:
-                dst.copy_(src, non_blocking=True)
-            else:                       # character matrices are as wide as the batch's longest word: pad into the static width
-                dst.zero_()
-                n = min(dst.size(1), src.size(1))
-                dst[:, :n].copy_(src[:, :n], non_blocking=True)
-        put(st['real'], real); st['real_len'].copy_(real_len, non_blocking=True)
-        put(st['cs'], cs); st['cl'].copy_(cl, non_blocking=True)
-        if cs2 is not None:
-            put(st['cs2'], cs2); st['cl2'].copy_(cl2, non_blocking=True)
+    def _next_inputs(self, noises):
+        """step boundary of a captured iteration: the staged minibatch becomes the graphs' input (train.Feeder: pinned ->
+        device staging on a copy stream while the previous replay runs, device -> static tensors here), then z and the
+        instance noise are drawn in place - the same draws, in the same order, as the eager iteration's torch.randn calls"""
+        f, st = self._feeder, self._static
+        t0 = time.perf_counter()
+        if 'nofeed' not in _EXP:
+            if f.n_fed >= f.n_staged:
+                f.stage(self._host_pair())
+            f.feed()
         st['z'].normal_()
         for k in ('n1', 'n2', 'n3')[:noises]:
             st[k].normal_().mul_(self.noisescale)
+        self.host_ms['inputs'] += (time.perf_counter() - t0) * 1e3
+
+    def _replay(self, key):
+        t0 = time.perf_counter()
+        if 'ev' in _EXP:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        self._graphs[key].replay()
+        if 'ev' in _EXP:
+            e1.record()
+            self._events = getattr(self, '_events', []) + [(key, e0, e1, t0)]
+        t1 = time.perf_counter()
+        # host work + upload of the NEXT minibatch overlap the replay just enqueued
+        pair = self._host_pair() if ('noload' not in _EXP or not hasattr(self, '_pair0')) else self._pair0
+        self._pair0 = pair
+        t2 = time.perf_counter()
+        if 'nofeed' not in _EXP:
+            if 'mainstream' in _EXP:
+                self._feeder.copy_stream = torch.cuda.current_stream()
+            self._feeder.stage(pair)
+        t3 = time.perf_counter()
+        h = self.host_ms
+        h['replay'] += (t1 - t0) * 1e3; h['loader'] += (t2 - t1) * 1e3; h['stage'] += (t3 - t2) * 1e3
 
     # ---- iterations -----------------------------------------------------------------------
     def d_iteration(self):
@@ -167,11 +210,9 @@ class TrainLoop(object):
             if self._graphs is None:
                 self._capture()
             self.dis_iter += 1
-            real, real_len, cs, cl = self._real()
-            cs2, cl2 = self._words()
             even = self.dis_iter % 2 == 0
-            self._fill(real, real_len, cs, cl, cs2, cl2, noises=2 if even else 0)
-            self._graphs['d0' if even else 'd1'].replay()
+            self._next_inputs(2 if even else 0)
+            self._replay('d0' if even else 'd1')
             return self._out['d0' if even else 'd1']
         self.dis_iter += 1
         real, real_len, cs, cl = self._real()
@@ -180,7 +221,7 @@ class TrainLoop(object):
         even = self.dis_iter % 2 == 0       # (odd iterations take the FGSM branch: no instance noise is drawn, :729-736, :752-759)
         r = train.d_step_full(self.g, self.d, self.e_g, self.e_d, self.opt_d, self.dis_iter, real, real_len, cs, cl, cs2, cl2, z,
                               self._noise() if even else None, self._noise() if even else None, self.dgradclip,
-                              stop=self._stop_arg(self.nframes), check=self.check)
+                              stop=self._stop_arg(self.nframes), check=self.check, host=self.host)
         return r
 
     def _maybe_checkpoint(self):
@@ -195,10 +236,8 @@ class TrainLoop(object):
             if self._graphs is None:
                 self._capture()
             self.gen_iter += 1
-            real, real_len, _, _ = self._real()
-            cs, cl = self._words()
-            self._fill(real, real_len, cs, cl, noises=3)
-            self._graphs['g'].replay()
+            self._next_inputs(3)
+            self._replay('g')
             self.baseline = self._static['baseline']
             self._maybe_checkpoint()
             return self._out['g']
@@ -208,7 +247,7 @@ class TrainLoop(object):
         z0 = torch.randn(self.B, self.nframes, self.g._noise_size, device=self.dev)
         r = train.g_step_full(self.g, self.d, self.e_g, self.e_d, self.opt_g, real, real_len, cs, cl, z0, self._noise(),
                               self._noise(), self._noise(), self._stop_arg(self.nframes), self._stop_arg(self.nframes),
-                              self.baseline, self.ggradclip, self.g_optim, check=self.check)
+                              self.baseline, self.ggradclip, self.g_optim, check=self.check, host=self.host)
         self.baseline = r['baseline']
         self._maybe_checkpoint()
         return r
@@ -226,11 +265,11 @@ class TrainLoop(object):
                 self.log.append(('D', self.dis_iter, float(rd['loss']), float(rd['acc_d']), float(rd['acc_g'])))
                 if float(rd['acc_d']) > self.require_acc and float(rd['acc_g']) > self.require_acc:
                     break
-            elif not self.graphed:
+            elif self.host:
                 self.log.append(('D', self.dis_iter, float(rd['loss']), float(rd['acc_d']), float(rd['acc_g'])))
         for _ in range(self.gencatchup):
             rg = self.g_iteration()
-            if not self.graphed:
+            if self.host:
                 self.log.append(('G', self.gen_iter, float(rg['loss']), float(rg['feature_penalty'])))
         return ran, rd, rg
 

@@ -227,23 +227,54 @@ def run_full(args, dev):
     g, d, e_g, e_d, opt_g, opt_d = mods
     pick = loop.words_picker(D, args.batch, maxlen, h5, keys_train, a, frame_size=FRAME)
     lp = loop.TrainLoop(g, d, e_g, e_d, opt_g, opt_d, gen_train, pick, args.batch, maxlen, dev, fixed_critic_iter=2,
-                        gencatchup=1, stop='never', checkpoint_every=0, check=False)
+                        gencatchup=1, stop='never', checkpoint_every=0, check=False, graphed=args.full_launch == 'graph')
     for _ in range(max(args.warmup, 1)):
         lp.outer()
     torch.cuda.synchronize()
+    h0 = dict(lp.host_ms)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         lp.outer()
+    t_issue = time.perf_counter() - t0
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    host_ms = {k: (lp.host_ms[k] - h0[k]) / args.steps for k in h0}
     # the same pass with device time only (launches enqueued back to back inside one profiler window): how much of the wall
     # time is the host issuing ~3000 launches
-    K.Profiler.start(only=None)
-    lp.outer()
-    prof = K.Profiler.stop()
-    dev_ms = sum(v['ms'] for v in prof.values())
+    prof, dev_ms = {}, None
+    if not lp.graphed:
+        K.Profiler.start(only=None)
+        lp.outer()
+        prof = K.Profiler.stop()
+        dev_ms = sum(v['ms'] for v in prof.values())
     status = K.lstm_persist_status(dev)
     finite = all(np.isfinite(v) for rec in lp.log for v in rec[2:])
+    extra = {}
+    if lp.graphed:
+        # where a pass's wall time goes: the three replays alone (inputs left as they are), and the host's share (loader +
+        # pick_words for three minibatches), which the Feeder overlaps with the replays
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(5):
+            for k in ("d1", "d0", "g"):
+                lp._graphs[k].replay()
+        torch.cuda.synchronize()
+        extra['replay_only_ms_per_step'] = (time.perf_counter() - t1) / 5 * 1e3
+        t1 = time.perf_counter()
+        for _ in range(6):
+            lp._host_pair()
+        extra['host_batches_ms_per_step'] = (time.perf_counter() - t1) / 2 * 1e3
+        extra['host_ms_per_step'] = dict(host_ms, issue_total=t_issue / args.steps * 1e3)
+        evs = getattr(lp, '_events', None)
+        if evs:       # AG_LOOP_EXP=ev: GPU duration of every replay and the idle time in front of it (last 12 replays)
+            tl = []
+            for (k0, a0, b0, h0_), (k1, a1, b1, h1_) in zip(evs[-13:-1], evs[-12:]):
+                tl.append((k1, round(a1.elapsed_time(b1), 2), round(b0.elapsed_time(a1), 2), round((h1_ - h0_) * 1e3, 2)))
+            extra['replay_timeline(key, gpu_ms, idle_before_ms, host_interval_ms)'] = tl
+    if lp.graphed:       # the captured iterations keep their scalars on the device: read the last ones once, after the timed region
+        ran, rd, rg = lp.outer()
+        finite = finite and all(np.isfinite(float(v)) for v in (rd['loss'], rd['acc_d'], rd['acc_g'], rg['loss'],
+                                                                 rg['feature_penalty'], rg['baseline']))
     ms = dt / args.steps * 1e3
     out = {
         'metric': 'audio-samples/sec per pass of the reference\'s training loop body (2 critic iterations + 1 generator iteration)',
@@ -255,12 +286,16 @@ def run_full(args, dev):
                                '(odd = FGSM branch, even = instance noise) + gencatchup 1, both Embedders, adversarial z, feature '
                                'penalty, REINFORCE surrogate, stop=never, rmsprop, clip d=1 g=0.1' % args.batch,
                    'global_batch': args.batch, 'clip_len': L, 'parallelism': 'dp1',
-                   'launch': 'eager (host reads of accuracies / baseline every iteration, as the reference)'},
+                   'launch': ('three hipGraphs (odd / even critic iteration, generator iteration) replayed over static inputs; '
+                              'loader batches uploaded and z / instance noise drawn between replays; no host read in the pass')
+                   if lp.graphed else 'eager (host reads of accuracies / baseline every iteration, as the reference)'},
         'persist_status': status, 'losses_finite': bool(finite),
-        'kernel_ms_per_step': dev_ms, 'launches_per_step': int(sum(v['n'] for v in prof.values())),
-        'kernel_table': [{'kernel': k, 'share': round(v['ms'] / dev_ms, 4), 'launches': v['n']}
-                         for k, v in sorted(prof.items(), key=lambda kv: -kv[1]['ms'])[:10]],
     }
+    if dev_ms:
+        out.update({'kernel_ms_per_step': dev_ms, 'launches_per_step': int(sum(v['n'] for v in prof.values())),
+                    'kernel_table': [{'kernel': k, 'share': round(v['ms'] / dev_ms, 4), 'launches': v['n']}
+                                     for k, v in sorted(prof.items(), key=lambda kv: -kv[1]['ms'])[:10]]})
+    out.update({k: v for k, v in extra.items() if v is not None})
     if not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline_full(min(args.cpu_batch, 8), 'rmsprop', min(32, os.cpu_count() or 1))
     print(json.dumps(out), flush=True)
@@ -337,6 +372,8 @@ def main():
                     help='f32 = BASELINE configs[1] (the headline); bf16 = configs[2]: every contraction rounds its '
                          'operands to bfloat16 and accumulates in fp32, gradients cross ranks as bfloat16; f32x3 = an EXPERIMENT, never '
                          'the headline: the large GEMMs on three bf16 MFMAs per product of bf16 hi + lo operand parts')
+    ap.add_argument('--full-launch', default='eager', choices=['eager', 'graph'],
+                    help='--workload full only: Python-issued launches, or the three captured iteration graphs')
     ap.add_argument('--workload', default='c2', choices=['c2', 'c4', 'c5', 'full'],
                     help='c2 = the headline (BASELINE configs[1]; with --dtype bf16: configs[2]); c4 = GRU-front '
                          'generator + conv critic (configs[3]); c5 = WGAN-GP with the conv critic (configs[4]): extra '

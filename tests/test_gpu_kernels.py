@@ -230,7 +230,10 @@ def test_conv_slab_views_and_residual_grad(K):
 
 @pytest.mark.parametrize('shape', [(64, 4096, 1480), (8192, 1024, 1024), (8192, 1, 512), (37, 53, 29),
                                    (64, 256, 1024), (130, 70, 5), (1, 1, 1), (2048, 4096, 200),
-                                   (256, 384, 4096), (200, 132, 2048)])   # LDS-DMA kernel: split-K, ragged tiles
+                                   (256, 384, 4096), (200, 132, 2048),     # LDS-DMA kernel: split-K, ragged tiles
+                                   # the larger tiles of gemm_tile.h as gemm_pick_tile selects them, ragged in both directions:
+                                   # 256 x 256, 256 x 128, 128 x 256
+                                   (4000, 4072, 64), (8100, 1000, 48), (128, 65500, 32)])
 @pytest.mark.parametrize('ta,tb', [(False, True), (False, False), (True, False), (True, True)])
 def test_gemm(K, shape, ta, tb):
     M, N, Kd = shape

@@ -62,3 +62,42 @@ for k, p in d.named_parameters():
     pos = tuple(int(v) for v in torch.unravel_index(torch.tensor(idx), eh.shape)) if eh.dim() else ()
     print('%-44s %10.2e %10.2e | %10.2e %10.2e | %s' % (k, float(eh.abs().max()) / mx, float(e3.abs().max()) / mx,
                                                       float(eh.norm()) / nr, float(e3.norm()) / nr, pos))
+
+
+# ---- the generator iteration (boundary-seeking loss through the frozen critic) ----------------------------------------------
+def oracle_g_grads(dtype):
+    g2 = O.Generator(frame_size=256, embed_size=100, noise_size=100, state_size=1024)
+    d2 = O.Discriminator(state_size=1024, embed_size=100)
+    g2.load_state_dict(go.state_dict()); d2.load_state_dict(do.state_dict())
+    g2, d2 = g2.to(dtype), d2.to(dtype)
+    for p in d2.parameters():
+        p.requires_grad_(False)
+    torch.set_default_dtype(dtype)
+    bb = {k: (t.to(dtype) if t.is_floating_point() else t) for k, t in b.items()}
+    fake, _, _, fl = g2(z=bb['z'], c=bb['c'], stop=stop)
+    cg, _, _, ng = d2(fake + bb['noise_fake'], fl, bb['c'])
+    bce = O.binary_cross_entropy_with_logits_per_sample
+    loss = (bce(cg, torch.full_like(cg, 0.5), weight=O.length_mask(cg.size(), ng)) / ng.to(dtype)).mean()
+    loss.backward()
+    torch.set_default_dtype(torch.float32)
+    return {k: p.grad.double() for k, p in g2.named_parameters() if p.grad is not None}, float(loss)
+
+
+d.load_state_dict(do.state_dict())
+o64, l64 = oracle_g_grads(torch.float64)
+o32, l32 = oracle_g_grads(torch.float32)
+opt_g = optim.make_optimizer(list(g.parameters()), 'adam', 1e-4)
+l = train.g_backward(g, d, opt_g, cu['c'], cu['z'], cu['noise_fake'])
+torch.cuda.synchronize()
+print()
+print('GENERATOR iteration: loss  hip %.8f  o32 %.8f  o64 %.8f' % (float(l), l32, l64))
+print('%-44s %10s %10s | %10s %10s | %10s' % ('tensor', 'hip max', 'o32 max', 'hip l2', 'o32 l2', '|grad|'))
+for k, p in g.named_parameters():
+    if (k.split('.')[-1].startswith('bias') and k.endswith('_v')) or k not in o64 or p.grad is None:
+        continue
+    r = o64[k]
+    gh, g3 = p.grad.detach().cpu().double(), o32[k]
+    mx, nr = float(r.abs().max()), float(r.norm())
+    eh, e3 = (gh - r), (g3 - r)
+    print('%-44s %10.2e %10.2e | %10.2e %10.2e | %10.2e' % (k, float(eh.abs().max()) / mx, float(e3.abs().max()) / mx,
+                                                          float(eh.norm()) / nr, float(e3.norm()) / nr, nr))

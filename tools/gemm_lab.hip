@@ -1,0 +1,326 @@
+// gemm_lab.hip -- a measuring bench for the fp32 GEMM class (C[M][N] = A[M][K] * B[N][K]^T, both operands k-contiguous:
+// gemm_dma_kernel<0,1> of csrc/gemm.hip).  Not part of the library: variants are built here, timed with HIP events, and only a
+// winner moves into csrc/.  Build: hipcc --offload-arch=gfx950 -O3 tools/gemm_lab.hip -o tools/gemm_lab
+//   ./tools/gemm_lab [M N K]       (default 16384 1024 1024)
+// Prints, per variant: microseconds, TFLOP/s, and the largest deviation from variant 0 on a sample of the output.
+//   peak      : v_mfma_f32_32x32x2_f32 back to back from registers (4 accumulators per wave, 4 waves per SIMD) + the shader
+//               clock measured against s_memrealtime - what the matrix pipes deliver with nothing else going on
+//   V<bm>x<bn>/<ti>x<tj>/s<stages>[/abl] : LDS-DMA tile kernel, wave tile ti x tj blocks of 32 x 32, `stages` LDS stages
+//               abl 1 = no DMA after the first stage (MFMA + LDS reads + barriers only), 2 = no output stores,
+//               4 = no LDS reads (MFMA from stale registers; DMA + barriers only)
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+
+#include "../audiogan_amd/csrc/gemm_tile.h"
+
+#define LDS_AS(p) ((__attribute__((address_space(3))) void*)(p))
+#define GLB_AS(p) ((const __attribute__((address_space(1))) void*)(p))
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+struct P {
+  const float* A; const float* B; float* C;
+  int M, N, K, lda, ldb, ldc;
+};
+
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mfma_peak_kernel(float* out, int iters, uint64_t* clk) {
+  f32x16 acc[4];
+  for (int i = 0; i < 4; ++i)
+    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+  float a = threadIdx.x * 1e-3f, b = 1.f + blockIdx.x * 1e-6f;
+  const uint64_t t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+  }
+  const uint64_t t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+  float s = 0.f;
+  for (int i = 0; i < 4; ++i)
+    for (int e = 0; e < 16; ++e) s += acc[i][e];
+  if (s == 12345.678f) out[threadIdx.x] = s;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { clk[0] = t1 - t0; clk[1] = r1 - r0; }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// LDS image of a stage: [BM + BN rows][16 k] floats (A rows first); the 16-byte piece kq of row r sits in slot kq ^ ((r>>2)&3).
+// A DMA instruction of a wave covers a row group of 16 rows (64 lanes x 16 B).  Pipeline: barrier at the TOP of an iteration
+// (after waiting for that iteration's stage), then the DMA of stage it + NST - 1 is issued, then the MFMAs of stage it.
+template <int BM, int BN, int TI, int TJ, int NST, int ABL>
+__global__ __launch_bounds__((BM / (32 * TI)) * (BN / (32 * TJ)) * 64) void lab_kernel(const P p) {
+  constexpr int WI = BM / (32 * TI), WJ = BN / (32 * TJ), NW = WI * WJ;
+  constexpr int ROWS = BM + BN, RG = ROWS / 16, IPS = RG / NW;     // DMA instructions per wave and stage
+  static_assert(RG % NW == 0, "row groups must divide over the waves");
+  constexpr int STAGE = ROWS * 16;                                // floats
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int wm0 = (wid / WJ) * 32 * TI, wn0 = (wid % WJ) * 32 * TJ;
+  // XCD-aware tile map: consecutive workgroup ids land on different XCDs; give every XCD a contiguous run of tiles
+  const int nbx = p.N / BN, nby = p.M / BM, nb = nbx * nby;
+  int id = blockIdx.x;
+  if (nb % 8 == 0) id = (id & 7) * (nb >> 3) + (id >> 3);
+  const int by = id / nbx, bx = id - by * nbx;
+  const int m0 = by * BM, n0 = bx * BN;
+
+  const float* src[IPS];
+  int dsto[IPS];
+#pragma unroll
+  for (int it = 0; it < IPS; ++it) {
+    const int g = wid + NW * it;
+    const int r = 16 * g + (lane >> 2), sl = lane & 3;
+    const int piece = sl ^ ((r >> 2) & 3);
+    src[it] = (r < BM) ? p.A + (int64_t)(m0 + r) * p.lda + 4 * piece : p.B + (int64_t)(n0 + r - BM) * p.ldb + 4 * piece;
+    dsto[it] = g * 256;           // wave-uniform float offset in the stage
+  }
+  auto stage = [&](int k0, int buf) {
+    float* S = sm + buf * STAGE;
+#pragma unroll
+    for (int it = 0; it < IPS; ++it) __builtin_amdgcn_global_load_lds(GLB_AS(src[it] + k0), LDS_AS(S + dsto[it]), 16, 0, 0);
+  };
+
+  f32x16 acc[TI][TJ];
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int j = 0; j < TJ; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int nk = p.K / 16;
+#pragma unroll
+  for (int s = 0; s < NST - 1; ++s)
+    if (s < nk) stage(16 * s, s);
+
+  f32x4 av[TI], bv[TJ];
+#pragma unroll
+  for (int i = 0; i < TI; ++i) av[i] = f32x4{1.f, 2.f, 3.f, 4.f} * (float)lane;
+#pragma unroll
+  for (int j = 0; j < TJ; ++j) bv[j] = f32x4{1.f, .5f, .25f, .125f};
+
+  for (int it = 0; it < nk; ++it) {
+    // the stage of this iteration must have landed; younger stages may stay in flight
+    if (NST >= 3 && it + NST - 2 < nk) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * IPS) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (!(ABL & 1) && it + NST - 1 < nk) stage(16 * (it + NST - 1), (it + NST - 1) % NST);
+    const float* S = sm + (it % NST) * STAGE;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      if (!(ABL & 4)) {
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
+          const int m = wm0 + 32 * i + l31;
+          av[i] = *reinterpret_cast<const f32x4*>(S + m * 16 + 4 * ((2 * q + h) ^ ((m >> 2) & 3)));
+        }
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+          const int n = BM + wn0 + 32 * j + l31;
+          bv[j] = *reinterpret_cast<const f32x4*>(S + n * 16 + 4 * ((2 * q + h) ^ ((n >> 2) & 3)));
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+          for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][e], bv[j][e], acc[i][j], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = m0 + wm0 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
+      float* dst = p.C + (int64_t)row * p.ldc + n0 + wn0 + l31;
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) {
+        if (ABL & 2) {
+          if (acc[i][j][e] == 12345.678f) dst[32 * j] = 1.f;
+        } else {
+          dst[32 * j] = acc[i][j][e];
+        }
+      }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+static float* dA; static float* dB; static float* dC; static float* dC0;
+static P gp;
+static hipEvent_t e0, e1;
+
+template <int BM, int BN, int TI, int TJ, int NST, int ABL>
+static void run(const char* name, bool ref = false) {
+  constexpr int NT = (BM / (32 * TI)) * (BN / (32 * TJ)) * 64;
+  const int lds = NST * (BM + BN) * 16 * 4;
+  auto k = lab_kernel<BM, BN, TI, TJ, NST, ABL>;
+  CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  if (gp.M % BM || gp.N % BN || gp.K % 16) { printf("%-28s skipped (shape)\n", name); return; }
+  const int grid = (gp.M / BM) * (gp.N / BN);
+  P p = gp;
+  p.C = ref ? dC0 : dC;
+  hipFuncAttributes fa;
+  CK(hipFuncGetAttributes(&fa, (const void*)k));
+  int occ = 0;
+  CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)k, NT, lds));
+  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k, dim3(grid), dim3(NT), lds, 0, p);
+  CK(hipDeviceSynchronize());
+  const int reps = 20;
+  CK(hipEventRecord(e0, 0));
+  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(k, dim3(grid), dim3(NT), lds, 0, p);
+  CK(hipEventRecord(e1, 0));
+  CK(hipEventSynchronize(e1));
+  float ms = 0;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  const double us = ms * 1e3 / reps, tf = 2.0 * gp.M * gp.N * gp.K / (us * 1e-6) / 1e12;
+  double dev = -1;
+  if (!ABL && !ref) {
+    const size_t n = 1 << 16;
+    std::vector<float> a(n), b(n);
+    const size_t off = (size_t)gp.M * gp.N / 2;
+    CK(hipMemcpy(a.data(), dC + off, n * 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(b.data(), dC0 + off, n * 4, hipMemcpyDeviceToHost));
+    dev = 0;
+    for (size_t i = 0; i < n; ++i) { double d = fabs((double)a[i] - b[i]); if (d > dev) dev = d; }
+    CK(hipMemset(dC, 0, (size_t)gp.M * gp.N * 4));
+  }
+  printf("%-28s %8.1f us %7.1f TF   vgpr %3d agpr? lds %6d  wg/CU %d  grid %d  dev %g\n", name, us, tf, fa.numRegs, lds, occ, grid, dev);
+  fflush(stdout);
+}
+
+// the library's kernel (gemm_tile.h) on the same product in all four operand layouts
+static float* dAt; static float* dBt;
+static void run_lib(int ta, int tb, int shape, int ksplit = 1) {
+  int bm, bn;
+  gemm_tile_dims(shape, bm, bn);
+  GemmP q;
+  q.A = ta ? dAt : dA; q.B = tb ? dB : dBt; q.C = dC; q.bias = nullptr; q.res = nullptr;
+  q.lda = ta ? gp.M : gp.K; q.ldb = tb ? gp.K : gp.N; q.ldc = gp.N; q.ldres = 0;
+  q.M = gp.M; q.N = gp.N; q.K = gp.K; q.alpha = 1.f; q.beta = 0.f; q.slope = 0.f; q.act = 0; q.vecA = q.vecB = 1; q.rb = 0;
+  q.ksplit = 1; q.kchunk = gp.K; q.part = nullptr;
+  CK(hipMemset(dC, 0, (size_t)gp.M * gp.N * 4));
+  for (int i = 0; i < 3; ++i) gemm_tile_launch(q, ta, tb, shape, 0);
+  CK(hipDeviceSynchronize());
+  const int reps = 20;
+  CK(hipEventRecord(e0, 0));
+  for (int i = 0; i < reps; ++i) gemm_tile_launch(q, ta, tb, shape, 0);
+  CK(hipEventRecord(e1, 0));
+  CK(hipEventSynchronize(e1));
+  float ms = 0;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  const double us = ms * 1e3 / reps, tf = 2.0 * gp.M * gp.N * gp.K / (us * 1e-6) / 1e12;
+  const size_t n = 1 << 16;
+  std::vector<float> a(n), b(n);
+  const size_t off = (size_t)gp.M * gp.N / 2;
+  CK(hipMemcpy(a.data(), dC + off, n * 4, hipMemcpyDeviceToHost));
+  CK(hipMemcpy(b.data(), dC0 + off, n * 4, hipMemcpyDeviceToHost));
+  double dev = 0;
+  for (size_t i = 0; i < n; ++i) { double d = fabs((double)a[i] - b[i]); if (d > dev) dev = d; }
+  printf("lib ta=%d tb=%d tile %dx%d   %8.1f us %7.1f TF   dev %g\n", ta, tb, bm, bn, us, tf, dev);
+  fflush(stdout);
+}
+
+template <int DBG>
+static void run_dbg() {
+  GemmP q;
+  q.A = dA; q.B = dB; q.C = dC; q.bias = nullptr; q.res = nullptr;
+  q.lda = gp.K; q.ldb = gp.K; q.ldc = gp.N; q.ldres = 0;
+  q.M = gp.M; q.N = gp.N; q.K = gp.K; q.alpha = 1.f; q.beta = 0.f; q.slope = 0.f; q.act = 0; q.vecA = q.vecB = 1; q.rb = 0;
+  q.ksplit = 1; q.kchunk = gp.K; q.part = nullptr;
+  auto k = gemm_tile_kernel<0, 1, 256, 256, 2, 4, DBG>;
+  const int lds = 2 * 512 * 16 * 4;
+  CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  dim3 grid(gp.N / 256, gp.M / 256, 1);
+  for (int rep = 0; rep < 2; ++rep) {
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k, grid, dim3(512), lds, 0, q);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0, 0));
+    for (int i = 0; i < 20; ++i) hipLaunchKernelGGL(k, grid, dim3(512), lds, 0, q);
+    CK(hipEventRecord(e1, 0));
+    CK(hipEventSynchronize(e1));
+    float ms = 0;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    printf("dbg %d (1 = lab placement, 2 = plain epilogue): %8.1f us %7.1f TF\n", DBG, ms * 50, 2.0 * gp.M * gp.N * gp.K / (ms * 50e-6) / 1e12);
+  }
+  fflush(stdout);
+}
+
+int main(int argc, char** argv) {
+  gp.M = argc > 3 ? atoi(argv[1]) : 16384; gp.N = argc > 3 ? atoi(argv[2]) : 1024; gp.K = argc > 3 ? atoi(argv[3]) : 1024;
+  gp.lda = gp.K; gp.ldb = gp.K; gp.ldc = gp.N;
+  CK(hipMalloc(&dA, (size_t)gp.M * gp.K * 4)); CK(hipMalloc(&dB, (size_t)gp.N * gp.K * 4));
+  CK(hipMalloc(&dC, (size_t)gp.M * gp.N * 4)); CK(hipMalloc(&dC0, (size_t)gp.M * gp.N * 4));
+  {
+    std::vector<float> a((size_t)gp.M * gp.K), b((size_t)gp.N * gp.K);
+    uint32_t s = 12345;
+    for (auto& v : a) { s = s * 1664525u + 1013904223u; v = ((s >> 9) & 0xFFFF) / 65536.f - 0.5f; }
+    for (auto& v : b) { s = s * 1664525u + 1013904223u; v = ((s >> 9) & 0xFFFF) / 65536.f - 0.5f; }
+    CK(hipMemcpy(dA, a.data(), a.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dB, b.data(), b.size() * 4, hipMemcpyHostToDevice));
+    std::vector<float> at(a.size()), bt(b.size());
+    for (int m = 0; m < gp.M; ++m) for (int k = 0; k < gp.K; ++k) at[(size_t)k * gp.M + m] = a[(size_t)m * gp.K + k];
+    for (int n = 0; n < gp.N; ++n) for (int k = 0; k < gp.K; ++k) bt[(size_t)k * gp.N + n] = b[(size_t)n * gp.K + k];
+    CK(hipMalloc(&dAt, at.size() * 4)); CK(hipMalloc(&dBt, bt.size() * 4));
+    CK(hipMemcpy(dAt, at.data(), at.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dBt, bt.data(), bt.size() * 4, hipMemcpyHostToDevice));
+  }
+  gp.A = dA; gp.B = dB;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  printf("M %d N %d K %d\n", gp.M, gp.N, gp.K);
+  {
+    uint64_t* clk; CK(hipMalloc(&clk, 16));
+    float* o; CK(hipMalloc(&o, 4096));
+    const int iters = 2000;
+    for (int wpc = 1; wpc <= 4; wpc *= 2) {      // workgroups (of 4 waves) per CU
+      hipLaunchKernelGGL(mfma_peak_kernel, dim3(256 * wpc), dim3(256), 0, 0, o, iters, clk);
+      CK(hipDeviceSynchronize());
+      CK(hipEventRecord(e0, 0));
+      hipLaunchKernelGGL(mfma_peak_kernel, dim3(256 * wpc), dim3(256), 0, 0, o, iters, clk);
+      CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+      float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+      uint64_t c[2]; CK(hipMemcpy(c, clk, 16, hipMemcpyDeviceToHost));
+      const double flop = 256.0 * wpc * 4 * iters * 32 * 4096.0;
+      printf("peak: %d waves/SIMD  %.1f us  %.1f TF   shader clock %.0f MHz (s_memtime %llu / s_memrealtime %llu @100MHz)\n", wpc,
+             ms * 1e3, flop / (ms * 1e-3) / 1e12, (double)c[0] / ((double)c[1] / 100.0), (unsigned long long)c[0], (unsigned long long)c[1]);
+    }
+  }
+  run<128, 128, 2, 2, 2, 0>("V128x128/2x2/s2", true);
+  run<128, 128, 2, 2, 2, 0>("V128x128/2x2/s2");
+  if (!getenv("LAB_DBG")) {
+    for (int shape = 0; shape < 4; ++shape)
+      for (int lay = 0; lay < 4; ++lay) run_lib(lay >> 1, lay & 1, shape);
+  }
+  if (getenv("LAB_DBG")) {
+    run<256, 256, 2, 4, 2, 0>("V256x256/2x4/s2 (8 waves)");
+    run_dbg<0>(); run_dbg<1>(); run_dbg<2>(); run_dbg<3>();
+    run<256, 256, 2, 4, 2, 0>("V256x256/2x4/s2 (8 waves)");
+    run_dbg<0>(); run_dbg<3>();
+    return 0;
+  }
+  if (getenv("LAB_LIB_ONLY")) return 0;
+  run<128, 128, 2, 2, 2, 1>("V128x128/2x2/s2/noDMA");
+  run<128, 128, 2, 2, 2, 2>("V128x128/2x2/s2/noStore");
+  run<128, 128, 2, 2, 2, 4>("V128x128/2x2/s2/noLDSread");
+  run<128, 128, 2, 2, 2, 5>("V128x128/2x2/s2/mfma+bar");
+  run<128, 128, 2, 2, 3, 0>("V128x128/2x2/s3");
+  run<128, 128, 2, 2, 4, 0>("V128x128/2x2/s4");
+  run<256, 128, 2, 2, 2, 0>("V256x128/2x2/s2 (8 waves)");
+  run<256, 128, 2, 2, 3, 0>("V256x128/2x2/s3 (8 waves)");
+  run<128, 256, 2, 4, 2, 0>("V128x256/2x4/s2 (4 waves)");
+  run<128, 256, 2, 4, 3, 0>("V128x256/2x4/s3 (4 waves)");
+  run<256, 128, 4, 2, 2, 0>("V256x128/4x2/s2 (4 waves)");
+  run<256, 128, 4, 2, 3, 0>("V256x128/4x2/s3 (4 waves)");
+  run<256, 256, 4, 4, 2, 0>("V256x256/4x4/s2 (4 waves)");
+  run<256, 256, 4, 4, 3, 0>("V256x256/4x4/s3 (4 waves)");
+  run<256, 256, 2, 4, 2, 0>("V256x256/2x4/s2 (8 waves)");
+  run<256, 256, 2, 4, 3, 0>("V256x256/2x4/s3 (8 waves)");
+  return 0;
+}
