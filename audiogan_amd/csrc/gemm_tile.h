@@ -23,6 +23,8 @@
 //     between a DMA and a later ds_read (checked in the ISA), the explicit s_waitcnt + s_barrier at the top is what orders them
 // Needs K % 16 == 0 (per K slice), 16-byte aligned rows, row counts % 4 == 0 for row-contiguous operands.
 #pragma once
+#include <type_traits>
+
 #include "common.h"
 
 struct GemmP {
@@ -72,7 +74,8 @@ __device__ __forceinline__ void xcd_place(int& bx, int& by, int& bz) {
 // TA / TB: 0 = A stored [M][K] / B stored [K][N], 1 = A stored [K][M] / B stored [N][K]   (as ag_gemm's ta / tb)
 // BM x BN: workgroup tile; TI x TJ: blocks of 32 x 32 per wave.  Dynamic LDS: 2 stages x (BM + BN) x 16 floats.
 template <int TA, int TB, int BM, int BN, int TI, int TJ, int DBG = 0>
-__global__ __launch_bounds__((BM / (32 * TI)) * (BN / (32 * TJ)) * 64) void gemm_tile_kernel(const GemmP p) {
+__global__ __launch_bounds__((BM / (32 * TI)) * (BN / (32 * TJ)) * 64, (BM * BN >= 65536 ? 2 : 4))      // (threads, waves per SIMD)
+void gemm_tile_kernel(const GemmP p) {
   constexpr int WJ = BN / (32 * TJ), NW = (BM / (32 * TI)) * WJ;
   constexpr int GA = BM / 16, GB = BN / 16, IPS = (GA + GB) / NW;     // 1-KiB DMA instructions: per operand, per wave
   static_assert((GA + GB) % NW == 0, "the DMA instructions of a stage must divide over the waves");
@@ -188,24 +191,66 @@ __global__ __launch_bounds__((BM / (32 * TI)) * (BN / (32 * TJ)) * 64) void gemm
     return;
   }
   if (p.ksplit == 1 && m0 + BM <= p.M && n0 + BN <= p.N) {
-    // interior tile: no bounds tests; the uniform epilogue options are tested once per element by scalar branches
+    // interior tile: no bounds tests.  The options are uniform: the reads of `res` / of C (beta) are issued EG rows at a time
+    // (all in flight together) under one branch each, the activation is chosen once around the arithmetic + stores - an
+    // epilogue that tested the options per element cost 7 % of a 256 x 256 tile's time (tools/gemm_lab.hip, LAB_DBG).
     const bool hb = p.bias != nullptr, hr = p.res != nullptr, hbeta = p.beta != 0.f;
+    constexpr int EG = 4;                        // rows per group: EG x TJ values of res and of C in registers
     float bj[TJ];
 #pragma unroll
     for (int j = 0; j < TJ; ++j) bj[j] = hb ? p.bias[n0 + wn0 + 32 * j + l31] : 0.f;
+    const float alpha = p.alpha, beta = p.beta, slope = p.slope;
+    const int act = p.act;
 #pragma unroll
     for (int i = 0; i < TI; ++i)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row = m0 + wm0 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
-        float* dst = p.C + (int64_t)row * p.ldc + n0 + wn0 + l31;
-        const float* rs = p.res + (int64_t)row * p.ldres + n0 + wn0 + l31;
+      for (int e0 = 0; e0 < 16; e0 += EG) {
+        float rv[EG][TJ], cv[EG][TJ];
+        float* dst[EG];
 #pragma unroll
-        for (int j = 0; j < TJ; ++j) {
-          float v = p.alpha * acc[i][j][e] + bj[j];
-          if (hbeta) v += p.beta * dst[32 * j];
-          dst[32 * j] = ag_res_act(v, hr, hr ? rs[32 * j] : 0.f, p.act, p.slope);
+        for (int u = 0; u < EG; ++u) {
+          const int e = e0 + u, row = m0 + wm0 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
+          dst[u] = p.C + (int64_t)row * p.ldc + n0 + wn0 + l31;
+#pragma unroll
+          for (int j = 0; j < TJ; ++j) rv[u][j] = cv[u][j] = 0.f;
         }
+        if (hr) {
+#pragma unroll
+          for (int u = 0; u < EG; ++u) {
+            const int e = e0 + u, row = m0 + wm0 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
+            const float* rs = p.res + (int64_t)row * p.ldres + n0 + wn0 + l31;
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) rv[u][j] = rs[32 * j];
+          }
+        }
+        if (hbeta) {
+#pragma unroll
+          for (int u = 0; u < EG; ++u)
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) cv[u][j] = dst[u][32 * j];
+        }
+        auto finish = [&](auto actc) {
+          constexpr int ACT = decltype(actc)::value;
+#pragma unroll
+          for (int u = 0; u < EG; ++u)
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) {
+              float v = alpha * acc[i][j][e0 + u] + bj[j];
+              v = __builtin_fmaf(beta, cv[u][j], v);          // (beta == 0: cv is 0, not C)
+              if (ACT == AG_ACT_LEAKY_GATE) {
+                v = rv[u][j] > 0.f ? v : v * slope;
+              } else {
+                v += rv[u][j];
+                if (ACT == AG_ACT_LEAKY) v = v > 0.f ? v : v * slope;
+                if (ACT == AG_ACT_TANH) v = tanhf(v);
+              }
+              dst[u][32 * j] = v;
+            }
+        };
+        if (act == AG_ACT_NONE) finish(std::integral_constant<int, AG_ACT_NONE>());
+        else if (act == AG_ACT_LEAKY) finish(std::integral_constant<int, AG_ACT_LEAKY>());
+        else if (act == AG_ACT_LEAKY_GATE) finish(std::integral_constant<int, AG_ACT_LEAKY_GATE>());
+        else finish(std::integral_constant<int, AG_ACT_TANH>());
       }
     return;
   }

@@ -68,8 +68,14 @@ class TrainLoop(object):
 
     # ---- minibatch pieces ---------------------------------------------------------------
     def _up(self, a, dtype):
-        t = torch.from_numpy(np.ascontiguousarray(a)).to(dtype)
-        return t.pin_memory().to(self.dev, non_blocking=True) if self.dev.type == 'cuda' else t
+        a = np.asarray(a)
+        if self.dev.type != 'cuda':
+            return torch.from_numpy(np.ascontiguousarray(a)).to(dtype)
+        # (a pinned buffer filled by numpy's single-threaded copy / conversion: Tensor.to / pin_memory fan a 2 MB copy out over
+        # every core and the idle pool's spinning eats a container's CPU quota - see train.Feeder.stage)
+        t = torch.empty(a.shape, dtype=dtype, pin_memory=True)
+        t.numpy()[...] = a
+        return t.to(self.dev, non_blocking=True)
 
     def _real(self):
         """``tovar`` of the loader's next minibatch (audiogan.py:94-97, :714): float32 clips padded to the frame grid"""
@@ -203,6 +209,7 @@ class TrainLoop(object):
         t3 = time.perf_counter()
         h = self.host_ms
         h['replay'] += (t1 - t0) * 1e3; h['loader'] += (t2 - t1) * 1e3; h['stage'] += (t3 - t2) * 1e3
+        h['loader_max'] = max(h.get('loader_max', 0.0), (t2 - t1) * 1e3); h['replay_max'] = max(h.get('replay_max', 0.0), (t1 - t0) * 1e3)
 
     # ---- iterations -----------------------------------------------------------------------
     def d_iteration(self):

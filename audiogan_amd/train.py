@@ -518,11 +518,13 @@ class Feeder(object):
         any_t = static[self.keys[0]]
         self.cuda = any_t.is_cuda
         self.n_staged = self.n_fed = 0
+        self.host_ms = dict(sync=0.0, pin=0.0, sync_max=0.0, pin_max=0.0)     # where stage() spends host time
         self._ready = [None, None]
         if self.cuda:
             self.copy_stream = torch.cuda.Stream(device=any_t.device)
             self.pinned = [{k: torch.empty(static[k].shape, dtype=static[k].dtype).pin_memory() for k in self.keys}
                            for _ in range(2)]
+            self.pinned_np = [{k: v.numpy() for k, v in sl.items()} for sl in self.pinned]
             self.dev = [{k: torch.empty_like(static[k]) for k in self.keys} for _ in range(2)]
             self._free = [None, None]            # event: the device staging slot has been consumed (D2D done)
         else:
@@ -552,10 +554,20 @@ class Feeder(object):
             for k, t in items:
                 self.dev[slot][k].copy_(t)
         else:
+            import time as _t
+            t0 = _t.perf_counter()
             if self._free[slot] is not None:
                 self._free[slot].synchronize()       # the pinned + device slot were consumed two batches ago
+            t1 = _t.perf_counter()
+            # (numpy's single-threaded memcpy, not Tensor.copy_: a CPU tensor copy of a few MB fans out over every core the
+            # machine has and the pool then spins through its idle time; under a container's CPU quota that gets the whole
+            # process throttled for the rest of the scheduler period - 90 ms stalls once per pass were measured)
             for k, t in items:
-                self.pinned[slot][k].copy_(t)
+                self.pinned_np[slot][k][...] = t.numpy()
+            t2 = _t.perf_counter()
+            self.host_ms['sync'] += (t1 - t0) * 1e3; self.host_ms['pin'] += (t2 - t1) * 1e3
+            self.host_ms['sync_max'] = max(self.host_ms['sync_max'], (t1 - t0) * 1e3)
+            self.host_ms['pin_max'] = max(self.host_ms['pin_max'], (t2 - t1) * 1e3)
             with torch.cuda.stream(self.copy_stream):
                 if self._free[slot] is not None:
                     self.copy_stream.wait_event(self._free[slot])

@@ -238,7 +238,7 @@ def run_full(args, dev):
     t_issue = time.perf_counter() - t0
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    host_ms = {k: (lp.host_ms[k] - h0[k]) / args.steps for k in h0}
+    host_ms = {k: ((lp.host_ms[k] - h0.get(k, 0.0)) / args.steps if not k.endswith('_max') else lp.host_ms[k]) for k in lp.host_ms}
     # the same pass with device time only (launches enqueued back to back inside one profiler window): how much of the wall
     # time is the host issuing ~3000 launches
     prof, dev_ms = {}, None
@@ -265,6 +265,7 @@ def run_full(args, dev):
             lp._host_pair()
         extra['host_batches_ms_per_step'] = (time.perf_counter() - t1) / 2 * 1e3
         extra['host_ms_per_step'] = dict(host_ms, issue_total=t_issue / args.steps * 1e3)
+        extra['feeder_host_ms_total'] = dict(lp._feeder.host_ms)
         evs = getattr(lp, '_events', None)
         if evs:       # AG_LOOP_EXP=ev: GPU duration of every replay and the idle time in front of it (last 12 replays)
             tl = []

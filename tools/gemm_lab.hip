@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <math.h>
 #include <stdlib.h>
 #include <vector>
 
@@ -263,8 +264,18 @@ int main(int argc, char** argv) {
   {
     std::vector<float> a((size_t)gp.M * gp.K), b((size_t)gp.N * gp.K);
     uint32_t s = 12345;
-    for (auto& v : a) { s = s * 1664525u + 1013904223u; v = ((s >> 9) & 0xFFFF) / 65536.f - 0.5f; }
-    for (auto& v : b) { s = s * 1664525u + 1013904223u; v = ((s >> 9) & 0xFFFF) / 65536.f - 0.5f; }
+// operand values: standard normal with full-entropy mantissas by default (what the step's tensors look like).  LAB_LOWENT=1:
+    // 16-bit uniform values - the matrix pipes draw less power on operands with few toggling bits and the clock stays higher,
+    // which flatters every variant by ~10 % (first lab runs); decisions are taken on the default
+    const bool lowent = getenv("LAB_LOWENT") != nullptr;
+    auto nextf = [&](uint32_t& st) {
+      if (lowent) { st = st * 1664525u + 1013904223u; return ((st >> 9) & 0xFFFF) / 65536.f - 0.5f; }
+      st = st * 1664525u + 1013904223u; const float u1 = ((st >> 8) + 1) / 16777217.f;
+      st = st * 1664525u + 1013904223u; const float u2 = (st >> 8) / 16777216.f;
+      return sqrtf(-2.f * logf(u1)) * cosf(6.2831853f * u2);
+    };
+    for (auto& v : a) v = nextf(s);
+    for (auto& v : b) v = nextf(s);
     CK(hipMemcpy(dA, a.data(), a.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dB, b.data(), b.size() * 4, hipMemcpyHostToDevice));
     std::vector<float> at(a.size()), bt(b.size());
     for (int m = 0; m < gp.M; ++m) for (int k = 0; k < gp.K; ++k) at[(size_t)k * gp.M + m] = a[(size_t)m * gp.K + k];

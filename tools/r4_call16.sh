@@ -1,0 +1,14 @@
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+timeout -k 10 600 python -m pytest tests/test_gpu_kernels.py -m gpu -q -x -k "gemm" > gpurun_out/r4_t16.log 2>&1; echo "gemm tests rc $?"; tail -3 gpurun_out/r4_t16.log
+python tools/prof_gemm.py > gpurun_out/r4_gemm_f32_tiles3.txt 2>&1; grep -v amdgpu.ids gpurun_out/r4_gemm_f32_tiles3.txt
+python bench.py --steps 20 --warmup 3 --no-cpu-baseline > gpurun_out/r4_bench16.json 2> gpurun_out/r4_bench16.err || tail -5 gpurun_out/r4_bench16.err
+python -c "import json,sys; d=json.load(open('gpurun_out/r4_bench16.json')); print('bench16', d['ms_per_step'], d.get('replay_check'), d.get('persist_status'), d['roofline']['kernel'], round(d['roofline']['frac'],3), d['roofline']['avg_launch_us']); [print('  ',k) for k in d['kernel_table'][:4]]"
+AG_LOOP_EXP=ev timeout -k 10 200 python bench.py --workload full --full-launch graph --steps 6 --warmup 2 --no-cpu-baseline > gpurun_out/r4_full_graph_ev.json 2> gpurun_out/r4_full_graph_ev.err || tail -15 gpurun_out/r4_full_graph_ev.err
+python -c "
+import json; d=json.load(open('gpurun_out/r4_full_graph_ev.json')); print('ev', d['ms_per_step'], d.get('replay_only_ms_per_step'), d.get('host_ms_per_step'), d.get('feeder_host_ms_total'))
+for k,v in d.items():
+    if k.startswith('replay_timeline'): print(k); [print('   ', x) for x in v]
+"
+timeout -k 10 200 python bench.py --workload full --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/r4_full_eager2.json 2> gpurun_out/r4_full_eager2.err || tail -5 gpurun_out/r4_full_eager2.err
+python -c "import json,sys; d=json.load(open('gpurun_out/r4_full_eager2.json')); print('eager', d['ms_per_step'], d['kernel_ms_per_step'], d['launches_per_step'])"
