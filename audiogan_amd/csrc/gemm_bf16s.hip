@@ -19,36 +19,7 @@
 // LDS-DMA writes LDS in lane order, so both swizzles are applied to the SOURCE address of a DMA lane and to the reader.
 // Needs K (and a K slice) % 64 == 0, 16-byte aligned rows, and row counts % 8 == 0 for KS operands.
 #include "common.h"
-
-typedef short hbf16x8 __attribute__((ext_vector_type(8)));
-typedef short hs16x4 __attribute__((ext_vector_type(4)));
-
-#define H_LDS_AS(p) ((__attribute__((address_space(3))) void*)(p))
-#define H_GLB_AS(p) ((const __attribute__((address_space(1))) void*)(p))
-
-struct GemmH {
-  const unsigned short* A;      // TA = 0: [M][K] (lda)   TA = 1: [K][M] (lda)
-  const unsigned short* B;      // TB = 1: [N][K] (ldb)   TB = 0: [K][N] (ldb)
-  float* C;                     // fp32 output (ldc) or NULL
-  unsigned short* C16;          // bf16 output (ldc16) or NULL
-  const float* bias;            // [N] fp32
-  const float* res;             // fp32 residual / gate source (ldres) or NULL
-  const unsigned short* res16;  // bf16 residual / gate source (ldres16) or NULL
-  const unsigned short* gate16; // bf16 SAVED OUTPUT of a LeakyReLU (ldgate16) or NULL: the result (after bias / res) is scaled by
-                                // that activation's derivative - a residual layer's backward (W^T da + da) gated by the layer below
-  float* part;                  // split-K slabs
-  int lda, ldb, ldc, ldc16, ldres, ldres16, ldgate16;
-  int M, N, K, ksplit, kchunk, act;
-  float alpha, beta, slope;
-};
-
-// KC image, rows of 2 * BK bytes: BK = 64: chunk c of row r in slot c ^ ((r >> 1) & 7);  BK = 32 (64-byte rows): slot c ^ ((r >> 2) & 3)
-template <int BK>
-__device__ __forceinline__ int h_kc_slot(int r, int c) {
-  return BK == 64 ? r * 128 + ((c ^ ((r >> 1) & 7)) << 4) : r * 64 + ((c ^ ((r >> 2) & 3)) << 4);
-}
-__device__ __forceinline__ int h_ks_f(int k) { return ((k & 3) << 2) | ((k >> 2) & 3); }
-__device__ __forceinline__ float h_bf(unsigned short v) { return __uint_as_float((unsigned)v << 16); }
+#include "gemm_bf16_tile.h"
 
 // BK: k per stage (64 or 32);  NBUF: LDS stages (2: the DMA of tile i+1 under the MFMAs of tile i;  1: one stage, 32 KiB (BK
 // 64) per workgroup - latency is hidden by co-resident workgroups instead, four per CU)

@@ -190,6 +190,21 @@ void gemm_tile_kernel(const GemmP p) {
       }
     return;
   }
+  if (p.ksplit > 1 && m0 + BM <= p.M && n0 + BN <= p.N) {
+    // interior tile of a K slice: the partial tile goes to its slab as it is (alpha applied), no tests per element
+    float* slab = p.part + (int64_t)bz * p.M * p.N;
+    const float alpha = p.alpha;
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = m0 + wm0 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
+        float* dst = slab + (int64_t)row * p.N + n0 + wn0 + l31;
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) dst[32 * j] = alpha * acc[i][j][e];
+      }
+    return;
+  }
   if (p.ksplit == 1 && m0 + BM <= p.M && n0 + BN <= p.N) {
     // interior tile: no bounds tests.  The options are uniform: the reads of `res` / of C (beta) are issued EG rows at a time
     // (all in flight together) under one branch each, the activation is chosen once around the arithmetic + stores - an

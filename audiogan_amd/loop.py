@@ -28,9 +28,6 @@ import torch
 
 from . import checkpoint, train
 
-import os as _os
-_EXP = _os.environ.get('AG_LOOP_EXP', '')     # measurement knob of tools/r4_call11.sh (nofeed | mainstream | noload)
-
 
 class TrainLoop(object):
     def __init__(self, g, d, e_g, e_d, opt_g, opt_d, loader, pick_words, batch_size, maxlen, device, noisescale=0.01,
@@ -63,6 +60,7 @@ class TrainLoop(object):
         # host milliseconds spent per phase of the captured iterations (enqueueing a replay, the loader, staging the upload,
         # feeding the static inputs), summed since construction: bench.py --workload full reports them per pass
         self.host_ms = dict(replay=0.0, loader=0.0, stage=0.0, inputs=0.0)
+        self.gpu_timeline = None         # set to a list to record (key, start event, end event, host time) per replay
         if self.graphed:
             assert stop == 'never' and self.dev.type == 'cuda', "graphed=True needs stop='never' and a CUDA device"
 
@@ -179,10 +177,9 @@ class TrainLoop(object):
         instance noise are drawn in place - the same draws, in the same order, as the eager iteration's torch.randn calls"""
         f, st = self._feeder, self._static
         t0 = time.perf_counter()
-        if 'nofeed' not in _EXP:
-            if f.n_fed >= f.n_staged:
-                f.stage(self._host_pair())
-            f.feed()
+        if f.n_fed >= f.n_staged:
+            f.stage(self._host_pair())
+        f.feed()
         st['z'].normal_()
         for k in ('n1', 'n2', 'n3')[:noises]:
             st[k].normal_().mul_(self.noisescale)
@@ -190,22 +187,18 @@ class TrainLoop(object):
 
     def _replay(self, key):
         t0 = time.perf_counter()
-        if 'ev' in _EXP:
+        if self.gpu_timeline is not None:     # (bench.py: GPU duration of each replay and the idle time between two)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
         self._graphs[key].replay()
-        if 'ev' in _EXP:
+        if self.gpu_timeline is not None:
             e1.record()
-            self._events = getattr(self, '_events', []) + [(key, e0, e1, t0)]
+            self.gpu_timeline.append((key, e0, e1, t0))
         t1 = time.perf_counter()
         # host work + upload of the NEXT minibatch overlap the replay just enqueued
-        pair = self._host_pair() if ('noload' not in _EXP or not hasattr(self, '_pair0')) else self._pair0
-        self._pair0 = pair
+        pair = self._host_pair()
         t2 = time.perf_counter()
-        if 'nofeed' not in _EXP:
-            if 'mainstream' in _EXP:
-                self._feeder.copy_stream = torch.cuda.current_stream()
-            self._feeder.stage(pair)
+        self._feeder.stage(pair)
         t3 = time.perf_counter()
         h = self.host_ms
         h['replay'] += (t1 - t0) * 1e3; h['loader'] += (t2 - t1) * 1e3; h['stage'] += (t3 - t2) * 1e3

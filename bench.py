@@ -218,8 +218,11 @@ def run_full(args, dev):
     generated clips (an input-gradient pass through D), adversarial z (a gradient pass through D and G), the feature-matching
     penalty over the critic's six activations, the two Embedder biLSTMs, the REINFORCE surrogate of the stop head; ragged
     real clips from the loader interface, fixed-length generated clips (stop='never': an untrained stop head would end every
-    clip after a frame or two), RMSprop + per-parameter clip as the reference.  Eager (Python-issued) launches: the
-    iterations read accuracies / the baseline back on the host like the reference does, which a hipGraph cannot."""
+    clip after a frame or two), RMSprop + per-parameter clip as the reference.
+    ``--full-launch graph`` (default): the three iteration bodies captured once (loop.TrainLoop(graphed=True)) and replayed
+    over static inputs, minibatches staged by train.Feeder behind the replays, accuracies / baseline kept on the device - with
+    a fixed critic_iter nothing in the pass needs the host (tests/test_loop.py: bit-identical to the eager loop);
+    ``--full-launch eager``: Python-issued launches with the host reads of the reference's iteration."""
     import audiogan_amd as A
     from audiogan_amd import kernels as K, loop, optim
     K.set_precision(args.dtype)
@@ -231,6 +234,8 @@ def run_full(args, dev):
     for _ in range(max(args.warmup, 1)):
         lp.outer()
     torch.cuda.synchronize()
+    if lp.graphed:
+        lp.gpu_timeline = []
     h0 = dict(lp.host_ms)
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -266,12 +271,12 @@ def run_full(args, dev):
         extra['host_batches_ms_per_step'] = (time.perf_counter() - t1) / 2 * 1e3
         extra['host_ms_per_step'] = dict(host_ms, issue_total=t_issue / args.steps * 1e3)
         extra['feeder_host_ms_total'] = dict(lp._feeder.host_ms)
-        evs = getattr(lp, '_events', None)
-        if evs:       # AG_LOOP_EXP=ev: GPU duration of every replay and the idle time in front of it (last 12 replays)
+        evs = lp.gpu_timeline
+        if evs:       # GPU duration of every replay and the idle time in front of it (last 12 replays)
             tl = []
             for (k0, a0, b0, h0_), (k1, a1, b1, h1_) in zip(evs[-13:-1], evs[-12:]):
                 tl.append((k1, round(a1.elapsed_time(b1), 2), round(b0.elapsed_time(a1), 2), round((h1_ - h0_) * 1e3, 2)))
-            extra['replay_timeline(key, gpu_ms, idle_before_ms, host_interval_ms)'] = tl
+            extra['replay_timeline'] = {'columns': ['graph', 'gpu_ms', 'gpu_idle_before_ms', 'host_interval_ms'], 'rows': tl}
     if lp.graphed:       # the captured iterations keep their scalars on the device: read the last ones once, after the timed region
         ran, rd, rg = lp.outer()
         finite = finite and all(np.isfinite(float(v)) for v in (rd['loss'], rd['acc_d'], rd['acc_g'], rg['loss'],
@@ -373,7 +378,7 @@ def main():
                     help='f32 = BASELINE configs[1] (the headline); bf16 = configs[2]: every contraction rounds its '
                          'operands to bfloat16 and accumulates in fp32, gradients cross ranks as bfloat16; f32x3 = an EXPERIMENT, never '
                          'the headline: the large GEMMs on three bf16 MFMAs per product of bf16 hi + lo operand parts')
-    ap.add_argument('--full-launch', default='eager', choices=['eager', 'graph'],
+    ap.add_argument('--full-launch', default='graph', choices=['eager', 'graph'],
                     help='--workload full only: Python-issued launches, or the three captured iteration graphs')
     ap.add_argument('--workload', default='c2', choices=['c2', 'c4', 'c5', 'full'],
                     help='c2 = the headline (BASELINE configs[1]; with --dtype bf16: configs[2]); c4 = GRU-front '

@@ -16,18 +16,18 @@ for M, N, Kd, ta, tb in shapes:
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     for it in range(2):
         ev[0].record()
-        for _ in range(10):
+        for _ in range(40):
             K.gemm(A, B, C, ta=bool(ta), tb=bool(tb), defer=False)
         ev[1].record(); torch.cuda.synchronize()
-    us = ev[0].elapsed_time(ev[1]) * 100
+    us = ev[0].elapsed_time(ev[1]) * 25
     # vendor library on the same shape (torch.matmul fp32 -> hipBLASLt / rocBLAS), as a practical ceiling
     At, Bt = (A.t() if ta else A), (B.t() if tb else B)
     torch.backends.cuda.matmul.allow_tf32 = False
     for it in range(2):
         ev[0].record()
-        for _ in range(10):
+        for _ in range(40):
             torch.matmul(At, Bt, out=C)
         ev[1].record(); torch.cuda.synchronize()
-    us2 = ev[0].elapsed_time(ev[1]) * 100
+    us2 = ev[0].elapsed_time(ev[1]) * 25
     print('M=%d N=%d K=%d ta=%d tb=%d: %.1f us  %.1f TF   (vendor sgemm %.1f us %.1f TF)' % (
         M, N, Kd, ta, tb, us, 2.0 * M * N * Kd / us / 1e6, us2, 2.0 * M * N * Kd / us2 / 1e6))
