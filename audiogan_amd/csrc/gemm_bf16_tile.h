@@ -1,5 +1,8 @@
-// gemm_bf16_tile.h -- the bf16-operand GEMM (ag_gemm_h) on tiles larger than 128 x 128.  Included by gemm_bf16s.hip and by
-// tools/gemm_lab_h.hip (the bench the tile shapes were chosen on).
+// gemm_bf16_tile.h -- shared definitions of the bf16-operand GEMM (ag_gemm_h: GemmH, the LDS image swizzles) and an
+// EXPERIMENT: the same product on tiles larger than 128 x 128.  Included by gemm_bf16s.hip (definitions only: it instantiates no
+// tile kernel) and by tools/gemm_lab_h.hip (the bench).  Result (round 4): built, parity-checked in the lab against float64,
+// measured, NOT dispatched - through ag_gemm_h over the critic's 11 shapes the 256 x 128 form took 613 us against 605 us of the
+// 128 x 128 kernel (tools/prof_gemm_h.py): +7 % on [16384 x 1024 x 1024], -13 % where it leaves one workgroup per CU (N = 512).
 //
 // v_mfma_f32_32x32x16_bf16 retires 16x the flops of the fp32 MFMA per operand byte, so what bounds the loop is LDS bandwidth:
 // a wave tile of TI x TJ blocks reads (TI + TJ) 1-KiB operand fragments per TI * TJ MFMAs of 32 cycles.  At 64 x 64 per wave
@@ -8,6 +11,7 @@
 // (gemm_bf16s.hip): KC [rows][64 k] for k-contiguous operands, KS [64 k][rows] read with ds_read_b64_tr_b16 for k-strided ones.
 #pragma once
 #include <type_traits>
+#include <utility>
 
 #include "common.h"
 
@@ -42,6 +46,15 @@ __device__ __forceinline__ int h_ks_f(int k) { return ((k & 3) << 2) | ((k >> 2)
 __device__ __forceinline__ float h_bf(unsigned short v) { return __uint_as_float((unsigned)v << 16); }
 
 
+template <int... I, class F>
+__device__ __forceinline__ void ag_static_for_impl(std::integer_sequence<int, I...>, F&& f) {
+  (f(std::integral_constant<int, I>()), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void ag_static_for(F&& f) {
+  ag_static_for_impl(std::make_integer_sequence<int, N>(), f);
+}
+
 // BM x BN: workgroup tile; TI x TJ: 32 x 32 blocks per wave (TI >= 2); NBUF: LDS stages; WPE: waves per SIMD the registers
 // are budgeted for.  Dynamic LDS: max(NBUF x (BM + BN) x 128 B, the epilogue's [64][BN + 4] fp32 image).
 template <int TA, int TB, int BM, int BN, int TI, int TJ, int NBUF, int WPE>
@@ -66,25 +79,25 @@ __global__ __launch_bounds__((BM / (32 * TI)) * (BN / (32 * TJ)) * 64, WPE) void
   const int bz = blockIdx.z;
   const int m0 = by * BM, n0 = bx * BN;
 
+  // this wave's DMA instructions: the first GA / NW fill the A image, the others the B image
+  static_assert(GA % NW == 0 && GB % NW == 0, "each operand image must divide over the waves");
+  constexpr int IA = GA / NW;
   const unsigned short* src[IPS];
-  int64_t kst[IPS];
   int dsto[IPS];
+  const int64_t ksa = AKS ? (int64_t)p.lda : 1, ksb = BKS ? (int64_t)p.ldb : 1;     // elements per unit of k
 #pragma unroll
   for (int it = 0; it < IPS; ++it) {
-    const int g = wid + NW * it;
-    const bool isA = g < GA;
-    const int gg = isA ? g : g - GA;
+    const bool isA = it < IA;
+    const int gg = wid + NW * (isA ? it : it - IA);
     const unsigned short* X = isA ? p.A : p.B;
     const int ld = isA ? p.lda : p.ldb, x0 = isA ? m0 : n0, R = isA ? p.M : p.N, BR = isA ? BM : BN;
     const bool ks = isA ? AKS : BKS;
     if (!ks) {      // KC: rows 8 gg .. 8 gg + 7, eight 16-byte chunks each
       const int r = 8 * gg + (lane >> 3), c = (lane & 7) ^ ((r >> 1) & 7);
       src[it] = X + (int64_t)min(x0 + r, R - 1) * ld + 8 * c;
-      kst[it] = 1;
     } else {        // KS: the gg-th KiB of the [64 k][BR rows] image
       const int j = gg * 64 + lane, cpr = BR / 8, k = j / cpr, ch = (j - k * cpr) ^ h_ks_f(k);
       src[it] = X + (int64_t)k * ld + min(x0 + 8 * ch, R - 8);
-      kst[it] = ld;
     }
     dsto[it] = (isA ? 0 : AIMG) + gg * 1024;
   }
@@ -92,7 +105,7 @@ __global__ __launch_bounds__((BM / (32 * TI)) * (BN / (32 * TJ)) * 64, WPE) void
     char* S = ht_sm + buf * STAGE;
 #pragma unroll
     for (int it = 0; it < IPS; ++it)
-      __builtin_amdgcn_global_load_lds(H_GLB_AS(src[it] + (int64_t)k0 * kst[it]), H_LDS_AS(S + dsto[it]), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(H_GLB_AS(src[it] + (int64_t)k0 * (it < IA ? ksa : ksb)), H_LDS_AS(S + dsto[it]), 16, 0, 0);
   };
 
   f32x16 acc[TI][TJ];
@@ -177,20 +190,17 @@ __global__ __launch_bounds__((BM / (32 * TI)) * (BN / (32 * TJ)) * 64, WPE) void
     typedef unsigned u32x2e __attribute__((ext_vector_type(2)));
     constexpr int CP = BN + 4;                                  // row pitch (floats): rows 4 apart on different banks
     float* Ct = reinterpret_cast<float*>(ht_sm);                // [64][CP] fp32
-#pragma unroll
-    for (int ps = 0; ps < BM / 64; ++ps) {
+    ag_static_for<BM / 64>([&](auto psc) {
+      constexpr int ps = decltype(psc)::value;
+      constexpr int i0 = ((64 * ps) % (32 * TI)) / 32;
       if (wr == (64 * ps) / (32 * TI)) {
-        constexpr int dummy = 0; (void)dummy;
-        const int i0 = ((64 * ps) % (32 * TI)) / 32;
 #pragma unroll
-        for (int i = 0; i < TI; ++i) {
-          if (i != i0 && i != i0 + 1) continue;
+        for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
           for (int e = 0; e < 16; ++e)
 #pragma unroll
             for (int j = 0; j < TJ; ++j)
-              Ct[(32 * (i - i0) + (e & 3) + 8 * (e >> 2) + 4 * h) * CP + wn0 + 32 * j + l31] = acc[i][j][e];
-        }
+              Ct[(32 * ii + (e & 3) + 8 * (e >> 2) + 4 * h) * CP + wn0 + 32 * j + l31] = acc[i0 + ii][j][e];
       }
       __syncthreads();
 #pragma unroll
@@ -235,12 +245,12 @@ __global__ __launch_bounds__((BM / (32 * TI)) * (BN / (32 * TJ)) * 64, WPE) void
         if (p.C16) *reinterpret_cast<u32x2e*>(p.C16 + row * p.ldc16 + col) = u32x2e{ag_pack_bf16(v[0], v[1]), ag_pack_bf16(v[2], v[3])};
       }
       __syncthreads();
-    }
+    });
     return;
   }
 
-#pragma unroll
-  for (int i = 0; i < TI; ++i)
+  ag_static_for<TI>([&](auto ic) {
+    constexpr int i = decltype(ic)::value;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int row = m0 + wm0 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
@@ -265,14 +275,22 @@ __global__ __launch_bounds__((BM / (32 * TI)) * (BN / (32 * TJ)) * 64, WPE) void
         if (p.C16) p.C16[(int64_t)row * p.ldc16 + col] = (unsigned short)(ag_pack_bf16(v, v) & 0xFFFFu);
       }
     }
+  });
 }
 
-// tile shapes: index -> (BM, BN, TI, TJ, NBUF, WPE)
-//   1: 256 x 128, 8 waves of 64 x 64,   one stage  (48 KiB, 2 workgroups per CU)
-//   2: 256 x 256, 8 waves of 64 x 128,  two stages (128 KiB, 1 per CU)
-//   3: 256 x 256, 4 waves of 128 x 128, two stages (128 KiB, 1 per CU, one wave per SIMD)
-//   4: 256 x 256, 8 waves of 64 x 128,  one stage  (67 KiB, 1 per CU... 2 if the registers allowed)
-#define AG_GEMMH_TILE_CASES(F) F(1, 256, 128, 2, 2, 1, 4) F(2, 256, 256, 2, 4, 2, 2) F(3, 256, 256, 4, 4, 2, 1) F(4, 256, 256, 2, 4, 1, 2)
+// tile shapes: index -> (BM, BN, TI, TJ, NBUF, WPE).  Measured on [16384 x 1024] x [1024 x 1024] (tools/gemm_lab_h.hip,
+// fp32 / bf16 output; the 128 x 128 kernel of gemm_bf16s.hip: 617-644 TF):
+//   1: 256 x 128, 8 waves of 64 x 64,   one stage  (48 KiB, 2 workgroups per CU)                    684 / 736 TF
+//   2: 256 x 256, 8 waves of 64 x 128,  two stages (128 KiB, 1 per CU)                              587 / 617
+//   3: 256 x 256, 4 waves of 128 x 128, two stages (128 KiB, 1 per CU, one wave per SIMD; spills)   419 / 435
+//   4: 256 x 256, 8 waves of 64 x 128,  one stage  (67 KiB, 1 per CU)                               560 / 580
+// With K = 512 .. 1024 a tile is 8-16 stages long: its prologue (first DMA round trip) and its epilogue (128 KiB of stores)
+// weigh as much as its MFMAs (14 us at peak for 34 GFLOP), and what helps is a second workgroup on the CU to run under
+// them - not the lower LDS traffic of a larger wave tile, which is what decided the fp32 kernel.
+#ifndef AG_GEMMH_TILE_CASES
+#define AG_GEMMH_TILE_CASES(F) F(1, 256, 128, 2, 2, 1, 4)
+#endif
+#define AG_GEMMH_TILE_CASES_ALL(F) F(1, 256, 128, 2, 2, 1, 4) F(2, 256, 256, 2, 4, 2, 2) F(3, 256, 256, 4, 4, 2, 1) F(4, 256, 256, 2, 4, 1, 2)
 
 template <int TA, int TB, int BM, int BN, int TI, int TJ, int NBUF, int WPE>
 static inline int gemm_bf16t_launch_one(const GemmH& p, hipStream_t st) {

@@ -19,6 +19,9 @@
 // LDS-DMA writes LDS in lane order, so both swizzles are applied to the SOURCE address of a DMA lane and to the reader.
 // Needs K (and a K slice) % 64 == 0, 16-byte aligned rows, and row counts % 8 == 0 for KS operands.
 #include "common.h"
+// (GemmH, the image swizzles - and the larger-tile kernel that tools/gemm_lab_h.hip measured and that did NOT beat this one
+// on the critic's shapes: see the table in the header)
+#define AG_GEMMH_TILE_CASES(F)
 #include "gemm_bf16_tile.h"
 
 // BK: k per stage (64 or 32);  NBUF: LDS stages (2: the DMA of tile i+1 under the MFMAs of tile i;  1: one stage, 32 KiB (BK

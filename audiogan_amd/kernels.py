@@ -887,7 +887,21 @@ def _work_gemm(A, B, Cm, ta=False, tb=False, *a_, **kw):
     if bf or x3:
         key = 'gemm_bf16_kernel<%d,%d%s>' % (int(ta), int(tb), ',x3' if x3 else '')
     elif dma:
-        key = 'gemm_dma_kernel<%d,%d>' % (int(ta), int(tb))
+        # mirrors gemm_pick_tile (gemm.hip): the largest tile that still gives every CU a workgroup
+        act = kw.get('act', ACT_NONE)
+        ks = 1
+        wsn = int(lib.ag_gemm_ws_numel(M, N, Kd, int(act)))
+        if wsn:
+            kchunk = _cdiv(_cdiv(Kd, wsn // (M * N)), 64) * 64
+            ks = _cdiv(Kd, kchunk)
+        best, best_t = None, 0.0
+        for (bm, bn, ti, tj), rate in (((256, 256, 2, 4), 137.), ((256, 128, 2, 2), 133.), ((128, 256, 2, 2), 133.),
+                                       ((128, 128, 2, 2), 120.)):
+            wgs = _cdiv(M, bm) * _cdiv(N, bn) * ks
+            t = _cdiv(wgs, 256) * bm * bn / rate + 1e-9 * wgs * bm * bn
+            if best is None or t < best_t * 0.98:
+                best, best_t = (bm, bn, ti, tj), t
+        key = 'gemm_tile_kernel<%d,%d,%d,%d,%d,%d,0>' % ((int(ta), int(tb)) + best)
     else:
         key = 'gemm_kernel<%s,%d,%d>' % ('2,2,2,2' if use128 else '1,1,2,2', int(ta), int(tb))
     return key, 2.0 * M * N * Kd, 4.0 * (M * Kd + N * Kd + M * N)

@@ -106,12 +106,12 @@ def one_step(train, g, d, opt_g, opt_d, b, hook_d=None, hook_g=None, overlap=Fal
 
 
 def pmc_traffic(kernel, dtype='f32'):
-    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r03_pmc_traffic.json, for
-    --dtype bf16 profiles/r03_pmc_traffic_bf16.json; the round-2 files when a round-3 one is absent: FETCH_SIZE and
+    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r04_pmc_traffic.json, for
+    --dtype bf16 profiles/r04_pmc_traffic_bf16.json; an earlier round's file when the newest has no entry: FETCH_SIZE and
     WRITE_SIZE in separate passes, gfx950 x2 read correction applied); the instantiation if it was profiled under that
     name, else the kernel class; None when neither was."""
     suffix = '_bf16' if dtype == 'bf16' else ''
-    for rnd in ('r03', 'r02'):
+    for rnd in ('r04', 'r03', 'r02'):
         path = os.path.join(ROOT, 'profiles', '%s_pmc_traffic%s.json' % (rnd, suffix))
         if not os.path.exists(path):
             continue
@@ -612,6 +612,21 @@ def main():
                                      'gpu_ms_per_step': cms, 'flops_per_step': sum(v['flops'] for v in cv),
                                      'alg_gbs': sum(v['bytes'] for v in cv) / (cms * 1e-3) / 1e9,
                                      'share_of_gpu_time': cms / sum(v['ms'] for v in disc.values())}
+            # the dense products as a class (Linear / LSTM input projections / their gradients): every fp32 GEMM launch of
+            # the step together, and the heaviest instantiation (a row of profiles/*_bench_kernel_stats.csv) by itself
+            gm = {k: v for k, v in disc.items() if k.startswith(('gemm_tile_kernel', 'gemm_kernel', 'gemm_bf16'))}
+            if gm:
+                gms = sum(v['ms'] for v in gm.values())
+                gtf = sum(v['flops'] for v in gm.values()) / (gms * 1e-3) / 1e12
+                gpeak = PEAK_BF16_MFMA_TFLOPS if args.dtype == 'bf16' else PEAK_F32_MFMA_TFLOPS
+                hk, hv = max(gm.items(), key=lambda kv: kv[1]['ms'])
+                out['gemm_class'] = {'bound': 'mfma', 'achieved': gtf, 'peak': gpeak, 'unit': 'TFLOP/s', 'frac': gtf / gpeak,
+                                     'gpu_ms_per_step': gms, 'launches_per_step': sum(v['n'] for v in gm.values()),
+                                     'share_of_gpu_time': gms / sum(v['ms'] for v in disc.values()),
+                                     'heaviest': {'kernel': hk, 'launches_per_step': hv['n'],
+                                                  'avg_launch_us': hv['ms'] / hv['n'] * 1e3,
+                                                  'achieved': hv['flops'] / (hv['ms'] * 1e-3) / 1e12,
+                                                  'frac': hv['flops'] / (hv['ms'] * 1e-3) / 1e12 / gpeak}}
             tot = sum(x['ms'] for x in disc.values())
             out['kernel_table'] = [
                 {'kernel': k, 'share': round(v['ms'] / tot, 4), 'launches': v['n'],

@@ -296,7 +296,8 @@ def _b16(*shape, gen, scale=1.0):
     return (torch.randn(*shape, generator=gen) * scale).to(torch.bfloat16)
 
 
-@pytest.mark.parametrize('shape', [(8192, 1024, 1024), (2048, 512, 2048), (384, 200, 128), (128, 128, 64), (16384, 2048, 512)])
+@pytest.mark.parametrize('shape', [(8192, 1024, 1024), (2048, 512, 2048), (384, 200, 128), (128, 128, 64), (16384, 2048, 512),
+                                   (8200, 1000, 128)])      # (ragged tiles in both directions on a full-chip grid)
 @pytest.mark.parametrize('ta,tb', [(False, True), (False, False), (True, False), (True, True)])
 def test_gemm_h_all_operand_layouts(K, shape, ta, tb):
     """k-contiguous operands through ds_read_b128, k-strided ones through the transposed LDS read, LDS-DMA staging with both
@@ -316,6 +317,36 @@ def test_gemm_h_all_operand_layouts(K, shape, ta, tb):
     got16, want16 = c16.float().cpu().double(), ref.float().bfloat16().double()
     assert float((got16 - want16).abs().max()) <= 2.0 ** -7 * scale       # one bf16 ulp at the top of the range
     assert float(((got16 - want16).abs() > 0).double().mean()) < 0.02       # (ties / last-bit sums only)
+
+
+def test_gemm_h_epilogues_at_full_size(K):
+    """the epilogue forms of the critic's heads at the critic's size (a full-chip grid of tiles through the LDS-transposed
+    epilogue): bias + bf16 residual + LeakyReLU to a bf16 output, fp32 residual into a pitched fp32 view, the gate forms, beta = 1"""
+    gen = torch.Generator().manual_seed(78)
+    M, N, Kd = 8192, 1024, 256
+    a, w = _b16(M, Kd, gen=gen).cuda(), _b16(N, Kd, gen=gen, scale=0.05).cuda()
+    bias = torch.randn(N, generator=gen).cuda()
+    res16, res32 = _b16(M, N, gen=gen).cuda(), torch.randn(M, N, generator=gen).cuda()
+    lin = a.double() @ w.double().t() + bias.double()
+    y16 = torch.empty(M, N, dtype=torch.bfloat16).cuda()
+    K.gemm_h(a, w, C16=y16, tb=True, bias=bias, res=res16, act=K.ACT_LEAKY)
+    ref = F.leaky_relu(lin + res16.double(), 0.01)
+    assert float((y16.double() - ref.float().bfloat16().double()).abs().max()) <= 2.0 ** -7 * float(ref.abs().max())
+    wide = torch.zeros(M, N + 24).cuda()
+    K.gemm_h(a, w, C=wide[:, 8:8 + N], tb=True, bias=bias, res=res32)
+    assert float((wide[:, 8:8 + N].double() - (lin + res32.double())).abs().max()) <= 1e-4 * float(lin.abs().max())
+    assert not wide[:, :8].any() and not wide[:, 8 + N:].any()
+    K.gemm_h(a, w, C=wide[:, 8:8 + N], tb=True, beta=1.0)                     # accumulate on top
+    assert float((wide[:, 8:8 + N].double() - (2 * lin - bias.double() + res32.double())).abs().max()) <= 2e-4 * float(lin.abs().max())
+    da, sv = _b16(M, N, gen=gen).cuda(), _b16(M, N, gen=gen).cuda()
+    w2 = _b16(N, N, gen=gen, scale=0.05).cuda()
+    dp = torch.empty(M, N, dtype=torch.bfloat16).cuda()
+    K.gemm_h(da, w2, C16=dp, res=da, gate=sv)
+    ref = (da.double() @ w2.double() + da.double()) * torch.where(sv.double() > 0, 1.0, 0.01)
+    assert float((dp.double() - ref.float().bfloat16().double()).abs().max()) <= 2.0 ** -7 * float(ref.abs().max())
+    K.gemm_h(da, w2, C16=dp, res=sv, act=K.ACT_LEAKY_GATE)
+    ref = (da.double() @ w2.double()) * torch.where(sv.double() > 0, 1.0, 0.01)
+    assert float((dp.double() - ref.float().bfloat16().double()).abs().max()) <= 2.0 ** -7 * float(ref.abs().max())
 
 
 def test_gemm_h_epilogues_views_and_split_k(K):

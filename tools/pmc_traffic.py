@@ -1,6 +1,6 @@
 """Turn two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs, as MI355X_MICROARCH.md prescribes)
 of `python bench.py --steps 2 --warmup 1 --no-graph --no-roofline --no-cpu-baseline` into
-profiles/r03_pmc_traffic.json: fabric bytes per launch for every kernel class.
+profiles/rNN_pmc_traffic.json: fabric bytes per launch for every kernel class.
 
     rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_f -o f -- python bench.py ...
     rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_w -o w -- python bench.py ...
@@ -45,7 +45,7 @@ def main():
         wk = w_tot.get(k, 0.0) / max(w_cnt.get(k, 1), 1)
         out[k] = {'launches': n, 'fetch_kb': round(fk, 1), 'write_kb': round(wk, 1),
                   'bytes_per_launch': int(1024 * (2 * fk + wk))}
-    dst = sys.argv[3] if len(sys.argv) > 3 else 'profiles/r03_pmc_traffic.json'
+    dst = sys.argv[3] if len(sys.argv) > 3 else 'profiles/r04_pmc_traffic.json'
     json.dump(out, open(dst, 'w'), indent=1)
     print('wrote %s with %d kernels' % (dst, len(out) - 1))
 
