@@ -1,0 +1,62 @@
+"""where do the isolated large deviations of the critic's INPUT gradient in bf16 mode come from?  (VERDICT round 3, weak #2:
+tests/test_bf16.py bounds d(loss)/d(waveform) at 0.2 of its largest entry while every other gradient holds 5e-2.)
+The setting of test_networks_bf16_vs_rounded_oracle; the critic's conv activations of both sides give the LeakyReLU gate
+of every unit: a unit whose pre-activation is within bf16 rounding of zero takes different branches on the two sides (a
+"flip").  Prints flips per layer, the error of the input gradient overall and OUTSIDE the receptive fields of flipped units.
+    python tools/diag_bf16_xgrad.py > gpurun_out/r4_diag_bf16_xgrad.txt"""
+import sys
+import torch
+sys.path.insert(0, '.')
+import audiogan_amd as A
+from audiogan_amd import kernels as K
+from oracle import audiogan_oracle as O
+from tests.test_bf16 import _small_models
+
+K.set_precision('bf16')
+go, do, g, d = _small_models(A)
+B, T, fs = 16, 16, 64
+gen = torch.Generator().manual_seed(32)
+z, c = torch.randn(B, T, 16, generator=gen), torch.randn(B, 16, generator=gen)
+lens = torch.randint(300, T * fs + 1, (B,), generator=gen)
+lens[0] = T * fs
+wl = torch.randn(B, T * fs // 16, generator=gen)
+stop = torch.zeros(B, T, dtype=torch.long)
+with O.bf16_mode(store=d.stores_bf16(B, 'cuda')):
+    xo = go(z=z, c=c, stop=stop)[0].detach().requires_grad_(True)
+    lo, actso, _, _ = do(xo, lens, c)
+    (lo * wl).sum().backward()
+x = xo.detach().clone().cuda().requires_grad_(True)          # the SAME waveform on both sides: only the critic differs
+l, acts, _, _ = d(x, lens.cuda(), c.cuda())
+(l * wl.cuda()).sum().backward()
+gx, gr = x.grad.cpu(), xo.grad
+scale = float(gr.abs().max())
+err = (gx - gr).abs() / scale
+L = gx.size(1)
+print('input gradient: max |err| / max|ref| = %.4f, relative L2 %.2e' % (float(err.max()), float((gx - gr).norm() / gr.norm())))
+under = torch.zeros(B, L, dtype=torch.bool)
+for i, (a, b) in enumerate(zip(acts, actso)):
+    a, b = a.detach().cpu().float(), b.detach().float()
+    flip = (a > 0) != (b > 0)                    # [B, C, L_i]
+    # only units inside the clip's valid length matter (the others are masked to zero on both sides)
+    n = int(flip.sum())
+    stride, R = 2 ** (i + 1), 3 * (2 ** (i + 1) - 1)
+    any_t = flip.any(1)                          # [B, L_i]
+    for bb, u in any_t.nonzero().tolist():
+        under[bb, max(0, u * stride - R):min(L, u * stride + R + 1)] = True
+    out = err[~under]
+    print('layer %d: %6d of %8d units flipped (%.3f %%); positions under a flipped unit of layers 0..%d: %.1f %%; '
+          'max err outside them %.4f' % (i, n, flip.numel(), 100.0 * n / flip.numel(), i, 100.0 * float(under.float().mean()),
+                                         float(out.max()) if out.numel() else 0.0))
+top = err.flatten().topk(12)
+print('largest deviations (clip, t, err, under a flipped unit?):')
+for v, idx in zip(top.values.tolist(), top.indices.tolist()):
+    bb, t = divmod(idx, L)
+    print('   clip %2d  t %4d  %.4f  %s  (len %d)' % (bb, t, v, bool(under[bb, t]), int(lens[bb])))
+# how close to zero were the flipped units?  (|activation| relative to the layer's rms, on the oracle side)
+for i, (a, b) in enumerate(zip(acts, actso)):
+    a, b = a.detach().cpu().float(), b.detach().float()
+    flip = (a > 0) != (b > 0)
+    if flip.any():
+        pre = torch.where(b > 0, b, b / 0.01)      # undo the LeakyReLU: the pre-activation
+        print('layer %d: |pre-activation| of flipped units: max %.2e, median %.2e; layer rms %.2e' % (
+            i, float(pre[flip].abs().max()), float(pre[flip].abs().median()), float(pre.pow(2).mean().sqrt())))
