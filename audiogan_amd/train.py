@@ -6,7 +6,7 @@ import torch
 from . import kernels as K
 from .common import frozen, network_backward
 from .ops import CriticInputFn
-from .extras import adversarial_movement_d, adversarially_sample_z, calc_dists, feature_penalty
+from .extras import adversarial_movement_d, adversarially_sample_z, calc_dists, feature_penalty, feature_penalty_fused  # noqa: F401
 from .losses import length_mask, masked_bce_mean, only_stopper_trains, real_fake_targets, stopper_surrogate_loss
 
 _SIDE = {}
@@ -287,7 +287,7 @@ def g_step_full(g, d, e_g, e_d, opt_g, real, real_len, cs, cl, z0, noise_real, n
         cls_g, hs_g, hl_g, nf_g = d(fake, fake_len, embed_d)
         with torch.no_grad():
             _, hs_d, hl_d, _ = d(real + noise_real, real_len, embed_d)
-        pen = feature_penalty(calc_dists(hs_d, hl_d), calc_dists(hs_g, hl_g), B)
+        pen = feature_penalty_fused(hs_d, hl_d, hs_g, hl_g, B)
         bce, per = masked_bce_mean(cls_g, 0.5 if g_optim == 'boundary_seeking' else 0.0, nf_g.contiguous())
         reward = -(per / nf_g.float())                       # per-sample loss, a constant for the stop head
         rmean = reward.mean().detach()

@@ -175,7 +175,29 @@ def test_networks_bf16_vs_rounded_oracle(K, bf16):
     for i, (a, b) in enumerate(zip(acts, actso)):
         close_bf16(a, b, 'act%d' % i)
     # the critic's input gradient first: it is what the generator's gradients are made of (a mismatch further down with
-    # this one green points at the generator's backward, red at the critic's)
+    # this one green points at the generator's backward, red at the critic's).
+    # (1) the critic ALONE: the oracle's waveform fed to the HIP critic - same point, so the declared activation-class bound
+    #     holds (measured 3.4e-3 of the largest entry, 1.3e-3 relative L2: tools/diag_bf16_xgrad.py)
+    xs = xo.detach().clone().cuda().requires_grad_(True)
+    ls = d(xs, lens.cuda(), c.cuda())[0]
+    gs, = torch.autograd.grad((ls * wl.cuda()).sum(), xs)
+    close_bf16(gs, xo.grad, 'd(loss)/d(waveform), same waveform', elem=1e-2, l2=3e-3)
+    # (2) end to end each critic reads ITS OWN generator's waveform (2.5e-4 apart in relative L2), i.e. the two gradients are
+    #     taken at different points: a LeakyReLU unit whose pre-activation is within that distance of zero takes the other
+    #     branch on one side (1-2 units of 262144 here) and the input positions in its receptive field move by up to 7 % of
+    #     the tensor's maximum.  The conv activations of both sides say which units flipped: outside their receptive fields
+    #     the same-point bound must hold, inside them 0.2 (the bound is now derived, not fitted).
+    under = torch.zeros(x.shape, dtype=torch.bool)
+    nflip = 0
+    for i, (a, b) in enumerate(zip(acts, actso)):
+        flip = (a.detach().cpu() > 0) != (b.detach() > 0)
+        nflip += int(flip.sum())
+        stride, R = 2 ** (i + 1), 3 * (2 ** (i + 1) - 1)            # k7 s2 p3 layers: field of unit u of layer i
+        for bb, u in flip.any(1).nonzero().tolist():
+            under[bb, max(0, u * stride - R):min(x.size(1), u * stride + R + 1)] = True
+    assert nflip <= 1e-4 * sum(a.numel() for a in acts) and float(under.float().mean()) <= 0.05, (nflip, float(under.float().mean()))
+    ge, gscale = (x.grad.cpu() - xo.grad).abs(), float(xo.grad.abs().max())
+    assert float(ge[~under].max()) <= 1e-2 * gscale, ('d(loss)/d(waveform) outside flipped units', float(ge[~under].max()) / gscale)
     close_bf16(x.grad, xo.grad, 'd(loss)/d(waveform)', elem=0.2, l2=2e-2)
     for mod, ref in ((d, do), (g, go)):
         rp = dict(ref.named_parameters())

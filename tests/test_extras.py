@@ -32,6 +32,12 @@ def _run(dev, A):
     po = O.feature_penalty(O.calc_dists(hsro, hlro), O.calc_dists(hso, hlo), B)
     p = X.feature_penalty(X.calc_dists(hsr, hlr), X.calc_dists(hs, hl), B)
     np.testing.assert_allclose(float(p), float(po), rtol=1e-3)
+    # the one-reduction form train.g_step_full uses: the same penalty and the same gradients into the activations
+    gr = torch.autograd.grad(p, list(hs), retain_graph=True)
+    pf = X.feature_penalty_fused(hsr, hlr, hs, hl, B)
+    np.testing.assert_allclose(float(pf), float(p), rtol=1e-5)
+    for a_, b_ in zip(torch.autograd.grad(pf, list(hs), retain_graph=True), gr):
+        np.testing.assert_allclose(a_.cpu().numpy(), b_.cpu().numpy(), rtol=1e-4, atol=1e-6 * float(b_.abs().max()))
     po.backward(); p.backward()
     for (k, q), (_, qo) in zip(g.named_parameters(), go.named_parameters()):
         if k.split('.')[-1].startswith('bias') and k.endswith('_v'):

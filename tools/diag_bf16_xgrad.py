@@ -25,38 +25,39 @@ with O.bf16_mode(store=d.stores_bf16(B, 'cuda')):
     xo = go(z=z, c=c, stop=stop)[0].detach().requires_grad_(True)
     lo, actso, _, _ = do(xo, lens, c)
     (lo * wl).sum().backward()
-x = xo.detach().clone().cuda().requires_grad_(True)          # the SAME waveform on both sides: only the critic differs
-l, acts, _, _ = d(x, lens.cuda(), c.cuda())
-(l * wl.cuda()).sum().backward()
-gx, gr = x.grad.cpu(), xo.grad
+gr = xo.grad
 scale = float(gr.abs().max())
-err = (gx - gr).abs() / scale
-L = gx.size(1)
-print('input gradient: max |err| / max|ref| = %.4f, relative L2 %.2e' % (float(err.max()), float((gx - gr).norm() / gr.norm())))
-under = torch.zeros(B, L, dtype=torch.bool)
-for i, (a, b) in enumerate(zip(acts, actso)):
-    a, b = a.detach().cpu().float(), b.detach().float()
-    flip = (a > 0) != (b > 0)                    # [B, C, L_i]
-    # only units inside the clip's valid length matter (the others are masked to zero on both sides)
-    n = int(flip.sum())
-    stride, R = 2 ** (i + 1), 3 * (2 ** (i + 1) - 1)
-    any_t = flip.any(1)                          # [B, L_i]
-    for bb, u in any_t.nonzero().tolist():
-        under[bb, max(0, u * stride - R):min(L, u * stride + R + 1)] = True
-    out = err[~under]
-    print('layer %d: %6d of %8d units flipped (%.3f %%); positions under a flipped unit of layers 0..%d: %.1f %%; '
-          'max err outside them %.4f' % (i, n, flip.numel(), 100.0 * n / flip.numel(), i, 100.0 * float(under.float().mean()),
-                                         float(out.max()) if out.numel() else 0.0))
-top = err.flatten().topk(12)
-print('largest deviations (clip, t, err, under a flipped unit?):')
-for v, idx in zip(top.values.tolist(), top.indices.tolist()):
-    bb, t = divmod(idx, L)
-    print('   clip %2d  t %4d  %.4f  %s  (len %d)' % (bb, t, v, bool(under[bb, t]), int(lens[bb])))
-# how close to zero were the flipped units?  (|activation| relative to the layer's rms, on the oracle side)
-for i, (a, b) in enumerate(zip(acts, actso)):
-    a, b = a.detach().cpu().float(), b.detach().float()
-    flip = (a > 0) != (b > 0)
-    if flip.any():
-        pre = torch.where(b > 0, b, b / 0.01)      # undo the LeakyReLU: the pre-activation
-        print('layer %d: |pre-activation| of flipped units: max %.2e, median %.2e; layer rms %.2e' % (
-            i, float(pre[flip].abs().max()), float(pre[flip].abs().median()), float(pre.pow(2).mean().sqrt())))
+L = gr.size(1)
+
+
+def analyse(x_in, title):
+    print('==== ' + title)
+    x = x_in.detach().clone().cuda().requires_grad_(True)
+    l, acts, _, _ = d(x, lens.cuda(), c.cuda())
+    (l * wl.cuda()).sum().backward()
+    gx = x.grad.cpu()
+    err = (gx - gr).abs() / scale
+    print('waveform: relative L2 distance of the two critic inputs %.2e' % float((x_in.detach().cpu() - xo.detach()).norm() / xo.detach().norm()))
+    print('input gradient: max |err| / max|ref| = %.4f, relative L2 %.2e' % (float(err.max()), float((gx - gr).norm() / gr.norm())))
+    under = torch.zeros(B, L, dtype=torch.bool)
+    for i, (a, b) in enumerate(zip(acts, actso)):
+        a, b = a.detach().cpu().float(), b.detach().float()
+        flip = (a > 0) != (b > 0)                    # [B, C, L_i]
+        n = int(flip.sum())
+        stride, R = 2 ** (i + 1), 3 * (2 ** (i + 1) - 1)
+        for bb, u in flip.any(1).nonzero().tolist():
+            under[bb, max(0, u * stride - R):min(L, u * stride + R + 1)] = True
+        out = err[~under]
+        print('layer %d: %6d of %8d units flipped (%.3f %%); positions under a flipped unit of layers 0..%d: %.1f %%; '
+              'max err outside them %.4f' % (i, n, flip.numel(), 100.0 * n / flip.numel(), i, 100.0 * float(under.float().mean()),
+                                             float(out.max()) if out.numel() else 0.0))
+    top = err.flatten().topk(8)
+    print('largest deviations (clip, t, err, under a flipped unit?):')
+    for v, idx in zip(top.values.tolist(), top.indices.tolist()):
+        bb, t = divmod(idx, L)
+        print('   clip %2d  t %4d  %.4f  %s  (len %d)' % (bb, t, v, bool(under[bb, t]), int(lens[bb])))
+
+
+analyse(xo, 'the critic alone: the ORACLE\'s waveform fed to both critics')
+xh = g(z=z.cuda(), c=c.cuda(), stop='never')[0]
+analyse(xh, 'end to end (what the test compares): each critic reads its own generator\'s waveform')

@@ -3,7 +3,7 @@ logic over tests/kernel_model.py (the torch model of the C ABI) under a TorchDis
 Python stack does not pass through the kernel model, grouped by the audiogan_amd source line that issued it.  Every op
 listed that touches tensor data is one (or more) device launches / graph nodes per step on the GPU.
 
-    python tools/glue_ops.py [c2|c4|c5] [small]
+    python tools/glue_ops.py [c2|c4|c5|full] [small]        (full: one pass of the reference's loop body, loop.TrainLoop)
 """
 import collections
 import os
@@ -43,7 +43,7 @@ class Log(TorchDispatchMode):
 
 
 def main():
-    wl = sys.argv[1] if len(sys.argv) > 1 and sys.argv[1] in ('c2', 'c4', 'c5') else 'c2'
+    wl = sys.argv[1] if len(sys.argv) > 1 and sys.argv[1] in ('c2', 'c4', 'c5', 'full') else 'c2'
     small = 'small' in sys.argv
 
     class MP(object):
@@ -55,6 +55,27 @@ def main():
     import audiogan_amd as A
     from audiogan_amd import train
     import bench
+    if wl == 'full':
+        from audiogan_amd import loop, optim
+        torch.set_num_threads(8)
+        dev = torch.device('cpu')
+        B = 2
+        mods, (D, h5, maxlen, gen_train, keys_train, a) = bench._full_setup(A, optim, dev, B, 'rmsprop')
+        g, d, e_g, e_d, opt_g, opt_d = mods
+        pick = loop.words_picker(D, B, maxlen, h5, keys_train, a, frame_size=bench.FRAME)
+        lp = loop.TrainLoop(g, d, e_g, e_d, opt_g, opt_d, gen_train, pick, B, maxlen, dev, fixed_critic_iter=2, gencatchup=1,
+                            stop='never', checkpoint_every=0, check=False, host=False)
+        lp.outer()
+        with Log() as lg:
+            lp.outer()
+        tot = sum(lg.rows.values())
+        print('%d aten ops outside the kernels in one eager pass of the full loop body' % tot)
+        by = collections.Counter()
+        for (where, name), n in lg.rows.items():
+            by[where] += n
+        for where, n in by.most_common(60):
+            print('%4d  %s' % (n, where))
+        return
     bench.WORKLOAD[0] = wl
     if small:
         bench.L, bench.FRAME = 1024, 256
