@@ -178,9 +178,11 @@ def test_networks_bf16_vs_rounded_oracle(K, bf16):
     # this one green points at the generator's backward, red at the critic's).
     # (1) the critic ALONE: the oracle's waveform fed to the HIP critic - same point, so the declared activation-class bound
     #     holds (measured 3.4e-3 of the largest entry, 1.3e-3 relative L2: tools/diag_bf16_xgrad.py)
+    from audiogan_amd.common import frozen
     xs = xo.detach().clone().cuda().requires_grad_(True)
-    ls = d(xs, lens.cuda(), c.cuda())[0]
-    gs, = torch.autograd.grad((ls * wl.cuda()).sum(), xs)
+    with frozen(d):          # (an input-gradient pass: the blocks' backward must not add to the weights' .grad a second time)
+        ls = d(xs, lens.cuda(), c.cuda())[0]
+        gs, = torch.autograd.grad((ls * wl.cuda()).sum(), xs)
     close_bf16(gs, xo.grad, 'd(loss)/d(waveform), same waveform', elem=1e-2, l2=3e-3)
     # (2) end to end each critic reads ITS OWN generator's waveform (2.5e-4 apart in relative L2), i.e. the two gradients are
     #     taken at different points: a LeakyReLU unit whose pre-activation is within that distance of zero takes the other
