@@ -46,6 +46,8 @@ struct ConvP {
   int s_shift;    // log2(stride) or -1
   int ncols_tile; // columns of the workgroup's tile (TT)
   int pipe;       // fp32 kernel: register-pipelined staging (see the kernel)
+  int solo;       // fp32 kernel launched with 4 waves and ONE LDS buffer: stage, multiply, stage, ... (see the kernel)
+  int dma;        // solo form, mode 1: interior tiles stage by LDS-DMA (global_load_lds) instead of through registers
   int nbuf;       // bf16 kernel: LDS buffers (1 when the whole reduction is one chunk)
   int rb;         // AG_PREC_BF16: both operands rounded to bf16 while staging (fp32 MFMA on rounded values)
   int tapoff[MAX_TAPS];
@@ -413,9 +415,38 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     }
   };
 
+  // ---- LDS-DMA staging (p.dma: solo form of a transposed conv, i.e. no polyphase de-interleave; host guarantees 16-byte
+  // aligned rows of x and of the prepared weights, chs % 16 == 0, CC % 16 == 0 and Cpad % CC == 0).  The input window of a chunk
+  // is then a plain copy of CC row segments of chs floats starting at base4 = floor4(base) - the reader adds base - base4 -
+  // and the weight panel a plain copy of CC * taps segments of OT rows: 1-KiB DMA instructions, lane-linear, no VGPR, no
+  // VALU (the register path spends ~40 VALU instructions per 16-byte piece on its index arithmetic, which is what a thin
+  // layer's short reduction cannot amortise).  A DMA cannot write zeros: tiles whose window leaves the signal (the first
+  // and the last one or two of a row) take the register path; channels beyond C read channel C - 1 (their weights are 0).
+  const int base4t = base - (((base % 4) + 4) % 4);
+  const bool dma_tile = p.dma && base4t >= 0 && base4t + chs <= a.Lin && row0 + OT <= p.Mpad;      // (uniform)
+  const int xshift = dma_tile ? base - base4t : 0;
+  auto stage_dma = [&](int c0) {
+    float* xs = smem;
+    float* ws = xs + (size_t)p.CC * chs;
+    const int npc = chs >> 2;                          // 16-byte pieces per channel
+    const int xins = (p.CC * npc) >> 6, wins = (p.CC * taps * (OT / 4)) >> 6;      // 64-piece instructions
+    for (int g = wid; g < xins; g += 4) {
+      const int e = g * 64 + lane, cc = e / npc, i4 = e - cc * npc;
+      const float* src = xb + (int64_t)min(c0 + cc, a.C - 1) * a.x_cs + base4t + 4 * i4;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(xs + g * 256), 16, 0, 0);
+    }
+    for (int g = wid; g < wins; g += 4) {
+      const int f = g * 64 + lane, ct = f / (OT / 4), r4 = f - ct * (OT / 4);
+      const float* src = a.wp + ((int64_t)c0 * taps + ct) * p.Mpad + row0 + 4 * r4;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(ws + g * 256), 16, 0, 0);
+    }
+  };
+
   // the bias of this workgroup's rows goes to LDS once (behind the two staging buffers): read per output group in
   // the epilogue it would be 16-32 dependent global loads per lane
-  float* bias_s = smem + 2 * bufsz;
+  float* bias_s = smem + (p.solo ? 1 : 2) * bufsz;
   if (tid < OT) {
     const int row = row0 + tid;
     bias_s[tid] = (a.bias && row < p.Mrows) ? a.bias[a.mode == 0 ? row : row / a.stride] : 0.f;
@@ -424,7 +455,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   // staging lane, 31-bit byte offsets): the staging waves run a register pipeline - the loads of chunk i+2 are in
   // flight while chunk i+1 is written to LDS and chunk i is multiplied.  Otherwise: generic staging, chunk 0 by all
   // 8 waves.
-  if (!p.pipe) {
+  // p.solo (thin layers: a reduction of a few short chunks, where the serial phases of a workgroup - stage, multiply, store -
+  // leave the matrix pipes idle more than half the time with only two 8-wave workgroups per CU to overlap): the launch has
+  // 4 waves and ONE buffer, every wave stages and multiplies, and FOUR workgroups share a CU.
+  if (!p.pipe && !p.solo) {
     stage(0, 0, wid, 8);
     __syncthreads();
   }
@@ -559,13 +593,22 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   for (int ci = 0; ci < nchunk; ++ci) {
-    const float* xs = smem + (ci & 1) * bufsz;
+    if (p.solo) {
+      if (dma_tile) {
+        stage_dma(ci * p.CC);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      } else {
+        stage(ci * p.CC, 0, wid, 4);
+      }
+      __syncthreads();
+    }
+    const float* xs = smem + (p.solo ? 0 : (ci & 1)) * bufsz;
     const float* ws = xs + (size_t)p.CC * chs;
     // ---- MFMA over (channel pair, tap)
     const int npair = p.CC >> 1;
     for (int cp = 0; cp < npair; ++cp) {
       const float* wrow = ws + (size_t)((2 * cp + h) * taps) * OT + wrow0 + l31;
-      const float* xrow = xs + (2 * cp + h) * chs + wcol0 + l31;
+      const float* xrow = xs + (2 * cp + h) * chs + wcol0 + l31 + xshift;
       if (TAPS > 0) {
 #pragma unroll
         for (int tau = 0; tau < TAPS; ++tau) {
@@ -796,12 +839,21 @@ static const bool g_conv_pipe = [] { const char* e = getenv("AG_CONV_PIPE"); ret
 // AG_CONV_BF16_MFMA=0 keeps the fp32-MFMA rounding emulation in bf16 mode (A/B measurements)
 static const bool g_conv_bf16_mfma = [] { const char* e = getenv("AG_CONV_BF16_MFMA"); return !(e && e[0] == '0'); }();
 
+// AG_CONV_SOLO: -1 (default) = by the heuristic of launch_cfg, 0 = never, 1 = every 128 x 128-tile fp32 launch; AG_CONV_SOLO_K:
+// largest reduction length C * taps that takes the solo form under the heuristic.  Measured at batch 64 (tools/prof_layers.py,
+// profiles/r04_conv_solo.txt; 8-wave form -> solo -> solo + DMA staging, microseconds): the generator's transposed convs forward
+// 92/88/86/72 -> 87/81/80/63 -> 88/83/84/55, its strided convs' backward-data 89/162/172 -> 83/150/139 (DMA: the same); a
+// strided conv itself (mode 0, G1.deconv backward-data) LOSES 56 -> 68, so the form is taken for mode 1 only.
+static const int g_conv_solo = [] { const char* e = getenv("AG_CONV_SOLO"); return e ? atoi(e) : -1; }();
+static const int g_conv_solo_k = [] { const char* e = getenv("AG_CONV_SOLO_K"); return e ? atoi(e) : 512; }();
+static const bool g_conv_dma = [] { const char* e = getenv("AG_CONV_DMA"); return !(e && e[0] == '0'); }();
+
 template <int TO, int TTL, int WO, int WT, int TAPS, int S0>
 static int launch_one(ConvP& p, size_t lds, dim3 grid, hipStream_t st) {
   auto kern = conv_engine_kernel<TO, TTL, WO, WT, TAPS, S0>;
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, p);
+  hipLaunchKernelGGL(kern, grid, dim3(p.solo ? 256 : 512), lds, st, p);
   AG_CHECK_LAUNCH("ag_conv1d_engine");
   return AG_OK;
 }
@@ -900,8 +952,34 @@ static int launch_cfg(ConvP& p, hipStream_t st) {
       p.pipe = 1;
     }
   }
+  // solo form (see the kernel): AG_CONV_SOLO = 1 forces it for every 128 x 128-tile launch, 0 forbids it (A/B runs);
+  // AG_CONV_DMA = 0 keeps its staging on the register path
+  p.solo = 0;
+  p.dma = 0;
+  size_t per_cs = per_c;
+  if (OT == 128 && TT == 128 && g_conv_solo != 0) {
+    const int ktot = p.Cpad * p.taps;
+    if (g_conv_solo == 1 || (a.mode == 1 && ktot <= g_conv_solo_k)) {
+      p.solo = 1;
+      p.pipe = 0;
+      if (a.mode == 1 && !p.rb && g_conv_dma && p.xvec && a.Lin % 4 == 0 && p.Cpad % 16 == 0 && p.Mpad % 4 == 0 &&
+          (((uintptr_t)a.wp) & 15) == 0) {
+        // DMA staging: row pitch a multiple of 16 floats that covers the window from floor4(base) on
+        p.dma = 1;
+        p.rowlen = ag_roundup(4 * ((p.ncols + 6) / 4), 16);
+        p.chs = p.rowlen;
+        per_cs = (size_t)(p.chs + p.taps * OT) * sizeof(float);
+        cc = (p.Cpad % 32 == 0 && 32 * per_cs <= 40 * 1024) ? 32 : 16;
+      } else {
+        cc = (int)((36 * 1024) / per_c) & ~1;          // the generic staging has no per-lane round limit
+        if (cc < 2) cc = 2;
+        if (cc > 32) cc = 32;
+        if (cc > p.Cpad) cc = p.Cpad;
+      }
+    }
+  }
   p.CC = cc;
-  const size_t lds = 2 * (size_t)cc * per_c + (size_t)OT * sizeof(float);   // two buffers + the bias of the row tile
+  const size_t lds = (p.solo ? 1 : 2) * (size_t)cc * per_cs + (size_t)OT * sizeof(float);   // buffers + the bias of the row tile
   if (lds > 160 * 1024) {
     ag_set_error("conv engine: tile needs %zu B of LDS", lds);
     return AG_ERR_UNSUPPORTED;
