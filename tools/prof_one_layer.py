@@ -3,7 +3,10 @@ import sys, torch
 sys.path.insert(0, '.')
 import audiogan_amd.kernels as K
 LAYERS = {'G1.deconv': ('convt', 128, 16, 16, 8, 4, 1024), 'G2.deconv': ('convt', 64, 32, 8, 4, 2, 2048),
-          'G4.deconv': ('convt', 32, 32, 8, 4, 2, 2048), 'G3.conv': ('conv', 49, 64, 9, 4, 4, 8192), 'G4.conv': ('conv', 81, 32, 9, 4, 4, 8192)}
+          'G4.deconv': ('convt', 32, 32, 8, 4, 2, 2048),
+          # (the same products with pad 4: every phase group of the output starts on a 16-byte boundary - is the 8-byte offset of
+          # the k8 s4 p2 layers' stores what their epilogue costs?)
+          'G2.deconv.p4': ('convt', 64, 32, 8, 4, 4, 2048), 'G4.deconv.p4': ('convt', 32, 32, 8, 4, 4, 2048), 'G3.conv': ('conv', 49, 64, 9, 4, 4, 8192), 'G4.conv': ('conv', 81, 32, 9, 4, 4, 8192)}
 B = 64
 for name in (sys.argv[1:] or ['G2.deconv', 'G4.conv']):
     kind, cin, cout, k, s, p, lin = LAYERS[name]
