@@ -100,6 +100,14 @@ extern "C" int ag_conv1d_engine(const ag_conv_args* args, void* stream) {
     return ag_conv_cfg_2114(p, st);                     // 64 x 128
   }
   if (p.n_cnt <= 64) return ag_conv_cfg_2122(p, st);   // 128 x 64
+  // Transposed convs with two tap slots (the generator's k = 2s deconvs forward: a reduction of C * 2, one or two short
+  // chunks): 128 x 64 tiles.  A launch of 128 x 128 tiles is ONE round of workgroups (1088 for 1024 slots) that all store at
+  // the same time after they all multiplied; twice as many half-width workgroups run in two rounds, and the second round's
+  // staging and MFMAs overlap the first one's stores.  Measured (profiles/r04_conv_solo.txt, microseconds, 128 x 128 solo ->
+  // 128 x 64): G1-G4.deconv forward 88 / 84 / 84 / 54 -> 78 (8-wave form) / 73 / 73 / 49 (solo); three tap slots (the strided
+  // convs' backward-data) lose 151 -> 165.  AG_CONV_HALF = 1 / 0 forces / forbids it (A/B runs).
+  static const int g_half = [] { const char* e = getenv("AG_CONV_HALF"); return e ? atoi(e) : -1; }();
+  if (a.mode == 1 && (g_half == 1 || (g_half != 0 && p.taps == 2))) return ag_conv_cfg_2122(p, st);
   // fewer than two 128x128 workgroups per CU: one MFMA wave per SIMD cannot keep the matrix pipe fed, take
   // half-width tiles (twice the workgroups, two co-resident per CU)
   // (the bf16 kernel runs one workgroup per CU and wants the full tile's reuse of the staged weights)

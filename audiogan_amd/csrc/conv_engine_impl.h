@@ -957,9 +957,10 @@ static int launch_cfg(ConvP& p, hipStream_t st) {
   p.solo = 0;
   p.dma = 0;
   size_t per_cs = per_c;
-  if (OT == 128 && TT == 128 && g_conv_solo != 0) {
+  if (OT == 128 && (TT == 128 || TT == 64) && g_conv_solo != 0) {
     const int ktot = p.Cpad * p.taps;
-    if (g_conv_solo == 1 || (a.mode == 1 && ktot <= g_conv_solo_k)) {
+    // (half-width tiles: the solo form wins up to C * taps = 128, the 8-wave form above - G1.deconv forward 78 vs 88 us)
+    if (g_conv_solo == 1 || (a.mode == 1 && ktot <= (TT == 64 ? g_conv_solo_k / 4 : g_conv_solo_k))) {
       p.solo = 1;
       p.pipe = 0;
       if (a.mode == 1 && !p.rb && g_conv_dma && p.xvec && a.Lin % 4 == 0 && p.Cpad % 16 == 0 && p.Mpad % 4 == 0 &&
