@@ -107,7 +107,8 @@ extern "C" int ag_conv1d_engine(const ag_conv_args* args, void* stream) {
   // 128 x 64): G1-G4.deconv forward 88 / 84 / 84 / 54 -> 78 (8-wave form) / 73 / 73 / 49 (solo); three tap slots (the strided
   // convs' backward-data) lose 151 -> 165.  AG_CONV_HALF = 1 / 0 forces / forbids it (A/B runs).
   static const int g_half = [] { const char* e = getenv("AG_CONV_HALF"); return e ? atoi(e) : -1; }();
-  if (a.mode == 1 && (g_half == 1 || (g_half != 0 && p.taps == 2))) return ag_conv_cfg_2122(p, st);
+  // (fp32 kernels only: the bf16-MFMA kernel's launches are 40-60 us of mostly stores and lose with half tiles, 51 -> 59 us)
+  if (a.mode == 1 && (g_half == 1 || (g_half != 0 && p.taps == 2 && !p.rb))) return ag_conv_cfg_2122(p, st);
   // fewer than two 128x128 workgroups per CU: one MFMA wave per SIMD cannot keep the matrix pipe fed, take
   // half-width tiles (twice the workgroups, two co-resident per CU)
   // (the bf16 kernel runs one workgroup per CU and wants the full tile's reuse of the staged weights)

@@ -920,7 +920,8 @@ def _work_conv(x, wp, y, K_, stride, pad, mode, *a_, **kw):
         tile = '2,1,2,2'
     else:
         tile = '2,2,2,2'
-    if mode == 1 and _cdiv(K_, stride) == 2 and rows > 64 and _os0.environ.get('AG_CONV_HALF', '-1') != '0':
+    if mode == 1 and _cdiv(K_, stride) == 2 and rows > 64 and lib.ag_get_precision() != 1 and \
+            _os0.environ.get('AG_CONV_HALF', '-1') != '0':
         tile = '2,1,2,2'         # (conv_engine.hip: two tap slots take 128 x 64 tiles)
     macs = B * O * Lout * Cc * K_ if mode == 0 else B * Cc * Lin * O * K_
     if (K_, stride) == (7, 2) and _os0.environ.get('AG_CONV_C1', '1') != '0':
