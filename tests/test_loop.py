@@ -75,6 +75,27 @@ def test_train_loop_host_logic(monkeypatch, tmp_path):
     _run(A, torch.device('cpu'), False, tmp_path, 4)
 
 
+def test_train_loop_device_scalars_match_host_scalars(monkeypatch, tmp_path):
+    """host=False (what the captured iterations run: accuracies, the reward mean and the REINFORCE baseline stay tensors, no
+    host read) against host=True on the same loader batches and random draws: same parameters up to the baseline's fp32 vs
+    float64 arithmetic"""
+    kernel_model.install(monkeypatch)
+    import audiogan_amd as A
+    res = []
+    for host in (True, False):
+        mk, mods, _ = _setup(A, torch.device('cpu'), False, tmp_path, 4)
+        torch.manual_seed(7)
+        lp = mk(fixed_critic_iter=2, gencatchup=1, stop='never', checkpoint_every=0, check=False, host=host)
+        for _ in range(2):
+            ran, rd, rg = lp.outer()
+        assert ran == 2 and lp.dis_iter == 4 and lp.gen_iter == 2
+        assert torch.is_tensor(rg['baseline']) == (not host)
+        res.append(([p.detach().clone() for m in mods for p in m.parameters()], float(rg['baseline']), float(rd['acc_d'])))
+    assert abs(res[0][1] - res[1][1]) <= 1e-6 * max(1.0, abs(res[0][1])) and res[0][2] == res[1][2]
+    for a, b in zip(res[0][0], res[1][0]):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-7)
+
+
 @pytest.mark.gpu
 def test_train_loop_at_c2_widths_gpu(tmp_path):
     """the outer loop at the C2 widths (default structs, state 1024, frame 256, 8192-sample ragged loader clips, both
