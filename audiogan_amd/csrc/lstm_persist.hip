@@ -185,24 +185,34 @@ __global__ __launch_bounds__(512) void lstm_persist_fwd_kernel(const PersistFwdP
   const int QW = ntile / NKS, q0w = ks * QW;
   bool alive = true;
 
+  // The epilogue's operands.  The pre-activations of step k + 1 are requested at the END of step k, after the flag and BEFORE the
+  // trailing gate / cell / output stores, and nothing is written at the top of the loop: the ISA of the previous form began every
+  // step with s_waitcnt vmcnt(3) ... vmcnt(0) in front of the re-initialisation of these registers, i.e. with a wait for the
+  // previous step's trailing stores to COMPLETE - the very stores that were moved behind the flag so that nobody would wait for
+  // them (profiles/r04_lstm_fwd_isa_skeleton.txt).  The time-invariant part is read once.
+  bool sv_pad = false;
+  float sv_ig = 0.f, sv_fg = 0.f, sv_gg = 0.f, sv_og = 0.f, sv_y = 0.f;
+  float pre4[4] = {0.f, 0.f, 0.f, 0.f}, cb4[4] = {0.f, 0.f, 0.f, 0.f};
+  auto load_pre = [&](int kk) {
+    if (epi) {
+      const int tt = dir == 0 ? kk : T - 1 - kk;
+      const float* pr = D.pre + ((int64_t)tt * B + em) * 4 * H + eu;
+      pre4[0] = pr[0]; pre4[1] = pr[H]; pre4[2] = pr[2 * H]; pre4[3] = pr[3 * H];
+    }
+  };
+  if (epi && D.cb) {
+    const float* cb = D.cb + (int64_t)em * 4 * H + eu;
+    cb4[0] = cb[0]; cb4[1] = cb[H]; cb4[2] = cb[2 * H]; cb4[3] = cb[3 * H];
+  }
+  load_pre(0);
   for (int k = 0; k < T; ++k) {
     const int t = dir == 0 ? k : T - 1 - k;
-    // epilogue operands first: their latency overlaps the wait and the product
-    float pre4[4] = {0.f, 0.f, 0.f, 0.f};
-    if (epi) {
-      const float* pr = D.pre + ((int64_t)t * B + em) * 4 * H + eu;
-      pre4[0] = pr[0]; pre4[1] = pr[H]; pre4[2] = pr[2 * H]; pre4[3] = pr[3 * H];
-      if (D.cb) {
-        const float* cb = D.cb + (int64_t)em * 4 * H + eu;
-        pre4[0] += cb[0]; pre4[1] += cb[H]; pre4[2] += cb[2 * H]; pre4[3] += cb[3 * H];
-      }
-    }
     f32x16 acc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-    bool sv_pad = false;
-    float sv_ig = 0.f, sv_fg = 0.f, sv_gg = 0.f, sv_og = 0.f, sv_y = 0.f;
     if (k > 0) {
+      // (polling from wave 7, which with 32-clip tiles has no epilogue loads or stores in flight for the poll's in-order
+      // s_waitcnt vmcnt(0) to retire behind, measured the same: 7.9 / 5.6 vs 8.1 / 5.5 us per step)
       if (wid == 0 && alive) {
         alive = ps_wait_flags(p.ctl, flags, ntile, (unsigned)k, lane);
         if (!alive) s_dead = 1;
@@ -260,7 +270,7 @@ __global__ __launch_bounds__(512) void lstm_persist_fwd_kernel(const PersistFwdP
       float g4[4];
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        float s = pre4[g];
+        float s = pre4[g] + cb4[g];
         if (k > 0) {
 #pragma unroll
           for (int s_ = 0; s_ < NKS; ++s_) {
@@ -296,6 +306,7 @@ __global__ __launch_bounds__(512) void lstm_persist_fwd_kernel(const PersistFwdP
       __syncthreads();
       if (tid == 0 && (int)blockIdx.x != p.ctl.mute)
         __hip_atomic_store(flags + ut, (unsigned)(k + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      load_pre(k + 1);
     }
     if (epi) {
       if (!sv_pad) {
