@@ -801,17 +801,23 @@ __global__ __launch_bounds__(512) void gfront_persist_fwd_kernel(const FrontFwdP
   const float bbias = (bwg && tid < 256) ? p.bp[bcol0 + bcl] : 0.f;
   bool alive = true;
 
-  for (int t = 0; t < T; ++t) {
-    float pre4[4] = {0.f, 0.f, 0.f, 0.f};
+  // (the pre-activations of frame t + 1 are requested at the end of frame t, after the flag and before the trailing stores, and
+  // nothing is written at the top of the loop - as in lstm_persist_fwd_kernel, where the re-initialisation of these registers made
+  // every step begin with a wait for the previous step's trailing stores)
+  float pre4[4] = {0.f, 0.f, 0.f, 0.f};
+  auto load_pre = [&](int tt) {
     if (epi) {
       if (CELL == 1) {
-        const float* pr = p.gates + ((int64_t)t * B + em) * 3 * S + eu;
+        const float* pr = p.gates + ((int64_t)tt * B + em) * 3 * S + eu;
         pre4[0] = pr[0]; pre4[1] = pr[S]; pre4[2] = pr[2 * S];
       } else {
-        const float* pr = p.gates + ((int64_t)t * B + em) * 4 * S + eu;
+        const float* pr = p.gates + ((int64_t)tt * B + em) * 4 * S + eu;
         pre4[0] = pr[0]; pre4[1] = pr[S]; pre4[2] = pr[2 * S]; pre4[3] = pr[3 * S];
       }
     }
+  };
+  load_pre(0);
+  for (int t = 0; t < T; ++t) {
     f32x16 acc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
@@ -921,6 +927,8 @@ __global__ __launch_bounds__(512) void gfront_persist_fwd_kernel(const FrontFwdP
     __syncthreads();
     if (tid == 0 && (int)blockIdx.x != p.ctl.mute)
       __hip_atomic_store(flag_h + ut, (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // this frame's pre-activations were consumed above (ig .. og hold what goes back into their place)
+    if (t + 1 < T) load_pre(t + 1);
     if (epi) {
       if (CELL == 1) {
         float* pr = p.gates + ((int64_t)t * B + em) * 3 * S + eu;
