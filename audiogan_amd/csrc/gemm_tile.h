@@ -73,6 +73,8 @@ __device__ __forceinline__ void xcd_place(int& bx, int& by, int& bz) {
 
 // TA / TB: 0 = A stored [M][K] / B stored [K][N], 1 = A stored [K][M] / B stored [N][K]   (as ag_gemm's ta / tb)
 // BM x BN: workgroup tile; TI x TJ: blocks of 32 x 32 per wave.  Dynamic LDS: 2 stages x (BM + BN) x 16 floats.
+// DBG: ablations of tools/gemm_lab.hip (LAB_DBG) - 1 = the lab's 1-D tile placement, 2 = plain-store epilogue; the library
+// instantiates DBG = 0 only.
 template <int TA, int TB, int BM, int BN, int TI, int TJ, int DBG = 0>
 __global__ __launch_bounds__((BM / (32 * TI)) * (BN / (32 * TJ)) * 64, (BM * BN >= 65536 ? 2 : 4))      // (threads, waves per SIMD)
 void gemm_tile_kernel(const GemmP p) {
